@@ -1,0 +1,223 @@
+/* pvio_hip.h -- C ABI of the MI355X-native PVIO back-end (bundle adjustment + KLT).
+ *
+ * This is the drop-in boundary (seam B3).  Everything above it is host
+ * C++ that mirrors the reference's own seams:
+ *   - pvio::BundleAdjustor::{solve, marginalize_frame, compute_reprojection_error}
+ *       reference: pvio/src/pvio/estimation/bundle_adjustor.h:29-42 (impl bundle_adjustor.cpp:63-599)
+ *   - pvio::Image::{preprocess, track_keypoints}
+ *       reference: pvio/include/pvio/pvio.h:114-133 (impl pvio-extra/src/pvio/extra/opencv_image.cpp:88-160)
+ *   - pvio::PreIntegrator::integrate
+ *       reference: pvio/src/pvio/estimation/preintegrator.cpp:84-100
+ * Everything below it is hand-written HIP for gfx950.
+ *
+ * Conventions
+ *   - plain C, POD structs, fixed-width ints, no size_t, no ownership transfer: every host buffer is
+ *     owned by the caller and only read/written during the call; device memory is owned by the ctx.
+ *   - all BA data is FP64.  Dense matrices are ROW-major (the adapter transposes Eigen's col-major).
+ *   - quaternions are stored x,y,z,w (Eigen coeffs() order, bundle_adjustor.cpp:77).
+ *   - a frame state is 16 doubles: q[4] p[3] v[3] bg[3] ba[3]; the tangent ("error state") order is
+ *     ES_Q=0, ES_P=3, ES_V=6, ES_BG=9, ES_BA=12 (estimation/state.h:29-36).
+ *   - every function returns 0 on success or a negative pvio_status; nothing throws or aborts.
+ *   - one ctx per process and per GPU; calls on one ctx are serialized by the caller (this is the
+ *     reference's threading contract: BA is never called concurrently with itself).
+ */
+#ifndef PVIO_HIP_H
+#define PVIO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PVIO_ES_SIZE 15
+#define PVIO_FRAME_STATE_DIM 16
+#define PVIO_MAX_FRAMES 32
+#define PVIO_KLT_LEVELS 4 /* maxLevel 3 -> 4 levels, opencv_image.cpp:103 with level_num()==3 */
+
+typedef enum pvio_status {
+    PVIO_OK = 0,
+    PVIO_ERR_INVALID_ARGUMENT = -1,
+    PVIO_ERR_NO_DEVICE = -2,
+    PVIO_ERR_HIP = -3,
+    PVIO_ERR_OUT_OF_MEMORY = -4,
+    PVIO_ERR_UNSUPPORTED = -5,
+    PVIO_ERR_COMM = -6
+} pvio_status;
+
+/* Ceres TerminationType values the reference's `IsSolutionUsable()` looks at (bundle_adjustor.cpp:298). */
+typedef enum pvio_termination {
+    PVIO_TERM_CONVERGENCE = 0,
+    PVIO_TERM_NO_CONVERGENCE = 1,
+    PVIO_TERM_FAILURE = 2
+} pvio_termination;
+
+typedef struct pvio_hip_ctx pvio_hip_ctx;
+typedef struct pvio_hip_image pvio_hip_image;
+
+typedef struct pvio_hip_opts {
+    int32_t device;          /* HIP device ordinal */
+    int32_t rank;            /* landmark-shard index of this process (0 when single GPU) */
+    int32_t world_size;      /* number of landmark shards / processes (1 when single GPU) */
+    int32_t use_graph;       /* 1: replay the per-iteration kernel sequence from a hipGraph */
+    int32_t reserved[4];
+} pvio_hip_opts;
+
+/* ------------------------------------------------------------------------------------------------
+ * Flat bundle-adjustment problem.  Replaces the ceres::Problem assembled at bundle_adjustor.cpp:75-242.
+ * The adapter (pvio_amd/host/bundle_adjustor.cpp) fills it from the Map in the reference's block order.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct pvio_ba_problem {
+    int32_t n_frames;              /* N: frames in the window, Map index order                         */
+    int32_t n_landmarks;           /* M: inverse-depth parameter blocks (VALID non-PLANE tracks, :91-103)*/
+    int32_t n_obs;                 /* F: reprojection residual blocks = non-anchor observations (:142-161)*/
+    int32_t use_inertial;          /* solve(..., use_inertial) (:63)                                     */
+
+    /* per frame */
+    const uint8_t *frame_fixed;    /* [N]   FF_FIX_POSE: q,p blocks constant (:79-82)                   */
+    const double *cam_extrinsic;   /* [N][7] frame->camera: q_cs(xyzw) p_cs                              */
+    const double *imu_extrinsic;   /* [N][7] frame->imu                                                  */
+    const double *sqrt_inv_cov;    /* [N][4] frame->sqrt_inv_cov, 2x2 row-major (core.cpp:114-116)       */
+    const double *intrinsics;      /* [N][4] fx fy cx cy of frame->K (quality pass, :277-296)            */
+
+    /* landmarks, CSR over their non-anchor observations; anchor = track->first_keypoint()              */
+    const int32_t *lm_anchor_frame;/* [M]                                                                */
+    const double *lm_anchor_z;     /* [M][2] normalized keypoint in the anchor frame                     */
+    const int32_t *lm_obs_ptr;     /* [M+1]                                                              */
+    const int32_t *obs_frame;      /* [F]   target frame index                                           */
+    const double *obs_z;           /* [F][2] normalized keypoint in the target frame                     */
+
+    /* IMU pre-integration factors; entry j couples frame j-1 -> j; entry 0 unused (:220-242)            */
+    const uint8_t *preint_valid;   /* [N]                                                                */
+    const double *preint_delta;    /* [N][11] dt, dq(xyzw), dp, dv (PreIntegrator::Delta)                */
+    const double *preint_sqrt_inv_cov; /* [N][225] 15x15 row-major                                       */
+    const double *preint_jacobian; /* [N][45] dq_dbg dp_dbg dp_dba dv_dbg dv_dba, 3x3 row-major each     */
+
+    /* marginalization prior (:126-139); prior_n == 0 when Map has no marginalization factor             */
+    int32_t prior_n;               /* n: frames the prior relates                                        */
+    int32_t n_plane_factors;       /* P: AugmentedPlaneDistanceErrorCost blocks (:180-195)               */
+    const int32_t *prior_frames;   /* [n] window index of each related frame                             */
+    const double *prior_S;         /* [15n][15n] row-major sqrt-information matrix                       */
+    const double *prior_s;         /* [15n]     sqrt-information vector                                   */
+    const double *prior_lin_state; /* [n][16]   pose_0/motion_0 captured at construction                 */
+
+    /* plane-distance factors, CSR over ALL observations of the track (anchor included)                  */
+    const int32_t *plane_obs_ptr;  /* [P+1]                                                              */
+    const int32_t *plane_obs_frame;/* [..]                                                               */
+    const double *plane_obs_z;     /* [..][2]                                                            */
+    const double *plane_normal;    /* [P][3] constant block                                              */
+    const double *plane_distance;  /* [P]    constant block                                              */
+    double plane_sqrt_inv_cov;     /* sqrt(1/config->plane_distance_cov()) (:181)                        */
+
+    /* solver options (solver_options.h:26-33); everything else is a Ceres 1.14 default                   */
+    int32_t max_iterations;        /* config->solver_iteration_limit()                                   */
+    int32_t reserved0;
+    double max_solver_time;        /* config->solver_time_limit() [s]                                    */
+} pvio_ba_problem;
+
+/* In/out states, updated in place exactly like Frame::pose/motion and Track::landmark.inv_depth. */
+typedef struct pvio_ba_state {
+    double *frame_state;           /* [N][16] */
+    double *lm_inv_depth;          /* [M]     */
+    /* post-solve pass (:277-296); either may be NULL */
+    double *lm_quality;            /* [M] mean pixel reprojection error; untouched when the landmark is invalidated */
+    uint8_t *lm_valid;             /* [M] 0 when the depth gate (z<=1e-3 or z>50) cleared TF_VALID */
+} pvio_ba_state;
+
+typedef struct pvio_ba_iteration {
+    int32_t iteration;
+    int32_t step_is_valid;
+    int32_t step_is_successful;
+    int32_t reserved;
+    double cost;                   /* cost of the accepted point after this iteration (candidate cost if rejected) */
+    double cost_change;
+    double gradient_max_norm;
+    double step_norm;
+    double relative_decrease;
+    double trust_region_radius;    /* radius after the iteration */
+    double mu;                     /* Dogleg regularization multiplier after the iteration */
+} pvio_ba_iteration;
+
+typedef struct pvio_ba_summary {
+    int32_t termination;           /* pvio_termination */
+    int32_t is_usable;             /* == ceres::Solver::Summary::IsSolutionUsable() */
+    int32_t num_iterations;        /* trust-region iterations executed (iteration 0 excluded) */
+    int32_t num_successful_steps;
+    double initial_cost;
+    double final_cost;
+    double solve_seconds;          /* wall time inside the call */
+    double device_seconds;         /* hipEvent time of the kernel sequence only */
+    int32_t trace_capacity;        /* in: entries available in `trace` (0 allowed) */
+    int32_t trace_len;             /* out */
+    pvio_ba_iteration *trace;      /* optional per-iteration records (iteration 0 first) */
+    double *trace_states;          /* optional [trace_capacity][N*16+M] states after each iteration */
+} pvio_ba_summary;
+
+/* New marginalization prior produced by marginalize_frame (:583-598). */
+typedef struct pvio_ba_prior {
+    int32_t n;                     /* out: number of remaining frames (N-1) */
+    int32_t reserved;
+    double *S;                     /* [15n][15n] row-major, caller-allocated for n = N-1 */
+    double *s;                     /* [15n] */
+    double *info_matrix;           /* optional [15n][15n]: the Schur complement before the eigendecomposition */
+    double *info_vector;           /* optional [15n] */
+} pvio_ba_prior;
+
+int32_t pvio_hip_create(const pvio_hip_opts *opts, pvio_hip_ctx **out);
+void pvio_hip_destroy(pvio_hip_ctx *ctx);
+const char *pvio_hip_last_error(const pvio_hip_ctx *ctx);
+const char *pvio_hip_version(void);
+
+/* replaces BundleAdjustor::solve (bundle_adjustor.cpp:63-299) */
+int32_t pvio_hip_ba_solve(pvio_hip_ctx *ctx, const pvio_ba_problem *problem, pvio_ba_state *state,
+                          pvio_ba_summary *summary);
+
+/* replaces BundleAdjustor::marginalize_frame (bundle_adjustor.cpp:348-599) */
+int32_t pvio_hip_ba_marginalize(pvio_hip_ctx *ctx, const pvio_ba_problem *problem,
+                                const pvio_ba_state *state, int32_t victim, pvio_ba_prior *out);
+
+/* replaces BundleAdjustor::compute_reprojection_error (bundle_adjustor.cpp:321-336) */
+int32_t pvio_hip_ba_reprojection_error(pvio_hip_ctx *ctx, const pvio_ba_problem *problem,
+                                       const pvio_ba_state *state, double *mean_pixel_error);
+
+/* Device-resident variant used by bench.py / multi-GPU: upload once, solve repeatedly from the same
+ * initial state without re-uploading (inputs resident in HBM when the timed region starts). */
+int32_t pvio_hip_ba_upload(pvio_hip_ctx *ctx, const pvio_ba_problem *problem, const pvio_ba_state *state);
+int32_t pvio_hip_ba_solve_resident(pvio_hip_ctx *ctx, pvio_ba_summary *summary);
+int32_t pvio_hip_ba_download(pvio_hip_ctx *ctx, pvio_ba_state *state);
+
+/* multi-GPU (landmark shards, one process per GPU): RCCL communicator bootstrap.
+ * rank 0 creates the 128-byte unique id, the launcher broadcasts it (torch.distributed), every rank inits. */
+int32_t pvio_hip_comm_unique_id(uint8_t id[128]);
+int32_t pvio_hip_comm_init(pvio_hip_ctx *ctx, const uint8_t id[128], int32_t rank, int32_t world_size);
+
+/* replaces PreIntegrator::integrate(t, bg, ba, true, true) (preintegrator.cpp:84-100); host-side, serial. */
+typedef struct pvio_imu_noise {
+    double cov_w[9], cov_a[9], cov_bg[9], cov_ba[9]; /* 3x3 row-major, continuous-time */
+} pvio_imu_noise;
+int32_t pvio_preintegrate(int32_t n_samples, const double *imu_t, const double *imu_w, const double *imu_a,
+                          double t_end, const double bg[3], const double ba[3], const pvio_imu_noise *noise,
+                          double delta[11], double cov[225], double sqrt_inv_cov[225], double jacobian[45]);
+
+/* ------------------------------------------------------------------------------------------------
+ * KLT front end.  Replaces OpenCvImage::preprocess / track_keypoints.
+ * ---------------------------------------------------------------------------------------------- */
+/* upload + CLAHE(6.0, 8x8) + 4-level pyramid + Scharr derivatives, all on device (opencv_image.cpp:138-145) */
+int32_t pvio_hip_image_create(pvio_hip_ctx *ctx, const uint8_t *pixels, int32_t width, int32_t height,
+                              int32_t stride, int32_t apply_clahe, pvio_hip_image **out);
+void pvio_hip_image_release(pvio_hip_ctx *ctx, pvio_hip_image *img);
+/* copy a pyramid level back (tests): level l image u8 [h_l][w_l] and/or derivatives int16 [h_l][w_l][2] */
+int32_t pvio_hip_image_download_level(pvio_hip_ctx *ctx, const pvio_hip_image *img, int32_t level,
+                                      uint8_t *pixels, int16_t *deriv, int32_t *w, int32_t *h);
+
+/* pyramidal LK, win 21x21, levels 3..0, <=30 iterations, eps 0.01, minEigThreshold 1e-4,
+ * OPTFLOW_USE_INITIAL_FLOW, followed by the 20-px border kill (opencv_image.cpp:103-109).
+ * next_xy is in/out (initial guess in, tracked position out; failed tracks keep their last estimate).
+ * The F-matrix RANSAC (:121-129) stays on the host adapter. */
+int32_t pvio_hip_klt_track(pvio_hip_ctx *ctx, const pvio_hip_image *prev, const pvio_hip_image *next,
+                           int32_t n, const float *prev_xy, float *next_xy, uint8_t *status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PVIO_HIP_H */

@@ -1,0 +1,133 @@
+"""ctypes loader for the CPU oracle (oracle/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+The product package (pvio_amd/) never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from pvio_amd import capi  # noqa: E402  (struct layouts only)
+
+LIB = os.path.join(HERE, "liboracle.so")
+dp = capi.c_double_p
+
+
+def build(force=False):
+    srcs = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith((".cpp", ".h"))]
+    srcs.append(os.path.join(HERE, "..", "include", "pvio_hip.h"))
+    if force or not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in srcs if os.path.exists(s)):
+        subprocess.check_call(["make", "-s", "-C", HERE, "liboracle.so"])
+    return LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            build()
+        _lib = C.CDLL(LIB)
+        L = _lib
+        L.oracle_ba_solve.argtypes = [C.POINTER(capi.BAProblemC), C.POINTER(capi.BAStateC), C.POINTER(capi.BASummaryC)]
+        L.oracle_ba_linearize.argtypes = [C.POINTER(capi.BAProblemC), dp, dp, dp, dp, dp, dp, dp, dp, capi.c_int32_p, capi.c_int32_p]
+        L.oracle_ba_cost.argtypes = [C.POINTER(capi.BAProblemC), dp, dp, dp, dp]
+        L.oracle_ba_reprojection_error.argtypes = [C.POINTER(capi.BAProblemC), C.POINTER(capi.BAStateC), dp]
+        L.oracle_ba_marginalize.argtypes = [C.POINTER(capi.BAProblemC), C.POINTER(capi.BAStateC), C.c_int32, C.POINTER(capi.BAPriorC)]
+        L.oracle_preintegrate.argtypes = [C.c_int32, dp, dp, dp, C.c_double, dp, dp, C.POINTER(capi.ImuNoiseC), dp, dp, dp, dp]
+        L.oracle_eval_reprojection.argtypes = [dp, dp, C.c_double, dp, dp, dp, dp, dp, dp, dp]
+        L.oracle_eval_reprojection.restype = None
+        L.oracle_eval_preintegration.argtypes = [dp] * 10
+        L.oracle_eval_preintegration.restype = None
+        L.oracle_eval_prior.argtypes = [C.c_int32, dp, dp, dp, dp, dp, dp]
+        L.oracle_eval_prior.restype = None
+        L.oracle_eval_plane.argtypes = [C.c_int32, dp, dp, dp, dp, C.c_double, C.c_double, dp, dp]
+        L.oracle_eval_plane.restype = None
+        L.oracle_plus.argtypes = [dp, dp, dp]
+        L.oracle_plus.restype = None
+        for n in ("oracle_expmap", "oracle_logmap", "oracle_right_jacobian"):
+            getattr(L, n).argtypes = [dp, dp]
+            getattr(L, n).restype = None
+    return _lib
+
+
+def _d(a):
+    return None if a is None else a.ctypes.data_as(dp)
+
+
+def f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def noise_c(nd):
+    nz = capi.ImuNoiseC()
+    for k in ("cov_w", "cov_a", "cov_bg", "cov_ba"):
+        getattr(nz, k)[:] = list(np.asarray(nd[k], float).ravel())
+    return nz
+
+
+def preintegrate(t, w, a, t_end, bg, ba, noise):
+    t, w, a, bg, ba = f64(t), f64(w), f64(a), f64(bg), f64(ba)
+    delta, cov, U, jac = np.zeros(11), np.zeros(225), np.zeros(225), np.zeros(45)
+    nz = noise_c(noise)
+    rc = lib().oracle_preintegrate(len(t), _d(t), _d(w), _d(a), float(t_end), _d(bg), _d(ba), C.byref(nz), _d(delta), _d(cov), _d(U), _d(jac))
+    assert rc == 0
+    return delta, cov, U, jac
+
+
+def solve(problem, state, summary):
+    pb, st = problem.as_c(), state.as_c()
+    rc = lib().oracle_ba_solve(C.byref(pb), C.byref(st), C.byref(summary.c))
+    assert rc == 0
+    return summary
+
+
+def linearize(problem, frame_state, rho):
+    pb = problem.as_c()
+    N, M = problem.n_frames, problem.n_landmarks
+    fs, rho = f64(frame_state), f64(rho)
+    po, mo = np.zeros(N, np.int32), np.zeros(N, np.int32)
+    P = lib().oracle_ba_linearize(C.byref(pb), _d(fs), _d(rho), None, None, None, None, None, None,
+                                  po.ctypes.data_as(capi.c_int32_p), mo.ctypes.data_as(capi.c_int32_p))
+    cost = np.zeros(1)
+    Hpp, gp, Hll, bl, W = np.zeros((P, P)), np.zeros(P), np.zeros(M), np.zeros(M), np.zeros((M, P))
+    lib().oracle_ba_linearize(C.byref(pb), _d(fs), _d(rho), _d(cost), _d(Hpp), _d(gp), _d(Hll), _d(bl), _d(W),
+                              po.ctypes.data_as(capi.c_int32_p), mo.ctypes.data_as(capi.c_int32_p))
+    return dict(cost=cost[0], Hpp=Hpp, gp=gp, Hll=Hll, bl=bl, W=W, pose_off=po, motion_off=mo, P=P)
+
+
+def cost(problem, frame_state, rho, user=None):
+    pb = problem.as_c()
+    fs, rho = f64(frame_state), f64(rho)
+    u = f64(user) if user is not None else fs
+    c = np.zeros(1)
+    lib().oracle_ba_cost(C.byref(pb), _d(fs), _d(rho), _d(u), _d(c))
+    return c[0]
+
+
+def marginalize(problem, state, victim, want_info=True):
+    pb, st = problem.as_c(), state.as_c()
+    n = problem.n_frames - 1
+    S, s = np.zeros((15 * n, 15 * n)), np.zeros(15 * n)
+    IM, iv = np.zeros((15 * n, 15 * n)), np.zeros(15 * n)
+    pr = capi.BAPriorC()
+    pr.S, pr.s = _d(S), _d(s)
+    if want_info:
+        pr.info_matrix, pr.info_vector = _d(IM), _d(iv)
+    rc = lib().oracle_ba_marginalize(C.byref(pb), C.byref(st), int(victim), C.byref(pr))
+    assert rc == 0
+    return S, s, IM, iv
+
+
+def reprojection_error(problem, state):
+    pb, st = problem.as_c(), state.as_c()
+    out = np.zeros(1)
+    lib().oracle_ba_reprojection_error(C.byref(pb), C.byref(st), _d(out))
+    return out[0]
