@@ -104,9 +104,15 @@ def _pose(t):
 
 
 def make_window(n_frames=10, n_landmarks=1000, use_inertial=False, visibility=None, plane_fraction=0.0,
-                seed=SEED, preintegrate=None, kf_dt=0.25, imu_rate=200.0, perturb=True, max_iterations=10):
+                seed=SEED, preintegrate=None, kf_dt=0.25, imu_rate=200.0, perturb=True, max_iterations=10,
+                bias_init="near_truth", perturb_scale=None):
     """Builds a BAProblem.  `preintegrate(t, w, a, t_end, bg, ba, noise_dict) -> (delta11, cov225, U225, jac45)`
-    is required when use_inertial (the product's pvio_preintegrate or the oracle's)."""
+    is required when use_inertial (the product's pvio_preintegrate or the oracle's).
+
+    bias_init: "near_truth" (default; truth + N(0, 1e-5 rad/s / 1e-4 m/s^2), what a steady-state window holds)
+    or "zero" (SURVEY 8d's original choice).  With "zero" the reference's live-bias read
+    (preintegration_error_cost.h:57-58 + update_state_every_iteration) makes every step after the first accepted
+    one see a different cost function and get rejected -- kept as a parity case, not as the benchmark."""
     N, M = n_frames, n_landmarks
     rng = Rng(seed)
     pb = BAProblem(N)
@@ -205,6 +211,10 @@ def make_window(n_frames=10, n_landmarks=1000, use_inertial=False, visibility=No
         pb.plane_sqrt_inv_cov = np.sqrt(1.0 / 1.0e-4)  # pvio-pc/config/euroc.yaml plane.noise
 
     # IMU
+    bias_guess = np.zeros((N, 6))
+    if use_inertial and bias_init == "near_truth":
+        bias_guess[:, :3] = bg_true + rng.normal(3 * N).reshape(N, 3) * 1e-5
+        bias_guess[:, 3:] = ba_true + rng.normal(3 * N).reshape(N, 3) * 1e-4
     if use_inertial:
         assert preintegrate is not None, "use_inertial needs a preintegrate callable"
         dt_imu = 1.0 / imu_rate
@@ -222,8 +232,8 @@ def make_window(n_frames=10, n_landmarks=1000, use_inertial=False, visibility=No
                 R, _, _, acc = _pose(ts[k] + 0.5 * dt_imu)
                 w[k] = np.array([OMEGA, 0.0, 0.0]) + bg_true + nw[k]  # body x = world z
                 a[k] = R.T @ (acc + np.array([0, 0, GRAVITY])) + ba_true + na[k]
-            # integrated at the INITIAL-GUESS biases of frame j-1 (zeros), as solve() does at :224
-            delta, cov, U, jac = preintegrate(ts, w, a, j * kf_dt, np.zeros(3), np.zeros(3), noise_d)
+            # integrated at the INITIAL-GUESS biases of frame j-1, as solve() does at :224
+            delta, cov, U, jac = preintegrate(ts, w, a, j * kf_dt, bias_guess[j - 1, :3], bias_guess[j - 1, 3:], noise_d)
             pb.preint_valid[j] = 1
             pb.preint_delta[j] = delta
             pb.preint_sqrt_inv_cov[j] = U
@@ -235,17 +245,21 @@ def make_window(n_frames=10, n_landmarks=1000, use_inertial=False, visibility=No
     init = truth.copy()
     rho0 = pb.truth_inv_depth.copy()
     if perturb:
-        rot = rng.normal(3 * N).reshape(N, 3) * np.deg2rad(0.5)
-        pos = rng.normal(3 * N).reshape(N, 3) * 0.02
-        vel = rng.normal(3 * N).reshape(N, 3) * 0.02
+        # vision-only: 0.5 deg / 2 cm / 5 %.  VIO: one tenth of that by default -- a steady-state
+        # window starts from the previous optimum + an IMU-predicted new frame, and the pre-integration factors
+        # are ~100x tighter than 2 cm over 0.25 s.
+        ps_ = perturb_scale if perturb_scale is not None else (0.1 if use_inertial else 1.0)
+        rot = rng.normal(3 * N).reshape(N, 3) * np.deg2rad(0.5) * ps_
+        pos = rng.normal(3 * N).reshape(N, 3) * 0.02 * ps_
+        vel = rng.normal(3 * N).reshape(N, 3) * 0.02 * ps_
         first = 0 if use_inertial else 1
         for i in range(first, N):
             init[i, 0:4] = qmul(truth[i, 0:4], qexp(rot[i]))
             init[i, 0:4] /= np.linalg.norm(init[i, 0:4])
             init[i, 4:7] += pos[i]
             init[i, 7:10] += vel[i]
-        rho0 = rho0 * (1.0 + 0.05 * rng.normal(Ml))
-    init[:, 10:16] = 0.0
+        rho0 = rho0 * (1.0 + 0.05 * ps_ * rng.normal(Ml))
+    init[:, 10:16] = bias_guess
     if not use_inertial:
         init[:, 7:10] = 0.0
         pb.frame_fixed[0] = 1  # initializer.cpp:199: frame 0 FF_FIX_POSE for the visual BA
