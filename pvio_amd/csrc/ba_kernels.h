@@ -1,0 +1,18 @@
+// ba_kernels.h -- host-callable launchers of the bundle-adjustment kernels (ba_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "ba_types.h"
+
+namespace pvba {
+size_t linearize_lds_bytes(const Dims &dm);
+size_t dense_lds_bytes(const Dims &dm, int *lds_matrix);
+int tiles_per_thread(const Dims &dm);
+hipError_t launch_linearize(const View &v, hipStream_t st);
+hipError_t launch_reduce(const View &v, hipStream_t st);
+hipError_t launch_dense(const View &v, hipStream_t st);
+hipError_t launch_backsub(const View &v, hipStream_t st);
+hipError_t launch_back_reduce(const View &v, hipStream_t st);
+hipError_t launch_quality(const View &v, hipStream_t st, int buf_from_ctrl, double *err_sum);
+hipError_t launch_prior_prep(const double *S, const double *s, int D, double *Lambda, double *eta, hipStream_t st);
+} // namespace pvba

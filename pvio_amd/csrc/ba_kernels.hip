@@ -1,0 +1,1260 @@
+// ba_kernels.hip -- gfx950 kernels of the sliding-window bundle adjustment.
+//
+// Per trust-region iteration four launches, no host round trip (the whole state machine is in pvba::Ctrl):
+//
+//   k_linearize  (many WGs)  dogleg step + candidate point (every WG redundantly, tiny) ->
+//                            per-factor residual/Jacobian (one thread per reprojection factor, frame records in LDS) ->
+//                            per-landmark H_ll, b_l, W_l (LDS segmented sums) ->
+//                            LDS-staged J^T J / Schur tile accumulation: every thread owns 3x3 tiles of the
+//                            6N x 6N reduced pose system in REGISTERS across all its landmark chunks
+//                            (output-stationary, no atomics, deterministic) -> one partial per WG.
+//                            Extra WG roles in the same launch: plane-distance factors, IMU pre-integration
+//                            factors, marginalization prior.
+//   k_reduce     (many WGs)  fixed-order sum of the WG partials -> [S | vectors | scalars] (the all-reduce payload
+//                            when landmark blocks are sharded across GPUs).
+//   k_dense      (1 WG)      accept/reject + radius/mu update (Ceres 1.14 semantics), assemble the Jacobi-scaled
+//                            reduced system, Cholesky (+ forward substitution as an augmented row), wave-level back
+//                            substitution, pose parts of every dogleg scalar.
+//   k_backsub    (<=64 WGs)  landmark back-substitution + landmark parts of the dogleg scalars.
+//
+// The linearization of the candidate is SPECULATIVE: the cost pass Ceres needs anyway and the Jacobian pass it
+// would run after accepting share one evaluation; a rejected step just discards the speculative set.
+//
+// Reference being replaced: BundleAdjustorSolver::solve -> ceres::Solve (bundle_adjustor.cpp:63-299,
+// solver_options.h:26-33); factor math in pv_factors.h.
+#include <hip/hip_runtime.h>
+
+#include <float.h>
+
+#include "ba_kernels.h"
+#include "pv_factors.h"
+
+namespace pvba {
+
+using namespace pv;
+
+// ------------------------------------------------------------------------------------------------------
+// small reductions
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    return v;
+}
+// sums NV values over the block; result valid in every thread.  scratch: NV * 16 doubles of LDS.
+template <int NV, bool MAX_LAST = false>
+__device__ __forceinline__ void block_sum(double *vals, double *scratch) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const double r = (MAX_LAST && k == NV - 1) ? wave_max(vals[k]) : wave_sum(vals[k]);
+        if (lane == 0) scratch[k * 16 + wv] = r;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        double r = scratch[k * 16];
+        for (int w = 1; w < nw; ++w) r = (MAX_LAST && k == NV - 1) ? fmax(r, scratch[k * 16 + w]) : r + scratch[k * 16 + w];
+        vals[k] = r;
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------------
+// k_linearize
+// ------------------------------------------------------------------------------------------------------
+struct Pro { // prologue result, one copy in LDS per WG
+    int mode, cur, lin, out_set, eval_buf, valid;
+    double mu_schur, ca, cb;
+};
+
+// LDS carve (doubles) common to every role: [est N*16][frec N*28][scratch 160][pro 16]
+__device__ __forceinline__ int common_lds_doubles(int N) { return N * 16 + N * kFrameRec + 160 + 16; }
+
+__device__ void lin_prologue(const View &v, double *lds, Pro *&pro_out) {
+    const int N = v.dm.N, d = v.dm.d, tid = threadIdx.x;
+    double *est = lds, *frec = lds + N * 16, *scratch = frec + N * kFrameRec;
+    Pro *pro = reinterpret_cast<Pro *>(scratch + 160);
+    pro_out = pro;
+    const Ctrl *c = v.ctrl;
+    const int mode = c->mode, cur = c->cur, lin = c->lin;
+    if (tid == 0) {
+        pro->mode = mode, pro->cur = cur, pro->lin = lin;
+        pro->valid = 1;
+        pro->ca = 0, pro->cb = 0;
+        pro->out_set = (mode == MODE_CANDIDATE) ? 1 - lin : lin;
+        pro->eval_buf = (mode == MODE_CANDIDATE) ? 1 - cur : cur;
+        pro->mu_schur = (mode == MODE_CANDIDATE) ? fmax(1e-8, 2.0 * c->mu / 10.0) : c->mu; // StepAccepted's mu, assumed
+    }
+    if (mode == MODE_CANDIDATE) {
+        // ---- DoglegStrategy::ComputeTraditionalDoglegStep on the scalars of the accepted linearization ----
+        if (tid < 64) {
+            double b[6] = {0, 0, 0, 0, 0, 0};
+            if (tid < v.dm.n_back_rows)
+                for (int k = 0; k < 6; ++k) b[k] = v.back_part[tid * kNumBackScal + k];
+            for (int k = 0; k < 6; ++k) b[k] = wave_sum(b[k]);
+            if (tid == 0) {
+                const double g2 = c->pose_g2 + c->lm_g2, gn2 = c->pose_gn2 + b[0], gdot = c->pose_gdot + b[1];
+                const double qvv = c->pose_qvv + b[2], qvy = c->pose_qvy + b[3], qyy = c->pose_qyy + b[4], gy = c->pose_gy + b[5];
+                const double radius = c->radius;
+                const double gradient_norm = sqrt(g2), gauss_newton_norm = sqrt(gn2);
+                const double alpha = g2 / qvv; // |g^|^2 / |J (g^/D)|^2
+                double ca, cb, sn;
+                if (gauss_newton_norm <= radius) {
+                    ca = 0.0, cb = 1.0, sn = gauss_newton_norm;
+                } else if (gradient_norm * alpha >= radius) {
+                    ca = -(radius / gradient_norm), cb = 0.0, sn = radius;
+                } else {
+                    const double b_dot_a = -alpha * gdot;
+                    const double a_squared_norm = (alpha * gradient_norm) * (alpha * gradient_norm);
+                    const double b_minus_a_squared_norm = a_squared_norm - 2 * b_dot_a + gn2;
+                    const double cc = b_dot_a - a_squared_norm;
+                    const double dd = sqrt(cc * cc + b_minus_a_squared_norm * (radius * radius - a_squared_norm));
+                    const double beta = (cc <= 0) ? (dd - cc) / b_minus_a_squared_norm : (radius * radius - a_squared_norm) / (dd + cc);
+                    ca = -alpha * (1.0 - beta), cb = beta;
+                    sn = sqrt(ca * ca * g2 + 2 * ca * cb * gdot + cb * cb * gn2);
+                }
+                // model_cost_change = -(J step)^T (r + J step / 2) = -(g_s^T step + step^T H_s step / 2), step = ca v + cb y'
+                const double gs = ca * g2 + cb * gy;
+                const double q = ca * ca * qvv + 2 * ca * cb * qvy + cb * cb * qyy;
+                const double mcc = -(gs + 0.5 * q);
+                pro->ca = ca, pro->cb = cb;
+                pro->valid = (mcc > 0.0) ? 1 : 0;
+                if (blockIdx.x == 0) {
+                    Ctrl *cw = v.ctrl;
+                    cw->ca = ca, cw->cb = cb, cw->dogleg_step_norm = sn, cw->model_cost_change = mcc;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- evaluation-point frame states (candidate = x (+) delta) -----------------------------------
+    const double ca = pro->ca, cb = pro->cb;
+    double step2 = 0, norm2 = 0;
+    if (tid < N) {
+        const double *x = v.fs + ((size_t)cur * N + tid) * 16;
+        double *y = est + tid * 16;
+        for (int k = 0; k < 16; ++k) y[k] = x[k];
+        if (mode == MODE_CANDIDATE && pro->valid) {
+            const double *vs = v.vstep + tid * d, *ys = v.ystep + tid * d;
+            if (v.pose_active[tid]) {
+                double dl[6];
+                for (int k = 0; k < 6; ++k) dl[k] = ca * vs[k] + cb * ys[k];
+                pose_plus(y, x, dl, dl + 3);
+            }
+            if (v.motion_active[tid] && d == 15)
+                for (int k = 0; k < 9; ++k) y[7 + k] = x[7 + k] + (ca * vs[6 + k] + cb * ys[6 + k]);
+            if (v.pose_active[tid])
+                for (int k = 0; k < 7; ++k) step2 += (y[k] - x[k]) * (y[k] - x[k]), norm2 += y[k] * y[k];
+            if (v.motion_active[tid])
+                for (int k = 7; k < 16; ++k) step2 += (y[k] - x[k]) * (y[k] - x[k]), norm2 += y[k] * y[k];
+            if (blockIdx.x == 0) {
+                double *out = v.fs + ((size_t)(1 - cur) * N + tid) * 16;
+                for (int k = 0; k < 16; ++k) out[k] = y[k];
+            }
+        } else {
+            if (v.pose_active[tid])
+                for (int k = 0; k < 7; ++k) norm2 += y[k] * y[k];
+            if (v.motion_active[tid])
+                for (int k = 7; k < 16; ++k) norm2 += y[k] * y[k];
+        }
+        frame_record(frec + tid * kFrameRec, y, v.cam_ext + 7 * tid, v.sic + 4 * tid);
+    }
+    if (tid < 64) { // N <= 32 < 64: wave 0 holds all frame partials
+        step2 = wave_sum(step2), norm2 = wave_sum(norm2);
+        if (tid == 0 && blockIdx.x == 0) {
+            Ctrl *cw = v.ctrl;
+            cw->cand_step2_pose = step2, cw->cand_norm2_pose = norm2;
+            cw->lin_result = !pro->valid ? LIN_INVALID_STEP : (mode == MODE_INIT ? LIN_INIT : (mode == MODE_CANDIDATE ? LIN_CANDIDATE : LIN_RELIN));
+        }
+    }
+    __syncthreads();
+}
+
+// One 3x3 tile task = rows 6 fi + 3 si .., cols 6 fj + 3 sj .. of the pose system (fi <= fj).
+__device__ __forceinline__ void unpack_task(int t, int &fi, int &fj, int &si, int &sj) {
+    fi = t & 255, fj = (t >> 8) & 255, si = (t >> 16) & 1, sj = (t >> 17) & 1;
+}
+
+// per-landmark LDS record (doubles): U[6N] JT[12N] JR[12N] GT[6N] FD[4N] HAA[36] GA[6] SC[4]
+__device__ __forceinline__ int lm_rec_doubles(int N) { return 40 * N + 46; }
+
+template <int T>
+__device__ void role_landmarks(const View &v, double *lds, const Pro *pro, int wg, int n_wg) {
+    const int N = v.dm.N, M = v.dm.M, P6 = v.dm.P6, tid = threadIdx.x, n_tasks = v.dm.n_tasks;
+    const double *frec = lds + N * 16;
+    double *scratch = lds + N * 16 + N * kFrameRec;
+    double *chunk = lds + common_lds_doubles(N);
+    const int rec = lm_rec_doubles(N), slots = v.dm.lm_slots;
+    double *rho_eval = chunk + (size_t)slots * rec; // [slots]
+    int *anch = reinterpret_cast<int *>(rho_eval + slots);
+    const int mode = pro->mode, cur = pro->cur, lin = pro->lin, oset = pro->out_set;
+    const double mu = pro->mu_schur, ca = pro->ca, cb = pro->cb;
+    const size_t Ms = (size_t)M, Fs = (size_t)v.dm.F;
+    double *o_Hll = v.Hll + oset * Ms, *o_bl = v.bl + oset * Ms, *o_Dl = v.Dl + oset * Ms, *o_ghl = v.ghl + oset * Ms;
+    double *o_Wa = v.Wa + oset * Ms * 6, *o_Wt = v.Wt + oset * Fs * 6;
+    const double *i_Dl = v.Dl + lin * Ms, *i_ghl = v.ghl + lin * Ms, *i_gnl = v.gnl + lin * Ms;
+    const double *rho_cur = v.rho + cur * Ms;
+    double *rho_cand = v.rho + (1 - cur) * Ms;
+
+    int tfi[T], tfj[T], tsi[T], tsj[T];
+    double acc[T][9];
+#pragma unroll
+    for (int k = 0; k < T; ++k) {
+        const int t = k * kLinThreads + tid;
+        int d = (t < n_tasks) ? v.task_desc[t] : 0;
+        unpack_task(d, tfi[k], tfj[k], tsi[k], tsj[k]);
+#pragma unroll
+        for (int e = 0; e < 9; ++e) acc[k][e] = 0.0;
+    }
+    double vg = 0, vrhs = 0, vdiag = 0;                         // vector tasks (tid < P6)
+    double s_cost = 0, s_g2 = 0, s_step2 = 0, s_norm2 = 0, s_bad = 0, s_bmax = 0; // scalars
+
+    for (int ck = wg; ck < v.dm.n_chunks; ck += n_wg) {
+        const int l0 = v.chunk_lm[ck], l1 = v.chunk_lm[ck + 1], ns = l1 - l0;
+        const int o0 = v.lm_ptr[l0], nf = v.lm_ptr[l1] - o0;
+        // ---- phase 0: clear the chunk records, evaluation-point inverse depths ----
+        for (int e = tid; e < ns * rec; e += kLinThreads) chunk[e] = 0.0;
+        if (tid < ns) {
+            const int l = l0 + tid;
+            double r = rho_cur[l];
+            const bool used = v.lm_ptr[l + 1] > v.lm_ptr[l];
+            if (mode == MODE_CANDIDATE && used) {
+                const double dl = v.cl[l] * (ca * i_ghl[l] + cb * i_gnl[l]) / i_Dl[l];
+                const double rc = r + dl;
+                s_step2 += (rc - r) * (rc - r);
+                r = rc;
+            }
+            if (mode == MODE_CANDIDATE) rho_cand[l] = r;
+            if (used) s_norm2 += r * r;
+            rho_eval[tid] = r;
+            anch[tid] = v.lm_anchor[l];
+        }
+        __syncthreads();
+        // ---- phase 1: one thread per reprojection factor ----
+        if (tid < nf) {
+            const int o = o0 + tid, l = v.obs_lm[o], s = l - l0, t = v.obs_frame[o], a = anch[s];
+            double r[2], Jt[12], Jr[12], Jd[2];
+            reproj_eval<true>(frec + t * kFrameRec, frec + a * kFrameRec, rho_eval[s], v.lm_zref[2 * l], v.lm_zref[2 * l + 1],
+                              v.obs_z[2 * (size_t)o], v.obs_z[2 * (size_t)o + 1], r, Jt, Jr, Jd);
+            const double sq = r[0] * r[0] + r[1] * r[1];
+            s_cost += 0.5 * log(1.0 + sq);                                  // CauchyLoss(1): rho(s) = log(1 + s)
+            double bad = isfinite(sq) ? 0.0 : 1.0;
+            const double sw = sqrt(fmax(DBL_MIN, 1.0 / (1.0 + sq)));         // Corrector, rho'' < 0: sqrt(rho')
+            const bool tfix = v.frame_fixed[t] != 0, afix = v.frame_fixed[a] != 0;
+            r[0] *= sw, r[1] *= sw, Jd[0] *= sw, Jd[1] *= sw;
+#pragma unroll
+            for (int k = 0; k < 12; ++k) {
+                bad += isfinite(Jt[k]) && isfinite(Jr[k]) ? 0.0 : 1.0;
+                Jt[k] = tfix ? 0.0 : Jt[k] * sw;                             // constant blocks have no Jacobian
+                Jr[k] = afix ? 0.0 : Jr[k] * sw;
+            }
+            s_bad += bad;
+            double *R = chunk + (size_t)s * rec;
+            double *U = R, *JT = R + 6 * N + 12 * t, *JR = R + 18 * N + 12 * t, *GT = R + 30 * N + 6 * t, *FD = R + 36 * N + 4 * t;
+            double wt[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                wt[k] = Jd[0] * Jt[k] + Jd[1] * Jt[6 + k];
+                U[6 * t + k] += wt[k]; // += : a landmark may list the same target frame twice (bundle_adjustor.cpp:165-179)
+                GT[k] += Jt[k] * r[0] + Jt[6 + k] * r[1];
+                o_Wt[(size_t)o * 6 + k] = wt[k];
+            }
+            // duplicates of one (landmark, frame) pair are rare; the records hold the LAST factor's J (used only for
+            // the direct blocks), so refuse duplicates at upload time instead of silently mis-summing.
+#pragma unroll
+            for (int k = 0; k < 12; ++k) JT[k] = Jt[k], JR[k] = Jr[k];
+            FD[0] = Jd[0], FD[1] = Jd[1], FD[2] = r[0], FD[3] = r[1];
+        }
+        __syncthreads();
+        // ---- phase 1b: per-landmark sums over its factors (50 outputs per landmark) ----
+        for (int e = tid; e < ns * 50; e += kLinThreads) {
+            const int s = e / 50, k = e - 50 * s;
+            const double *R = chunk + (size_t)s * rec, *JR = R + 18 * N, *FD = R + 36 * N;
+            double sum = 0;
+            if (k == 0) {
+                for (int f = 0; f < N; ++f) sum += FD[4 * f] * FD[4 * f] + FD[4 * f + 1] * FD[4 * f + 1];
+            } else if (k == 1) {
+                for (int f = 0; f < N; ++f) sum += FD[4 * f] * FD[4 * f + 2] + FD[4 * f + 1] * FD[4 * f + 3];
+            } else if (k < 8) {
+                const int c = k - 2;
+                for (int f = 0; f < N; ++f) sum += FD[4 * f] * JR[12 * f + c] + FD[4 * f + 1] * JR[12 * f + 6 + c];
+            } else if (k < 14) {
+                const int c = k - 8;
+                for (int f = 0; f < N; ++f) sum += JR[12 * f + c] * FD[4 * f + 2] + JR[12 * f + 6 + c] * FD[4 * f + 3];
+            } else {
+                const int i = (k - 14) / 6, j = (k - 14) - 6 * i;
+                for (int f = 0; f < N; ++f) sum += JR[12 * f + i] * JR[12 * f + j] + JR[12 * f + 6 + i] * JR[12 * f + 6 + j];
+            }
+            double *W = chunk + (size_t)s * rec + 40 * N; // HAA[36] GA[6] SC[4]
+            if (k == 0) W[42 + 3] = sum;        // Hll
+            else if (k == 1) W[42 + 1] = sum;   // bl
+            else if (k < 8) {                   // Wa -> anchor columns of U (added below), keep a copy in GA slot? no: stage in SC area
+                o_Wa[(size_t)(l0 + s) * 6 + (k - 2)] = sum;
+                chunk[(size_t)s * rec + 6 * anch[s] + (k - 2)] += sum; // anchor is never a target of its own landmark
+            } else if (k < 14) W[36 + (k - 8)] = sum;
+            else W[k - 14] = sum;
+        }
+        __syncthreads();
+        // ---- phase 1c: per-landmark scalars: Jacobi scale, dogleg diagonal, Schur weight ----
+        if (tid < ns) {
+            const int l = l0 + tid;
+            double *SC = chunk + (size_t)tid * rec + 40 * N + 42;
+            const double Hll = SC[3], b = SC[1];
+            const bool used = v.lm_ptr[l + 1] > v.lm_ptr[l];
+            double cl;
+            if (mode == MODE_INIT) {
+                cl = used ? 1.0 / (1.0 + sqrt(Hll)) : 1.0; // jacobi_scaling, computed once (iteration 0)
+                v.cl[l] = cl;
+            } else {
+                cl = v.cl[l];
+            }
+            const double d2 = cl * cl * Hll;
+            const double Dl = sqrt(fmin(fmax(d2, 1e-6), 1e32));     // DoglegStrategy diagonal (min/max_lm_diagonal)
+            const double gh = cl * b / Dl;
+            const double A = d2 + mu * Dl * Dl;                     // e-block: E^T E + mu D^2
+            SC[0] = used ? cl * cl / A : 0.0;                       // Schur weight on the UNscaled W rows
+            o_Hll[l] = Hll, o_bl[l] = b, o_Dl[l] = Dl, o_ghl[l] = used ? gh : 0.0;
+            if (used) {
+                s_g2 += gh * gh;
+                s_bmax = fmax(s_bmax, fabs(b));
+            }
+        }
+        __syncthreads();
+        // ---- phase 2: output-stationary tile accumulation over the chunk's landmarks ----
+        for (int s = 0; s < ns; ++s) {
+            const double *R = chunk + (size_t)s * rec;
+            const double *U = R, *JT = R + 6 * N, *JR = R + 18 * N, *HAA = R + 40 * N, *SC = HAA + 42;
+            const double w = SC[0];
+            const int a = anch[s];
+#pragma unroll
+            for (int k = 0; k < T; ++k) {
+                if (k * kLinThreads + tid >= n_tasks) continue;
+                const int fi = tfi[k], fj = tfj[k], r0 = 6 * fi + 3 * tsi[k], c0 = 6 * fj + 3 * tsj[k];
+                const double ur0 = w * U[r0], ur1 = w * U[r0 + 1], ur2 = w * U[r0 + 2];
+                const double uc0 = U[c0], uc1 = U[c0 + 1], uc2 = U[c0 + 2];
+                acc[k][0] -= ur0 * uc0, acc[k][1] -= ur0 * uc1, acc[k][2] -= ur0 * uc2;
+                acc[k][3] -= ur1 * uc0, acc[k][4] -= ur1 * uc1, acc[k][5] -= ur1 * uc2;
+                acc[k][6] -= ur2 * uc0, acc[k][7] -= ur2 * uc1, acc[k][8] -= ur2 * uc2;
+                const double *X = nullptr, *Y = nullptr;
+                if (fi == fj) {
+                    X = JT + 12 * fi + 3 * tsi[k], Y = JT + 12 * fi + 3 * tsj[k];
+                } else if (a == fj) {
+                    X = JT + 12 * fi + 3 * tsi[k], Y = JR + 12 * fi + 3 * tsj[k];
+                } else if (a == fi) {
+                    X = JR + 12 * fj + 3 * tsi[k], Y = JT + 12 * fj + 3 * tsj[k];
+                }
+                if (X) {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) acc[k][3 * i + j] += X[i] * Y[j] + X[6 + i] * Y[6 + j];
+                }
+                if (fi == fj && a == fi) {
+#pragma unroll
+                    for (int i = 0; i < 3; ++i)
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) acc[k][3 * i + j] += HAA[(3 * tsi[k] + i) * 6 + 3 * tsj[k] + j];
+                }
+            }
+            if (tid < P6) {
+                const int f = tid / 6, c = tid - 6 * f;
+                const double *GT = R + 30 * N, *GA = HAA + 36;
+                vg += GT[6 * f + c] + (a == f ? GA[c] : 0.0);
+                vrhs += w * SC[1] * U[tid];
+                vdiag += JT[12 * f + c] * JT[12 * f + c] + JT[12 * f + 6 + c] * JT[12 * f + 6 + c] + (a == f ? HAA[7 * c] : 0.0);
+            }
+        }
+        __syncthreads();
+    }
+    // ---- flush this WG's partial ----
+    double *pS = v.part_S + (size_t)wg * n_tasks * 9;
+#pragma unroll
+    for (int k = 0; k < T; ++k) {
+        const int t = k * kLinThreads + tid;
+        if (t < n_tasks)
+#pragma unroll
+            for (int e = 0; e < 9; ++e) pS[(size_t)e * n_tasks + t] = acc[k][e]; // element-major: coalesced across t
+    }
+    if (tid < P6) {
+        double *pv = v.part_vec + (size_t)wg * kNumPoseVec * P6;
+        pv[tid] = vg, pv[P6 + tid] = vrhs, pv[2 * P6 + tid] = vdiag;
+    }
+    double sc[6] = {s_cost, s_g2, s_step2, s_norm2, s_bad, s_bmax};
+    block_sum<6, true>(sc, scratch);
+    if (tid == 0) {
+        double *ps = v.part_scal + (size_t)wg * kNumLinScal;
+        ps[0] = sc[0], ps[1] = sc[1], ps[2] = sc[2], ps[3] = sc[3], ps[4] = sc[5], ps[5] = sc[4], ps[6] = 0, ps[7] = 0;
+    }
+}
+
+// ---- plane-distance factors: one thread per factor, rows staged in LDS, same tile machinery (sign +) ----
+template <int T>
+__device__ void role_planes(const View &v, double *lds, const Pro *pro, int wg, int n_wg, int part_row) {
+    const int N = v.dm.N, P6 = v.dm.P6, tid = threadIdx.x, n_tasks = v.dm.n_tasks;
+    const double *frec = lds + N * 16;
+    double *scratch = lds + N * 16 + N * kFrameRec;
+    double *rows = lds + common_lds_doubles(N); // [slots][P6 + 2]  (row, r, pad)
+    const int slots = v.dm.plane_slots, rs = P6 + 2;
+    int tfi[T], tfj[T], tsi[T], tsj[T];
+    double acc[T][9];
+#pragma unroll
+    for (int k = 0; k < T; ++k) {
+        const int t = k * kLinThreads + tid;
+        int d = (t < n_tasks) ? v.task_desc[t] : 0;
+        unpack_task(d, tfi[k], tfj[k], tsi[k], tsj[k]);
+#pragma unroll
+        for (int e = 0; e < 9; ++e) acc[k][e] = 0.0;
+    }
+    double vg = 0, vdiag = 0, s_cost = 0, s_bad = 0;
+    for (int ck = wg; ck < v.dm.n_plane_chunks; ck += n_wg) {
+        const int f0 = v.plane_chunk[ck], ns = v.plane_chunk[ck + 1] - f0;
+        for (int e = tid; e < ns * rs; e += kLinThreads) rows[e] = 0.0;
+        __syncthreads();
+        if (tid < ns) {
+            const int f = f0 + tid, b = v.plane_ptr[f], K = v.plane_ptr[f + 1] - b;
+            bool any_free = false;
+            for (int k = 0; k < K; ++k) any_free |= (v.frame_fixed[v.plane_frame[b + k]] == 0);
+            if (any_free) { // all-constant residual blocks are folded into Ceres' fixed_cost and dropped
+                double *row = rows + (size_t)tid * rs;
+                double r;
+                plane_eval_row(K, v.plane_frame + b, v.plane_z + 2 * (size_t)b, frec, v.plane_normal + 3 * f, v.plane_dist[f], v.plane_sic, &r, row);
+                const double sq = r * r;
+                s_cost += 0.5 * log(1.0 + sq);
+                s_bad += isfinite(sq) ? 0.0 : 1.0;
+                const double sw = sqrt(fmax(DBL_MIN, 1.0 / (1.0 + sq)));
+                for (int k = 0; k < K; ++k) {
+                    const int fr = v.plane_frame[b + k];
+                    const bool fx = v.frame_fixed[fr] != 0;
+                    for (int c = 0; c < 6; ++c) row[6 * fr + c] = fx ? 0.0 : row[6 * fr + c];
+                }
+                for (int c = 0; c < P6; ++c) row[c] *= sw;
+                row[P6] = r * sw;
+            }
+        }
+        __syncthreads();
+        for (int s = 0; s < ns; ++s) {
+            const double *U = rows + (size_t)s * rs;
+#pragma unroll
+            for (int k = 0; k < T; ++k) {
+                if (k * kLinThreads + tid >= n_tasks) continue;
+                const int r0 = 6 * tfi[k] + 3 * tsi[k], c0 = 6 * tfj[k] + 3 * tsj[k];
+                const double ur0 = U[r0], ur1 = U[r0 + 1], ur2 = U[r0 + 2];
+                const double uc0 = U[c0], uc1 = U[c0 + 1], uc2 = U[c0 + 2];
+                acc[k][0] += ur0 * uc0, acc[k][1] += ur0 * uc1, acc[k][2] += ur0 * uc2;
+                acc[k][3] += ur1 * uc0, acc[k][4] += ur1 * uc1, acc[k][5] += ur1 * uc2;
+                acc[k][6] += ur2 * uc0, acc[k][7] += ur2 * uc1, acc[k][8] += ur2 * uc2;
+            }
+            if (tid < P6) {
+                vg += U[tid] * U[P6];
+                vdiag += U[tid] * U[tid];
+            }
+        }
+        __syncthreads();
+    }
+    double *pS = v.part_S + (size_t)part_row * n_tasks * 9;
+#pragma unroll
+    for (int k = 0; k < T; ++k) {
+        const int t = k * kLinThreads + tid;
+        if (t < n_tasks)
+#pragma unroll
+            for (int e = 0; e < 9; ++e) pS[(size_t)e * n_tasks + t] = acc[k][e];
+    }
+    if (tid < P6) {
+        double *pv = v.part_vec + (size_t)part_row * kNumPoseVec * P6;
+        pv[tid] = vg, pv[P6 + tid] = 0.0, pv[2 * P6 + tid] = vdiag;
+    }
+    double sc[2] = {s_cost, s_bad};
+    block_sum<2>(sc, scratch);
+    if (tid == 0) {
+        double *ps = v.part_scal + (size_t)part_row * kNumLinScal;
+        ps[0] = sc[0], ps[1] = 0, ps[2] = 0, ps[3] = 0, ps[4] = 0, ps[5] = sc[1], ps[6] = 0, ps[7] = 0;
+    }
+}
+
+// ---- IMU pre-integration factor j (frames j-1 -> j): one WG ------------------------------------------------
+__device__ void role_preint(const View &v, double *lds, const Pro *pro, int j) {
+    const int N = v.dm.N, tid = threadIdx.x;
+    const double *est = lds;
+    double *work = lds + common_lds_doubles(N); // raw[16] G[450] J[450] r[16]
+    double *raw = work, *G = work + 16, *J = work + 466, *r = work + 916;
+    const int i = j - 1;
+    if (tid == 0) {
+        // live bias read: the accepted linearization keeps the biases it was evaluated with (RELIN must reuse them)
+        const double *b0 = (pro->mode == MODE_RELIN) ? v.bias0_lin + 6 * i : v.fs_user + 16 * i + 10;
+        preint_raw(est + 16 * i, est + 16 * j, b0, v.pre_delta + 11 * j, v.pre_jac + 45 * j, v.imu_ext + 7 * i, v.imu_ext + 7 * j, raw, G);
+        const bool fi = v.frame_fixed[i] != 0, fj = v.frame_fixed[j] != 0;
+        for (int row = 0; row < 15; ++row)
+            for (int c = 0; c < 6; ++c) {
+                if (fi) G[row * 30 + c] = 0.0;
+                if (fj) G[row * 30 + 15 + c] = 0.0;
+            }
+    }
+    __syncthreads();
+    const double *U = v.pre_U + 225 * (size_t)j;
+    for (int e = tid; e < 450; e += kLinThreads) {
+        const int row = e / 30, c = e - 30 * row;
+        double s = 0;
+        for (int k = 0; k < 15; ++k) s += U[row * 15 + k] * G[k * 30 + c];
+        J[e] = s;
+    }
+    if (tid < 15) {
+        double s = 0;
+        for (int k = 0; k < 15; ++k) s += U[tid * 15 + k] * raw[k];
+        r[tid] = s;
+    }
+    __syncthreads();
+    for (int e = tid; e < 900; e += kLinThreads) {
+        const int a = e / 30, b = e - 30 * a;
+        double s = 0;
+        for (int k = 0; k < 15; ++k) s += J[k * 30 + a] * J[k * 30 + b];
+        v.pre_H[(size_t)j * 900 + e] = s;
+    }
+    if (tid < 30) {
+        double s = 0;
+        for (int k = 0; k < 15; ++k) s += J[k * 30 + tid] * r[k];
+        v.pre_g[(size_t)j * 30 + tid] = s;
+    }
+    if (tid == 0) {
+        double s = 0;
+        for (int k = 0; k < 15; ++k) s += r[k] * r[k];
+        v.pre_cost[j] = 0.5 * s;
+    }
+}
+
+// ---- marginalization prior: block b of nb -------------------------------------------------------------------
+__device__ void role_prior(const View &v, double *lds, const Pro *pro, int b, int nb) {
+    const int N = v.dm.N, n = v.dm.prior_n, D = 15 * n, tid = threadIdx.x;
+    const double *est = lds;
+    double *scratch = lds + N * 16 + N * kFrameRec;
+    double *work = lds + common_lds_doubles(N); // e[D] JRI[9n] rr[D]
+    double *e = work, *JRI = work + D, *rr = JRI + 9 * n;
+    if (tid < n) prior_frame_error(est + 16 * v.prior_frames[tid], v.prior_lin + 16 * tid, e + 15 * tid, JRI + 9 * tid);
+    __syncthreads();
+    if (b == 0) {
+        // r = S e + s ; cost = |r|^2 / 2 ; g = B^T (Lambda e + eta)
+        double c2 = 0;
+        for (int row = tid; row < D; row += kLinThreads) {
+            double s = v.prior_s[row];
+            const double *Sr = v.prior_S + (size_t)row * D;
+            for (int k = 0; k < D; ++k) s += Sr[k] * e[k];
+            c2 += s * s;
+            double t = v.prior_eta[row];
+            const double *Lr = v.prior_Lambda + (size_t)row * D;
+            for (int k = 0; k < D; ++k) t += Lr[k] * e[k];
+            rr[row] = t;
+        }
+        double sc[1] = {c2};
+        block_sum<1>(sc, scratch); // also orders the rr writes
+        if (tid == 0) v.prior_cost[0] = 0.5 * sc[0];
+        for (int a = tid; a < D; a += kLinThreads) {
+            const int i = a / 15, k = a - 15 * i;
+            double g;
+            if (k < 3) {
+                const double *Jm = JRI + 9 * i;
+                g = Jm[k] * rr[15 * i] + Jm[3 + k] * rr[15 * i + 1] + Jm[6 + k] * rr[15 * i + 2];
+            } else {
+                g = rr[a];
+            }
+            const int fr = v.prior_frames[i];
+            if (k < 6 && v.frame_fixed[fr]) g = 0.0;
+            v.prior_g[a] = g;
+        }
+    }
+    // H = B^T Lambda B, rows split across the prior blocks
+    const int rows_per = (D + nb - 1) / nb, ra = b * rows_per, rb = min(D, ra + rows_per);
+    for (int idx = tid; idx < (rb - ra) * D; idx += kLinThreads) {
+        const int a = ra + idx / D, c = idx % D;
+        const int ia = a / 15, ka = a - 15 * ia, ic = c / 15, kc = c - 15 * ic;
+        const double *Ja = JRI + 9 * ia, *Jc = JRI + 9 * ic;
+        double h = 0;
+        if (ka < 3 && kc < 3) {
+            for (int x = 0; x < 3; ++x)
+                for (int y = 0; y < 3; ++y) h += Ja[3 * x + ka] * v.prior_Lambda[(size_t)(15 * ia + x) * D + 15 * ic + y] * Jc[3 * y + kc];
+        } else if (ka < 3) {
+            for (int x = 0; x < 3; ++x) h += Ja[3 * x + ka] * v.prior_Lambda[(size_t)(15 * ia + x) * D + c];
+        } else if (kc < 3) {
+            for (int y = 0; y < 3; ++y) h += v.prior_Lambda[(size_t)a * D + 15 * ic + y] * Jc[3 * y + kc];
+        } else {
+            h = v.prior_Lambda[(size_t)a * D + c];
+        }
+        if ((ka < 6 && v.frame_fixed[v.prior_frames[ia]]) || (kc < 6 && v.frame_fixed[v.prior_frames[ic]])) h = 0.0;
+        v.prior_H[(size_t)a * D + c] = h;
+    }
+}
+
+template <int T>
+__global__ void __launch_bounds__(kLinThreads) k_linearize(View v) {
+    HIP_DYNAMIC_SHARED(double, lds)
+    if (v.ctrl->done) return;
+    Pro *pro;
+    lin_prologue(v, lds, pro);
+    if (!pro->valid) return; // invalid trust-region step: k_dense handles it (HandleInvalidStep)
+    const int b = blockIdx.x, g0 = v.dm.G_lm, g1 = g0 + v.dm.G_plane, g2 = g1 + v.dm.G_pre;
+    if (b < g0) role_landmarks<T>(v, lds, pro, b, g0);
+    else if (b < g1) role_planes<T>(v, lds, pro, b - g0, v.dm.G_plane, b);
+    else if (b < g2) {
+        const int j = b - g1 + 1;
+        if (v.pre_valid[j]) role_preint(v, lds, pro, j);
+    } else role_prior(v, lds, pro, b - g2, v.dm.G_prior);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// k_reduce: fixed-order sums of the WG partials -> red = [S tiles (element-major) | 3 pose vectors | 8 scalars]
+// ------------------------------------------------------------------------------------------------------
+__global__ void k_reduce(View v) {
+    if (v.ctrl->done || v.ctrl->lin_result == LIN_INVALID_STEP) return;
+    const int G = v.dm.G_lm + v.dm.G_plane;
+    const size_t nS = (size_t)v.dm.n_tasks * 9, nV = (size_t)kNumPoseVec * v.dm.P6;
+    const size_t total = nS + nV + kNumLinScal;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+        double s = 0;
+        if (e < nS) {
+            for (int g = 0; g < G; ++g) s += v.part_S[(size_t)g * nS + e];
+        } else if (e < nS + nV) {
+            for (int g = 0; g < G; ++g) s += v.part_vec[(size_t)g * nV + (e - nS)];
+        } else {
+            const int k = (int)(e - nS - nV);
+            if (k == 4) {
+                for (int g = 0; g < G; ++g) s = fmax(s, v.part_scal[(size_t)g * kNumLinScal + k]);
+            } else {
+                for (int g = 0; g < G; ++g) s += v.part_scal[(size_t)g * kNumLinScal + k];
+            }
+        }
+        v.red[e] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// k_dense: the serial part of a trust-region iteration, one workgroup.
+// ------------------------------------------------------------------------------------------------------
+__device__ int record_trace(const View &v, Ctrl *c, int iteration) {
+    const int slot = c->trace_len;
+    if (slot >= c->trace_cap) return -1;
+    c->trace_len = slot + 1;
+    TraceRec &r = v.trace[slot];
+    r.iteration = iteration, r.step_is_valid = c->it_valid, r.step_is_successful = c->it_success, r.reserved = 0;
+    r.cost = c->it_cost, r.cost_change = c->it_cost_change, r.gradient_max_norm = c->grad_max, r.step_norm = c->it_step_norm;
+    r.relative_decrease = c->it_rel, r.trust_region_radius = c->radius, r.mu = c->mu;
+    return slot;
+}
+
+struct DenseShared {
+    int do_solve, do_trace, trace_slot, accepted, first;
+    double x_cost_new;
+};
+
+__global__ void __launch_bounds__(kDenseThreads) k_dense(View v, int lds_matrix) {
+    HIP_DYNAMIC_SHARED(double, lds)
+    Ctrl *c = v.ctrl;
+    if (c->done) return;
+    const int N = v.dm.N, d = v.dm.d, P = v.dm.P, P6 = v.dm.P6, tid = threadIdx.x, nthr = blockDim.x;
+    const int n_tasks = v.dm.n_tasks;
+    const size_t nS = (size_t)n_tasks * 9;
+    const double *redV = v.red + nS, *redS = v.red + nS + (size_t)kNumPoseVec * P6;
+    // layout of dynamic LDS: [header 128][vec area 8 x (P+1)][A: (P+1) x ld if lds_matrix]  (no static LDS: keeps the
+    // dynamic base 16-byte aligned, cdna_hip_programming.md Guideline 17)
+    DenseShared &sh = *reinterpret_cast<DenseShared *>(lds);
+    double *red_scratch = lds + 16; // 6 * 16 doubles
+    int &sh_fail = *reinterpret_cast<int *>(lds + 120);
+    const int ld = P + 1;
+    double *vec = lds + 128;
+    double *A = lds_matrix ? vec + 8 * (size_t)ld : v.Smat;
+    double *diagH = vec, *gtot = vec + ld, *rhs = vec + 2 * ld, *yv = vec + 3 * ld, *vv = vec + 4 * ld, *act = vec + 5 * ld, *tmp = vec + 6 * ld;
+
+    // ---------------- control (thread 0): Finalize the iteration in flight, decide what comes next ----------------
+    if (tid == 0) {
+        const int lr = c->lin_result;
+        sh.do_solve = 0, sh.do_trace = 0, sh.accepted = 0, sh.first = 0;
+        double aux_cost = 0;
+        if (lr != LIN_INVALID_STEP) {
+            for (int j = 1; j < N; ++j)
+                if (v.dm.G_pre && v.pre_valid[j]) aux_cost += v.pre_cost[j];
+            if (v.dm.prior_n > 0) aux_cost += v.prior_cost[0];
+        }
+        const double lm_cost = redS[0], lm_bad = redS[5];
+        double total_cost = aux_cost + lm_cost;
+        const bool finite_ok = (lm_bad == 0.0) && isfinite(total_cost);
+        bool finalize = false; // run FinalizeIterationAndCheckIfMinimizerCanContinue
+        if (lr == LIN_INIT) {
+            if (!finite_ok) {
+                c->termination = 2, c->done = 1; // FAILURE: initial evaluation failed
+            } else {
+                c->x_cost = total_cost, c->initial_cost = total_cost;
+                c->x_norm2_pose = c->cand_norm2_pose, c->x_norm2_lm = redS[3];
+                c->lm_g2 = redS[1];
+                c->it_cost = total_cost, c->it_cost_change = 0, c->it_step_norm = 0, c->it_rel = 0, c->it_valid = 1, c->it_success = 1;
+                sh.first = 1, sh.accepted = 1;
+                finalize = true;
+            }
+        } else if (lr == LIN_CANDIDATE) {
+            const double cand_cost = finite_ok ? total_cost : DBL_MAX;
+            const double step_norm = sqrt(c->cand_step2_pose + redS[2]);
+            const double x_norm = sqrt(c->x_norm2_pose + c->x_norm2_lm);
+            c->it_valid = 1, c->it_step_norm = step_norm;
+            c->invalid_steps = 0;
+            if (step_norm <= 1e-8 * (x_norm + 1e-8)) { // ParameterToleranceReached
+                c->termination = 0, c->done = 1;
+            } else {
+                const double cost_change = c->x_cost - cand_cost;
+                c->it_cost_change = cost_change;
+                if (fabs(cost_change) <= 1e-6 * c->x_cost) { // FunctionToleranceReached (candidate NOT applied)
+                    c->termination = 0, c->done = 1;
+                } else {
+                    const double rel = cost_change / c->model_cost_change;
+                    c->it_rel = rel;
+                    if (rel > 1e-3) { // HandleSuccessfulStep
+                        c->cur = 1 - c->cur, c->lin = 1 - c->lin;
+                        c->x_cost = cand_cost;
+                        c->x_norm2_pose = c->cand_norm2_pose, c->x_norm2_lm = redS[3];
+                        c->lm_g2 = redS[1];
+                        if (rel < 0.25) c->radius *= 0.5; // DoglegStrategy::StepAccepted
+                        if (rel > 0.75) c->radius = fmax(c->radius, 3.0 * c->dogleg_step_norm);
+                        c->mu = fmax(1e-8, 2.0 * c->mu / 10.0);
+                        c->reuse = 0;
+                        c->it_success = 1, c->it_cost = cand_cost;
+                        sh.accepted = 1;
+                    } else { // HandleUnsuccessfulStep
+                        c->radius *= 0.5; // DoglegStrategy::StepRejected
+                        c->reuse = 1;
+                        c->it_success = 0, c->it_cost = cand_cost;
+                    }
+                    finalize = true;
+                }
+            }
+        } else if (lr == LIN_INVALID_STEP) { // HandleInvalidStep
+            c->it_valid = 0, c->it_success = 0, c->it_cost = c->x_cost, c->it_cost_change = 0, c->it_step_norm = 0, c->it_rel = 0;
+            if (++c->invalid_steps >= 5) {
+                c->termination = 2, c->done = 1;
+            } else {
+                c->mu *= 10.0; // DoglegStrategy::StepIsInvalid
+                c->reuse = 0;
+                finalize = true;
+            }
+        } else if (lr == LIN_RELIN) {
+            // the accepted point re-linearized with a new mu: continue the iteration in flight
+            sh.do_solve = finite_ok ? 1 : 0;
+            if (!finite_ok) c->termination = 2, c->done = 1;
+        }
+        sh.x_cost_new = c->x_cost;
+        sh.do_trace = 0;
+        if (finalize) sh.do_trace = 1; // the record needs grad_max of an accepted linearization -> written after the build below
+    }
+    __syncthreads();
+    if (c->done && !sh.do_trace) {
+        if (tid == 0) c->mode = MODE_DONE;
+        return;
+    }
+    const bool need_build = sh.accepted || sh.do_solve; // a new accepted linearization (or RELIN) is in `red`
+    // ---------------- assemble the unscaled totals: diag(H), gradient, Schur rhs, matrix ----------------
+    if (need_build) {
+        for (int a = tid; a < P; a += nthr) {
+            const int f = a / d, k = a - d * f;
+            double dg = 0, g = 0, rs = 0;
+            if (k < 6) {
+                dg = redV[2 * P6 + 6 * f + k], g = redV[6 * f + k], rs = redV[P6 + 6 * f + k];
+            }
+            act[a] = (k < 6 ? v.pose_active[f] : v.motion_active[f]) ? 1.0 : 0.0;
+            diagH[a] = dg, gtot[a] = g, rhs[a] = -rs;
+        }
+        for (size_t e = tid; e < (size_t)(P + 1) * ld; e += nthr) A[e] = 0.0;
+        __syncthreads();
+        // landmark + plane tiles (upper block triangle, element-major) -> both triangles of A
+        for (size_t e = tid; e < nS; e += nthr) {
+            const int el = (int)(e / n_tasks), t = (int)(e - (size_t)el * n_tasks);
+            int fi, fj, si, sj;
+            unpack_task(v.task_desc[t], fi, fj, si, sj);
+            const int r = d * fi + 3 * si + el / 3, cc = d * fj + 3 * sj + el % 3;
+            const double val = v.red[e];
+            if (fi == fj) {
+                A[(size_t)r * ld + cc] = val; // diagonal blocks are computed in full (all four 3x3 sub tiles)
+            } else {
+                A[(size_t)r * ld + cc] = val;
+                A[(size_t)cc * ld + r] = val;
+            }
+        }
+        __syncthreads();
+        // IMU pre-integration blocks (30 x 30 on frames j-1, j) and the prior: one thread per output element
+        if (d == 15) {
+            for (int j = 1; j < N; ++j) {
+                if (!(v.dm.G_pre && v.pre_valid[j])) continue;
+                const double *H = v.pre_H + (size_t)j * 900;
+                for (int e = tid; e < 900; e += nthr) {
+                    const int a = e / 30, b = e - 30 * a;
+                    A[(size_t)(15 * (j - 1) + a) * ld + 15 * (j - 1) + b] += H[e];
+                }
+                if (tid < 30) {
+                    diagH[15 * (j - 1) + tid] += H[31 * tid];
+                    gtot[15 * (j - 1) + tid] += v.pre_g[(size_t)j * 30 + tid];
+                    rhs[15 * (j - 1) + tid] += v.pre_g[(size_t)j * 30 + tid];
+                }
+                __syncthreads();
+            }
+            if (v.dm.prior_n > 0) {
+                const int n = v.dm.prior_n, D = 15 * n;
+                for (int e = tid; e < D * D; e += nthr) {
+                    const int a = e / D, b = e - D * a;
+                    const int ga = 15 * v.prior_frames[a / 15] + a % 15, gb = 15 * v.prior_frames[b / 15] + b % 15;
+                    A[(size_t)ga * ld + gb] += v.prior_H[e];
+                }
+                for (int a = tid; a < D; a += nthr) {
+                    const int ga = 15 * v.prior_frames[a / 15] + a % 15;
+                    diagH[ga] += v.prior_H[(size_t)a * D + a];
+                    gtot[ga] += v.prior_g[a];
+                    rhs[ga] += v.prior_g[a];
+                }
+                __syncthreads();
+            }
+        }
+        // rhs so far = -rhs_schur + aux gradients; add the direct landmark gradient
+        for (int a = tid; a < P; a += nthr) {
+            const int f = a / d, k = a - d * f;
+            if (k < 6) rhs[a] += redV[6 * f + k];
+        }
+        __syncthreads();
+        // gradient_max_norm = max | x - (x (+) -g) | over the free blocks (ambient coordinates)
+        double gm = 0;
+        if (tid < N) {
+            const double *x = v.fs + ((size_t)c->cur * N + tid) * 16;
+            if (v.pose_active[tid]) {
+                double ng[6], y[7];
+                for (int k = 0; k < 6; ++k) ng[k] = -gtot[d * tid + k];
+                pose_plus(y, x, ng, ng + 3);
+                for (int k = 0; k < 7; ++k) gm = fmax(gm, fabs(x[k] - y[k]));
+            }
+            if (d == 15 && v.motion_active[tid])
+                for (int k = 0; k < 9; ++k) gm = fmax(gm, fabs(gtot[15 * tid + 6 + k]));
+        }
+        if (tid < 64) {
+            gm = wave_max(gm);
+            if (tid == 0) c->grad_max = fmax(gm, redS[4]);
+        }
+        __syncthreads();
+    }
+    // ---------------- Finalize: record, state-updating callback, termination tests ----------------
+    if (tid == 0 && sh.do_trace) {
+        const int lr = c->lin_result;
+        if (c->it_success) c->num_success++;
+        sh.trace_slot = record_trace(v, c, c->iter);
+        bool stop = false;
+        if (c->iter >= v.dm.max_iter) c->termination = 1, stop = true;                           // MaxSolverIterationsReached
+        else if (c->it_success && c->grad_max <= 1e-10) c->termination = 0, stop = true;         // GradientToleranceReached
+        else if (c->radius <= 1e-32) c->termination = 0, stop = true;                            // MinTrustRegionRadiusReached
+        if (stop) {
+            c->done = 1;
+        } else {
+            c->iter++;
+            c->it_valid = 0, c->it_success = 0, c->it_cost_change = 0, c->it_step_norm = 0, c->it_rel = 0, c->it_cost = c->x_cost;
+            if (lr == LIN_INIT || (lr == LIN_CANDIDATE && sh.accepted)) sh.do_solve = 1;      // new Gauss-Newton step needed
+            else if (lr == LIN_CANDIDATE) c->mode = MODE_CANDIDATE, c->solve_ok = 0;          // rejected: reuse gn / gradient
+            else if (lr == LIN_INVALID_STEP) c->mode = MODE_RELIN, c->solve_ok = 0, c->retry_relin = 0;
+        }
+    }
+    __syncthreads();
+    // trace states + StateUpdatingCallback (update_state_every_iteration): user state <- accepted iterate
+    if (sh.do_trace) {
+        const int cur = c->cur;
+        if (sh.accepted && !sh.first) {
+            // the accepted linearization was evaluated with the OLD user biases: keep them for a later RELIN
+            for (int e = tid; e < N * 6; e += nthr) v.bias0_lin[e] = v.fs_user[(e / 6) * 16 + 10 + e % 6];
+        }
+        __syncthreads();
+        if (sh.accepted)
+            for (int e = tid; e < N * 16; e += nthr) v.fs_user[e] = v.fs[(size_t)cur * N * 16 + e];
+        if (sh.first)
+            for (int e = tid; e < N * 6; e += nthr) v.bias0_lin[e] = v.fs[(size_t)cur * N * 16 + (e / 6) * 16 + 10 + e % 6];
+        if (v.trace_states && sh.trace_slot >= 0) {
+            double *dst = v.trace_states + (size_t)sh.trace_slot * (N * 16 + v.dm.M);
+            for (int e = tid; e < N * 16; e += nthr) dst[e] = v.fs[(size_t)cur * N * 16 + e];
+            for (int e = tid; e < v.dm.M; e += nthr) dst[N * 16 + e] = v.rho[(size_t)cur * v.dm.M + e];
+        }
+    }
+    __syncthreads();
+    if (c->done) {
+        if (tid == 0) c->mode = MODE_DONE;
+        return;
+    }
+    if (!sh.do_solve) return;
+
+    // ---------------- Jacobi scaling (once), dogleg diagonal, scaled system ----------------
+    if (!c->scaling_ready)
+        for (int a = tid; a < P; a += nthr) v.cp[a] = act[a] != 0.0 ? 1.0 / (1.0 + sqrt(diagH[a])) : 1.0;
+    __syncthreads();
+    const double mu = c->mu;
+    for (int a = tid; a < P; a += nthr) {
+        const double cpa = v.cp[a];
+        const double d2 = cpa * cpa * diagH[a];
+        const double Da = sqrt(fmin(fmax(d2, 1e-6), 1e32));
+        v.Dp[a] = Da;
+        const double gh = act[a] != 0.0 ? cpa * gtot[a] / Da : 0.0;
+        v.ghp[a] = gh;
+        vv[a] = gh / Da;           // v = g^ / D
+        tmp[a] = cpa * gtot[a];    // scaled gradient g_s
+        A[(size_t)P * ld + a] = act[a] != 0.0 ? cpa * rhs[a] : 0.0; // augmented row: scaled reduced rhs
+    }
+    __syncthreads();
+    for (size_t e = tid; e < (size_t)P * P; e += nthr) {
+        const int a = (int)(e / P), b = (int)(e - (size_t)a * P);
+        double val = A[(size_t)a * ld + b];
+        if (act[a] == 0.0 || act[b] == 0.0) val = (a == b) ? 1.0 : 0.0;
+        else val *= v.cp[a] * v.cp[b];
+        A[(size_t)a * ld + b] = val;
+    }
+    __syncthreads();
+    // pose quadratic forms with the Schur-reduced scaled matrix (mu D^2 not yet added): v^T S v
+    {
+        double q = 0;
+        for (int a = tid; a < P; a += nthr) {
+            double row = 0;
+            for (int b = 0; b < P; ++b) row += A[(size_t)a * ld + b] * vv[b];
+            yv[a] = row; // S v
+            q += act[a] != 0.0 ? vv[a] * row : 0.0;
+        }
+        double s1[1] = {q};
+        block_sum<1>(s1, red_scratch);
+        if (tid == 0) c->pose_qvv = s1[0];
+    }
+    // keep S v for q_vy: copy to tmp2 region (reuse diagH which is no longer needed after Dp)
+    for (int a = tid; a < P; a += nthr) diagH[a] = yv[a];
+    __syncthreads();
+    for (int a = tid; a < P; a += nthr)
+        if (act[a] != 0.0) A[(size_t)a * ld + a] += mu * v.Dp[a] * v.Dp[a];
+    __syncthreads();
+    // ---------------- Cholesky of the augmented matrix: one barrier per column ----------------
+    // a_ik -= a_ij a_kj / a_jj keeps columns unscaled; row P carries the right-hand side (forward substitution)
+    int fail = 0;
+    for (int j = 0; j < P; ++j) {
+        const double piv = A[(size_t)j * ld + j];
+        if (!(piv > 0.0) || !isfinite(piv)) {
+            fail = 1;
+            break;
+        }
+        const double ip = 1.0 / piv;
+        const int m = P - j; // rows j+1 .. P  (P = rhs row)
+        const int npairs = m * (m + 1) / 2 - 0;
+        // pairs (i,k), j < k <= i <= P, k <= P-1 ; enumerate i over [j+1, P], k over [j+1, min(i, P-1)]
+        for (int e = tid; e < npairs; e += nthr) {
+            // invert e -> (ii, kk) with 0 <= kk <= ii < m : e = ii (ii+1)/2 + kk
+            int ii = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+            while ((ii + 1) * (ii + 2) / 2 <= e) ++ii;
+            while (ii * (ii + 1) / 2 > e) --ii;
+            const int kk = e - ii * (ii + 1) / 2;
+            const int i = j + 1 + ii, k = j + 1 + kk;
+            if (k >= P) continue; // the rhs row has no column of its own
+            A[(size_t)i * ld + k] -= A[(size_t)i * ld + j] * A[(size_t)k * ld + j] * ip;
+        }
+        __syncthreads();
+    }
+    // ---------------- back substitution L^T y = z in wave 0 (rows owned by lanes, shuffles) ----------------
+    if (tid == 0) sh_fail = fail;
+    __syncthreads();
+    if (!fail) {
+        double zz = 0;
+        for (int a = tid; a < P; a += nthr) {
+            const double dj = sqrt(A[(size_t)a * ld + a]);
+            tmp[a] = dj;                                 // L_aa
+            const double z = A[(size_t)P * ld + a] / dj; // z_a = (L^-1 rhs)_a
+            yv[a] = z;
+            zz += act[a] != 0.0 ? z * z : 0.0;
+        }
+        double s1[1] = {zz};
+        block_sum<1>(s1, red_scratch);
+        if (tid == 0) c->pose_qyy = s1[0]; // y^T (S + mu D^2) y = |z|^2 ; the mu term is removed below
+        if (tid < 64) {
+            // lane owns rows a = tid + 64 q.  L[j][i] (j > i) = A[j][i] / sqrt(A[i][i]).
+            for (int j = P - 1; j >= 0; --j) {
+                const int owner = j & 63;
+                double yj = 0;
+                if (tid == owner) {
+                    yj = yv[j] / tmp[j];
+                    yv[j] = yj;
+                }
+                yj = __shfl(yj, owner);
+                for (int a = tid; a < j; a += 64) yv[a] -= (A[(size_t)j * ld + a] / tmp[a]) * yj;
+            }
+        }
+        __syncthreads();
+    }
+    // ---------------- outputs ----------------
+    if (tid == 0) {
+        int ok = !sh_fail;
+        if (ok)
+            for (int a = 0; a < P; ++a) ok &= isfinite(yv[a]) ? 1 : 0;
+        if (ok) {
+            c->solve_ok = 1, c->mode = MODE_CANDIDATE, c->scaling_ready = 1, c->retry_relin = 0;
+        } else {
+            // LINEAR_SOLVER_FAILURE at this mu: escalate; below max_mu re-run the Schur accumulation with the new mu
+            c->solve_ok = 0;
+            c->mu *= 10.0;
+            c->scaling_ready = 1;
+            if (c->mu < 1.0) {
+                c->mode = MODE_RELIN, c->retry_relin = 1;
+            } else {
+                // mu >= max_mu: Ceres would now burn 5 consecutive invalid iterations without moving x and return
+                // FAILURE; the iterate is identical, so terminate right away.
+                c->termination = 2, c->done = 1, c->mode = MODE_DONE;
+            }
+        }
+        sh.do_solve = ok;
+    }
+    __syncthreads();
+    if (!sh.do_solve) return;
+    // y solves (S + mu D^2) y = rhs_s ; step direction y' = -y ; gn = D y'
+    {
+        double s_g2 = 0, s_gn2 = 0, s_gd = 0, s_qvy = 0, s_qyy = 0, s_gy = 0;
+        for (int a = tid; a < P; a += nthr) {
+            const double yp = act[a] != 0.0 ? -yv[a] : 0.0;
+            const double Da = v.Dp[a], gh = v.ghp[a], gn = Da * yp;
+            v.ystep[a] = v.cp[a] * yp;
+            v.vstep[a] = act[a] != 0.0 ? v.cp[a] * vv[a] : 0.0;
+            s_g2 += gh * gh, s_gn2 += gn * gn, s_gd += gh * gn;
+            s_qvy += diagH[a] * yp;                      // (S v) . y'
+            s_gy += act[a] != 0.0 ? v.cp[a] * gtot[a] * yp : 0.0;
+        }
+        // y'^T S y' = |z|^2 - mu sum D_a^2 y'_a^2 = |z|^2 - mu |gn_p|^2
+        (void)s_qyy;
+        double sc[6] = {s_g2, s_gn2, s_gd, s_qvy, 0.0, s_gy};
+        block_sum<6>(sc, red_scratch);
+        if (tid == 0) {
+            c->pose_g2 = sc[0], c->pose_gn2 = sc[1], c->pose_gdot = sc[2], c->pose_qvy = sc[3], c->pose_gy = sc[5];
+            c->pose_qyy = c->pose_qyy - mu * sc[1];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// k_backsub: landmark back-substitution + landmark parts of the dogleg scalars; <= 64 WGs, one row each
+// ------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_backsub(View v) {
+    const Ctrl *c = v.ctrl;
+    if (c->done || !c->solve_ok) return;
+    __shared__ double scratch[6 * 16];
+    const int M = v.dm.M, d = v.dm.d, lin = c->lin;
+    const size_t Ms = (size_t)M, Fs = (size_t)v.dm.F;
+    const double *Hll = v.Hll + lin * Ms, *bl = v.bl + lin * Ms, *Dl = v.Dl + lin * Ms, *ghl = v.ghl + lin * Ms;
+    const double *Wa = v.Wa + lin * Ms * 6, *Wt = v.Wt + lin * Fs * 6;
+    double *gnl = v.gnl + lin * Ms;
+    const double mu = c->mu;
+    double s[6] = {0, 0, 0, 0, 0, 0};
+    for (int l = blockIdx.x * blockDim.x + threadIdx.x; l < M; l += gridDim.x * blockDim.x) {
+        const int o0 = v.lm_ptr[l], o1 = v.lm_ptr[l + 1];
+        if (o1 == o0) {
+            gnl[l] = 0.0;
+            continue;
+        }
+        const int a = v.lm_anchor[l];
+        double Wv = 0, Wy = 0; // W_l . (C_p v_p), W_l . (C_p y'_p)   (vstep / ystep already carry C_p)
+        for (int k = 0; k < 6; ++k) Wv += Wa[(size_t)l * 6 + k] * v.vstep[d * a + k], Wy += Wa[(size_t)l * 6 + k] * v.ystep[d * a + k];
+        for (int o = o0; o < o1; ++o) {
+            const int t = v.obs_frame[o];
+            for (int k = 0; k < 6; ++k) Wv += Wt[(size_t)o * 6 + k] * v.vstep[d * t + k], Wy += Wt[(size_t)o * 6 + k] * v.ystep[d * t + k];
+        }
+        const double cl = v.cl[l], D = Dl[l], gh = ghl[l];
+        const double Hs = cl * cl * Hll[l], A = Hs + mu * D * D;
+        const double w = cl * cl / A;
+        const double yl = -cl * (bl[l] + Wy) / A; // y'_l
+        const double vl = gh / D;
+        const double gn = D * yl;
+        gnl[l] = gn;
+        s[0] += gn * gn;
+        s[1] += gh * gn;
+        s[2] += w * Wv * Wv + 2 * cl * vl * Wv + Hs * vl * vl;                          // v^T H v (landmark + add-back)
+        s[3] += w * Wv * Wy + cl * vl * Wy + cl * yl * Wv + Hs * vl * yl;               // v^T H y'
+        s[4] += w * Wy * Wy + 2 * cl * yl * Wy + Hs * yl * yl;                          // y'^T H y'
+        s[5] += cl * bl[l] * yl;                                                        // g_s^T y'
+    }
+    block_sum<6>(s, scratch);
+    if (threadIdx.x == 0) {
+        double *row = v.back_part + (size_t)blockIdx.x * kNumBackScal;
+        for (int k = 0; k < 6; ++k) row[k] = s[k];
+        row[6] = row[7] = 0;
+    }
+}
+
+// sums the k_backsub rows into row 0 (only used before an all-reduce across landmark shards)
+__global__ void k_back_reduce(View v, int rows) {
+    const Ctrl *c = v.ctrl;
+    if (c->done || !c->solve_ok) return;
+    if (threadIdx.x < kNumBackScal) {
+        double s = 0;
+        for (int r = 0; r < rows; ++r) s += v.back_part[(size_t)r * kNumBackScal + threadIdx.x];
+        v.back_red[threadIdx.x] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// post-solve quality pass (bundle_adjustor.cpp:277-296) and compute_reprojection_error (:321-336)
+// ------------------------------------------------------------------------------------------------------
+__global__ void k_quality(View v, int buf_from_ctrl, double *err_sum /* [2] optional: sum, count */) {
+    __shared__ double scratch[2 * 16];
+    const int N = v.dm.N, M = v.dm.M;
+    const int cur = buf_from_ctrl ? v.ctrl->cur : 0;
+    const double *fs = v.fs + (size_t)cur * N * 16, *rho = v.rho + (size_t)cur * M;
+    double es = 0, en = 0;
+    for (int l = blockIdx.x * blockDim.x + threadIdx.x; l < M; l += gridDim.x * blockDim.x) {
+        const int a = v.lm_anchor[l];
+        double rec_a[kFrameRec], Rwc[9], pwc[3], y0[3], x[3], t[3];
+        frame_record(rec_a, fs + 16 * a, v.cam_ext + 7 * a, v.sic + 4 * a);
+        m3_mul(Rwc, rec_a, rec_a + 12);
+        m3_vec(t, rec_a, rec_a + 21);
+        v3_add(pwc, rec_a + 9, t);
+        const double inv = 1.0 / rho[l];
+        v3_set(y0, v.lm_zref[2 * l] * inv, v.lm_zref[2 * l + 1] * inv, inv);
+        m3_vec(x, Rwc, y0);
+        v3_add(x, x, pwc); // Track::get_landmark_point (track.cpp:137-141)
+        double q = 0, qn = 0;
+        bool ok = true;
+        const int o0 = v.lm_ptr[l], nobs = v.lm_ptr[l + 1] - o0;
+        for (int k = -1; k < nobs; ++k) {
+            const int f = k < 0 ? a : v.obs_frame[o0 + k];
+            const double zu = k < 0 ? v.lm_zref[2 * l] : v.obs_z[2 * (size_t)(o0 + k)], zv = k < 0 ? v.lm_zref[2 * l + 1] : v.obs_z[2 * (size_t)(o0 + k) + 1];
+            double rec[kFrameRec], Rf[9], pf[3], dd[3], y[3];
+            frame_record(rec, fs + 16 * f, v.cam_ext + 7 * f, v.sic + 4 * f);
+            m3_mul(Rf, rec, rec + 12);
+            m3_vec(t, rec, rec + 21);
+            v3_add(pf, rec + 9, t);
+            v3_sub(dd, x, pf);
+            m3_tvec(y, Rf, dd);
+            if (!err_sum && (y[2] <= 1.0e-3 || y[2] > 50)) {
+                ok = false;
+                break;
+            }
+            const double *K = v.intr + 4 * f;
+            const double du = (y[0] / y[2]) * K[0] + K[2] - (zu * K[0] + K[2]), dv = (y[1] / y[2]) * K[1] + K[3] - (zv * K[1] + K[3]);
+            q += sqrt(du * du + dv * dv);
+            qn += 1.0;
+        }
+        if (err_sum) {
+            es += q, en += qn;
+        } else {
+            if (v.lm_valid) v.lm_valid[l] = ok ? 1 : 0;
+            if (ok && v.lm_quality) v.lm_quality[l] = q / fmax(qn, 1.0);
+        }
+    }
+    if (err_sum) {
+        double s[2] = {es, en};
+        block_sum<2>(s, scratch);
+        if (threadIdx.x == 0) {
+            atomicAdd(&err_sum[0], s[0]);
+            atomicAdd(&err_sum[1], s[1]);
+        }
+    }
+}
+
+// Lambda = S^T S, eta = S^T s of the marginalization prior (once per upload)
+__global__ void k_prior_prep(const double *S, const double *s, int D, double *Lambda, double *eta) {
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < D * (D + 1); e += gridDim.x * blockDim.x) {
+        const int a = e / (D + 1), b = e - a * (D + 1);
+        double acc = 0;
+        if (b < D) {
+            for (int r = 0; r < D; ++r) acc += S[(size_t)r * D + a] * S[(size_t)r * D + b];
+            Lambda[(size_t)a * D + b] = acc;
+        } else {
+            for (int r = 0; r < D; ++r) acc += S[(size_t)r * D + a] * s[r];
+            eta[a] = acc;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// host-side launchers
+// ------------------------------------------------------------------------------------------------------
+size_t linearize_lds_bytes(const Dims &dm) {
+    const int N = dm.N;
+    size_t common = (size_t)(N * 16 + N * kFrameRec + 160 + 16);
+    size_t lm = (size_t)dm.lm_slots * (40 * N + 46) + dm.lm_slots + (dm.lm_slots + 1) / 2 + 2;
+    size_t pl = (size_t)dm.plane_slots * (dm.P6 + 2);
+    size_t pre = 16 + 450 + 450 + 16;
+    size_t pri = (size_t)dm.prior_n * (15 + 9 + 15) + 8;
+    size_t role = lm;
+    if (pl > role) role = pl;
+    if (pre > role) role = pre;
+    if (pri > role) role = pri;
+    return (common + role) * sizeof(double);
+}
+
+int tiles_per_thread(const Dims &dm) { return (dm.n_tasks + kLinThreads - 1) / kLinThreads; }
+
+template <int T>
+static hipError_t launch_lin_T(const View &v, hipStream_t st) {
+    const int grid = v.dm.G_lm + v.dm.G_plane + v.dm.G_pre + v.dm.G_prior;
+    const size_t lds = linearize_lds_bytes(v.dm);
+#ifndef PV_HIPEMU
+    static size_t configured = 0;
+    if (lds > configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_linearize<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        configured = lds;
+    }
+#endif
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_linearize<T>), dim3(grid), dim3(kLinThreads), lds, st, v);
+    return hipGetLastError();
+}
+
+hipError_t launch_linearize(const View &v, hipStream_t st) {
+    const int T = tiles_per_thread(v.dm);
+    if (T <= 1) return launch_lin_T<1>(v, st);
+    if (T <= 2) return launch_lin_T<2>(v, st);
+    if (T <= 4) return launch_lin_T<4>(v, st);
+    if (T <= 6) return launch_lin_T<6>(v, st);
+    return launch_lin_T<9>(v, st);
+}
+
+hipError_t launch_reduce(const View &v, hipStream_t st) {
+    const size_t total = (size_t)v.dm.n_tasks * 9 + (size_t)kNumPoseVec * v.dm.P6 + kNumLinScal;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(k_reduce, dim3(grid), dim3(256), 0, st, v);
+    return hipGetLastError();
+}
+
+size_t dense_lds_bytes(const Dims &dm, int *lds_matrix) {
+    const size_t P = dm.P, ld = P + 1;
+    const size_t vec = (128 + 8 * ld) * sizeof(double);
+    const size_t mat = (P + 1) * ld * sizeof(double);
+    *lds_matrix = (mat + vec <= 150 * 1024) ? 1 : 0;
+    return *lds_matrix ? mat + vec : vec;
+}
+
+hipError_t launch_dense(const View &v, hipStream_t st) {
+    int lm;
+    const size_t lds = dense_lds_bytes(v.dm, &lm);
+#ifndef PV_HIPEMU
+    static size_t configured = 0;
+    if (lds > configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dense), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        configured = lds;
+    }
+#endif
+    hipLaunchKernelGGL(k_dense, dim3(1), dim3(kDenseThreads), lds, st, v, lm);
+    return hipGetLastError();
+}
+
+hipError_t launch_backsub(const View &v, hipStream_t st) {
+    hipLaunchKernelGGL(k_backsub, dim3(v.dm.G_back), dim3(256), 0, st, v);
+    return hipGetLastError();
+}
+hipError_t launch_back_reduce(const View &v, hipStream_t st) {
+    hipLaunchKernelGGL(k_back_reduce, dim3(1), dim3(64), 0, st, v, v.dm.G_back);
+    return hipGetLastError();
+}
+hipError_t launch_quality(const View &v, hipStream_t st, int buf_from_ctrl, double *err_sum) {
+    int grid = (v.dm.M + 255) / 256;
+    if (grid < 1) grid = 1;
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(k_quality, dim3(grid), dim3(256), 0, st, v, buf_from_ctrl, err_sum);
+    return hipGetLastError();
+}
+hipError_t launch_prior_prep(const double *S, const double *s, int D, double *Lambda, double *eta, hipStream_t st) {
+    int grid = (D * (D + 1) + 255) / 256;
+    hipLaunchKernelGGL(k_prior_prep, dim3(grid), dim3(256), 0, st, S, s, D, Lambda, eta);
+    return hipGetLastError();
+}
+
+} // namespace pvba

@@ -1,0 +1,463 @@
+// ba_solver.cpp -- host side of the device-resident bundle adjustment.
+//
+// Replaces the ceres::Problem assembly + ceres::Solve call of BundleAdjustorSolver::solve
+// (pvio/src/pvio/estimation/bundle_adjustor.cpp:63-299): the flat problem is uploaded once, the whole
+// trust-region loop runs on the device (kernels in ba_kernels.hip), the host only replays a graph of
+// "slots" (linearize -> reduce -> dense -> backsub) until the device-side state machine reports done.
+#include "ba_solver.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+
+#include "ba_kernels.h"
+
+namespace pvba {
+
+DevicePool::~DevicePool() { release(); }
+void DevicePool::release() {
+    for (auto &s : slots_)
+        if (s.ptr) (void)hipFree(s.ptr);
+    slots_.clear();
+    total_ = 0;
+}
+void *DevicePool::get(const char *name, size_t bytes, bool *grew) {
+    if (bytes == 0) bytes = 8;
+    for (auto &s : slots_)
+        if (s.name == name) {
+            if (s.bytes >= bytes) return s.ptr;
+            (void)hipFree(s.ptr);
+            total_ -= s.bytes;
+            s.ptr = nullptr;
+            const size_t nb = bytes + bytes / 4;
+            if (hipMalloc(&s.ptr, nb) != hipSuccess) return nullptr;
+            s.bytes = nb;
+            total_ += nb;
+            if (grew) *grew = true;
+            return s.ptr;
+        }
+    Slot s;
+    s.name = name;
+    if (hipMalloc(&s.ptr, bytes) != hipSuccess) return nullptr;
+    s.bytes = bytes;
+    total_ += bytes;
+    slots_.push_back(s);
+    if (grew) *grew = true;
+    return s.ptr;
+}
+
+BASolver::BASolver(int device, int rank, int world, bool use_graph) : device_(device), rank_(rank), world_(world), use_graph_(use_graph) {
+    (void)hipSetDevice(device_);
+    (void)hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking);
+    (void)hipEventCreate(&ev0_);
+    (void)hipEventCreate(&ev1_);
+    (void)hipHostMalloc(&h_ctrl_, sizeof(Ctrl));
+}
+BASolver::~BASolver() {
+    invalidate_graph();
+    if (h_ctrl_) (void)hipHostFree(h_ctrl_);
+    if (ev0_) (void)hipEventDestroy(ev0_);
+    if (ev1_) (void)hipEventDestroy(ev1_);
+    if (stream_) (void)hipStreamDestroy(stream_);
+}
+int BASolver::fail(int code, const std::string &msg) {
+    err_ = msg;
+    return code;
+}
+int BASolver::check(hipError_t e, const char *what) {
+    if (e == hipSuccess) return PVIO_OK;
+    return fail(PVIO_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+void BASolver::invalidate_graph() {
+    if (graph_exec_) (void)hipGraphExecDestroy(graph_exec_);
+    if (graph_) (void)hipGraphDestroy(graph_);
+    graph_exec_ = nullptr;
+    graph_ = nullptr;
+    graph_slots_ = 0;
+}
+
+template <typename T>
+static bool up(DevicePool &pool, const char *name, const T *src, size_t n, const T **dst, hipStream_t st, bool *grew) {
+    T *p = static_cast<T *>(pool.get(name, n * sizeof(T), grew));
+    if (!p) return false;
+    if (n && src && hipMemcpyAsync(p, src, n * sizeof(T), hipMemcpyHostToDevice, st) != hipSuccess) return false;
+    *dst = p;
+    return true;
+}
+template <typename T>
+static bool dev(DevicePool &pool, const char *name, size_t n, T **dst, bool *grew) {
+    T *p = static_cast<T *>(pool.get(name, n * sizeof(T), grew));
+    *dst = p;
+    return p != nullptr;
+}
+
+int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st) {
+    if (!pb || !st || !st->frame_state) return fail(PVIO_ERR_INVALID_ARGUMENT, "null problem/state");
+    const int N = pb->n_frames, M = pb->n_landmarks, F = pb->n_obs;
+    if (N < 1 || N > kMaxFrames) return fail(PVIO_ERR_UNSUPPORTED, "n_frames must be in [1, 32]");
+    if (M < 0 || F < 0 || (M > 0 && !st->lm_inv_depth)) return fail(PVIO_ERR_INVALID_ARGUMENT, "bad landmark arrays");
+    if (check(hipSetDevice(device_), "hipSetDevice")) return PVIO_ERR_HIP;
+    Dims dm{};
+    dm.N = N, dm.M = M, dm.F = F;
+    dm.use_inertial = pb->use_inertial ? 1 : 0;
+    dm.prior_n = pb->prior_n;
+    dm.d = (dm.use_inertial || dm.prior_n > 0) ? 15 : 6;
+    dm.P = dm.d * N, dm.P6 = 6 * N;
+    dm.n_tasks = 4 * N * (N + 1) / 2;
+    dm.max_iter = pb->max_iterations;
+    dm.world = world_, dm.rank = rank_;
+    dm.n_plane = pb->n_plane_factors;
+
+    // ---- block usage (Ceres removes constant and unreferenced parameter blocks from the reduced program) ----
+    std::vector<uint8_t> pose_used(N, 0), motion_used(N, 0), pose_active(N, 0), motion_active(N, 0), pre_valid(N, 0);
+    std::vector<int32_t> obs_lm(F, 0);
+    int maxK = 1;
+    for (int l = 0; l < M; ++l) {
+        const int b = pb->lm_obs_ptr[l], e = pb->lm_obs_ptr[l + 1];
+        if (e < b || e > F) return fail(PVIO_ERR_INVALID_ARGUMENT, "lm_obs_ptr is not a valid CSR");
+        const int a = pb->lm_anchor_frame[l];
+        if (a < 0 || a >= N) return fail(PVIO_ERR_INVALID_ARGUMENT, "anchor frame out of range");
+        if (e > b) pose_used[a] = 1;
+        maxK = std::max(maxK, e - b);
+        uint32_t seen = 0;
+        for (int o = b; o < e; ++o) {
+            const int t = pb->obs_frame[o];
+            if (t < 0 || t >= N || t == a) return fail(PVIO_ERR_INVALID_ARGUMENT, "observation frame out of range or equal to the anchor");
+            if (seen & (1u << t)) return fail(PVIO_ERR_UNSUPPORTED, "a landmark lists the same target frame twice");
+            seen |= 1u << t;
+            obs_lm[o] = l;
+            pose_used[t] = 1;
+        }
+    }
+    if (maxK > kLinThreads) return fail(PVIO_ERR_UNSUPPORTED, "too many observations per landmark");
+    if (dm.use_inertial && pb->preint_valid)
+        for (int j = 1; j < N; ++j)
+            if (pb->preint_valid[j]) {
+                pre_valid[j] = 1;
+                pose_used[j - 1] = pose_used[j] = motion_used[j - 1] = motion_used[j] = 1;
+            }
+    for (int i = 0; i < dm.prior_n; ++i) {
+        const int f = pb->prior_frames[i];
+        if (f < 0 || f >= N) return fail(PVIO_ERR_INVALID_ARGUMENT, "prior frame out of range");
+        pose_used[f] = motion_used[f] = 1;
+    }
+    for (int f = 0; f < dm.n_plane; ++f) {
+        bool any_free = false;
+        for (int o = pb->plane_obs_ptr[f]; o < pb->plane_obs_ptr[f + 1]; ++o) any_free |= !pb->frame_fixed[pb->plane_obs_frame[o]];
+        if (any_free)
+            for (int o = pb->plane_obs_ptr[f]; o < pb->plane_obs_ptr[f + 1]; ++o) pose_used[pb->plane_obs_frame[o]] = 1;
+    }
+    for (int i = 0; i < N; ++i) {
+        pose_active[i] = pose_used[i] && !pb->frame_fixed[i];
+        motion_active[i] = (dm.d == 15) && motion_used[i];
+    }
+
+    // ---- landmark chunks: <= lm_slots landmarks and <= 256 factors each (one thread per factor) ----
+    const size_t lds_budget = 112 * 1024;
+    dm.lm_slots = (int)std::max<size_t>(1, std::min<size_t>(lds_budget / 8 / (40 * N + 46), (size_t)kLinThreads));
+    std::vector<int32_t> chunk_lm;
+    chunk_lm.push_back(0);
+    {
+        int cnt = 0, fac = 0;
+        for (int l = 0; l < M; ++l) {
+            const int k = pb->lm_obs_ptr[l + 1] - pb->lm_obs_ptr[l];
+            if (cnt > 0 && (cnt + 1 > dm.lm_slots || fac + k > kLinThreads)) {
+                chunk_lm.push_back(l);
+                cnt = 0, fac = 0;
+            }
+            ++cnt, fac += k;
+        }
+        if (M > 0) chunk_lm.push_back(M);
+    }
+    dm.n_chunks = (int)chunk_lm.size() - 1;
+    dm.plane_slots = (int)std::max<size_t>(1, std::min<size_t>(lds_budget / 8 / (dm.P6 + 2), (size_t)kLinThreads));
+    std::vector<int32_t> plane_chunk;
+    for (int f = 0; f <= dm.n_plane; f += dm.plane_slots) plane_chunk.push_back(f);
+    if (plane_chunk.empty() || plane_chunk.back() != dm.n_plane) plane_chunk.push_back(dm.n_plane);
+    dm.n_plane_chunks = (int)plane_chunk.size() - 1;
+
+    hipDeviceProp_t prop;
+    if (check(hipGetDeviceProperties(&prop, device_), "hipGetDeviceProperties")) return PVIO_ERR_HIP;
+    const int cus = std::max(1, prop.multiProcessorCount);
+    dm.G_lm = std::max(1, std::min(dm.n_chunks, cus));
+    dm.G_plane = dm.n_plane > 0 ? std::max(1, std::min(dm.n_plane_chunks, std::max(1, cus / 4))) : 0;
+    dm.G_pre = dm.use_inertial ? N - 1 : 0;
+    dm.G_prior = dm.prior_n > 0 ? std::max(1, std::min(16, (15 * dm.prior_n + 31) / 32)) : 0;
+    dm.G_back = std::max(1, std::min(64, (M + 255) / 256));
+    dm.n_back_rows = world_ > 1 ? 1 : dm.G_back;
+
+    // 3x3 tile tasks over the upper block triangle
+    std::vector<int32_t> task_desc;
+    for (int fi = 0; fi < N; ++fi)
+        for (int fj = fi; fj < N; ++fj)
+            for (int s = 0; s < 4; ++s) task_desc.push_back(fi | (fj << 8) | ((s >> 1) << 16) | ((s & 1) << 17));
+
+    // ---- device buffers ----
+    bool grew = false;
+    View v{};
+    v.dm = dm;
+    const size_t Ns = N, Ms = std::max(M, 1), Fs = std::max(F, 1);
+    bool ok = true;
+    ok &= up(pool_, "frame_fixed", pb->frame_fixed, Ns, &v.frame_fixed, stream_, &grew);
+    ok &= up(pool_, "pose_active", pose_active.data(), Ns, &v.pose_active, stream_, &grew);
+    ok &= up(pool_, "motion_active", motion_active.data(), Ns, &v.motion_active, stream_, &grew);
+    ok &= up(pool_, "cam_ext", pb->cam_extrinsic, Ns * 7, &v.cam_ext, stream_, &grew);
+    ok &= up(pool_, "imu_ext", pb->imu_extrinsic, Ns * 7, &v.imu_ext, stream_, &grew);
+    ok &= up(pool_, "sic", pb->sqrt_inv_cov, Ns * 4, &v.sic, stream_, &grew);
+    ok &= up(pool_, "intr", pb->intrinsics, Ns * 4, &v.intr, stream_, &grew);
+    ok &= up(pool_, "lm_anchor", pb->lm_anchor_frame, (size_t)M, &v.lm_anchor, stream_, &grew);
+    ok &= up(pool_, "lm_ptr", pb->lm_obs_ptr, (size_t)M + 1, &v.lm_ptr, stream_, &grew);
+    ok &= up(pool_, "lm_zref", pb->lm_anchor_z, (size_t)M * 2, &v.lm_zref, stream_, &grew);
+    ok &= up(pool_, "obs_frame", pb->obs_frame, (size_t)F, &v.obs_frame, stream_, &grew);
+    ok &= up(pool_, "obs_z", pb->obs_z, (size_t)F * 2, &v.obs_z, stream_, &grew);
+    ok &= up(pool_, "obs_lm", obs_lm.data(), (size_t)F, &v.obs_lm, stream_, &grew);
+    ok &= up(pool_, "chunk_lm", chunk_lm.data(), chunk_lm.size(), &v.chunk_lm, stream_, &grew);
+    ok &= up(pool_, "task_desc", task_desc.data(), task_desc.size(), &v.task_desc, stream_, &grew);
+    ok &= up(pool_, "pre_valid", pre_valid.data(), Ns, &v.pre_valid, stream_, &grew);
+    ok &= up(pool_, "pre_delta", dm.use_inertial ? pb->preint_delta : nullptr, Ns * 11, &v.pre_delta, stream_, &grew);
+    ok &= up(pool_, "pre_U", dm.use_inertial ? pb->preint_sqrt_inv_cov : nullptr, Ns * 225, &v.pre_U, stream_, &grew);
+    ok &= up(pool_, "pre_jac", dm.use_inertial ? pb->preint_jacobian : nullptr, Ns * 45, &v.pre_jac, stream_, &grew);
+    const size_t Dp = 15 * (size_t)dm.prior_n;
+    ok &= up(pool_, "prior_frames", pb->prior_frames, (size_t)dm.prior_n, &v.prior_frames, stream_, &grew);
+    ok &= up(pool_, "prior_S", pb->prior_S, Dp * Dp, &v.prior_S, stream_, &grew);
+    ok &= up(pool_, "prior_s", pb->prior_s, Dp, &v.prior_s, stream_, &grew);
+    ok &= up(pool_, "prior_lin", pb->prior_lin_state, (size_t)dm.prior_n * 16, &v.prior_lin, stream_, &grew);
+    double *Lambda = nullptr, *eta = nullptr;
+    ok &= dev(pool_, "prior_Lambda", Dp * Dp, &Lambda, &grew);
+    ok &= dev(pool_, "prior_eta", Dp, &eta, &grew);
+    v.prior_Lambda = Lambda, v.prior_eta = eta;
+    const size_t npo = dm.n_plane ? (size_t)pb->plane_obs_ptr[dm.n_plane] : 0;
+    ok &= up(pool_, "plane_ptr", pb->plane_obs_ptr, (size_t)dm.n_plane + 1, &v.plane_ptr, stream_, &grew);
+    ok &= up(pool_, "plane_frame", pb->plane_obs_frame, npo, &v.plane_frame, stream_, &grew);
+    ok &= up(pool_, "plane_chunk", plane_chunk.data(), plane_chunk.size(), &v.plane_chunk, stream_, &grew);
+    ok &= up(pool_, "plane_z", pb->plane_obs_z, npo * 2, &v.plane_z, stream_, &grew);
+    ok &= up(pool_, "plane_normal", pb->plane_normal, (size_t)dm.n_plane * 3, &v.plane_normal, stream_, &grew);
+    ok &= up(pool_, "plane_dist", pb->plane_distance, (size_t)dm.n_plane, &v.plane_dist, stream_, &grew);
+    v.plane_sic = pb->plane_sqrt_inv_cov;
+    // state + work
+    ok &= dev(pool_, "ctrl", 1, &v.ctrl, &grew);
+    ok &= dev(pool_, "fs", 2 * Ns * 16, &v.fs, &grew);
+    ok &= dev(pool_, "fs_user", Ns * 16, &v.fs_user, &grew);
+    ok &= dev(pool_, "bias0_lin", Ns * 6, &v.bias0_lin, &grew);
+    ok &= dev(pool_, "rho", 2 * Ms, &v.rho, &grew);
+    ok &= dev(pool_, "cl", Ms, &v.cl, &grew);
+    ok &= dev(pool_, "Hll", 2 * Ms, &v.Hll, &grew);
+    ok &= dev(pool_, "bl", 2 * Ms, &v.bl, &grew);
+    ok &= dev(pool_, "Dl", 2 * Ms, &v.Dl, &grew);
+    ok &= dev(pool_, "ghl", 2 * Ms, &v.ghl, &grew);
+    ok &= dev(pool_, "gnl", 2 * Ms, &v.gnl, &grew);
+    ok &= dev(pool_, "Wa", 2 * Ms * 6, &v.Wa, &grew);
+    ok &= dev(pool_, "Wt", 2 * Fs * 6, &v.Wt, &grew);
+    const size_t G = (size_t)dm.G_lm + dm.G_plane, nS = (size_t)dm.n_tasks * 9, nV = (size_t)kNumPoseVec * dm.P6;
+    ok &= dev(pool_, "part_S", G * nS, &v.part_S, &grew);
+    ok &= dev(pool_, "part_vec", G * nV, &v.part_vec, &grew);
+    ok &= dev(pool_, "part_scal", G * kNumLinScal, &v.part_scal, &grew);
+    ok &= dev(pool_, "red", nS + nV + kNumLinScal, &v.red, &grew);
+    ok &= dev(pool_, "back_part", (size_t)std::max(dm.G_back, 1) * kNumBackScal, &v.back_part, &grew);
+    ok &= dev(pool_, "back_red", kNumBackScal, &v.back_red, &grew);
+    ok &= dev(pool_, "pre_H", Ns * 900, &v.pre_H, &grew);
+    ok &= dev(pool_, "pre_g", Ns * 30, &v.pre_g, &grew);
+    ok &= dev(pool_, "pre_cost", Ns, &v.pre_cost, &grew);
+    ok &= dev(pool_, "prior_H", Dp * Dp, &v.prior_H, &grew);
+    ok &= dev(pool_, "prior_g", Dp, &v.prior_g, &grew);
+    ok &= dev(pool_, "prior_cost", 1, &v.prior_cost, &grew);
+    const size_t P = dm.P;
+    ok &= dev(pool_, "Smat", (P + 1) * (P + 1), &v.Smat, &grew);
+    ok &= dev(pool_, "cp", P, &v.cp, &grew);
+    ok &= dev(pool_, "Dp", P, &v.Dp, &grew);
+    ok &= dev(pool_, "gtot", P, &v.gtot, &grew);
+    ok &= dev(pool_, "ghp", P, &v.ghp, &grew);
+    ok &= dev(pool_, "vstep", P, &v.vstep, &grew);
+    ok &= dev(pool_, "ystep", P, &v.ystep, &grew);
+    ok &= dev(pool_, "lm_quality", Ms, &v.lm_quality, &grew);
+    ok &= dev(pool_, "lm_valid", Ms, &v.lm_valid, &grew);
+    trace_cap_ = dm.max_iter + 2;
+    ok &= dev(pool_, "trace", (size_t)trace_cap_, &v.trace, &grew);
+    v.trace_states = nullptr;
+    if (!ok) return fail(PVIO_ERR_OUT_OF_MEMORY, "device allocation / upload failed");
+    if (world_ > 1) v.back_part = v.back_part; // rows are reduced into back_red and all-reduced (see enqueue_slot)
+
+    // initial state: kept on the host (tiny for frames) and on the device in buffer 0
+    h_init_fs_.assign(st->frame_state, st->frame_state + Ns * 16);
+    h_init_rho_.assign(st->lm_inv_depth, st->lm_inv_depth + M);
+    double *fs_init = nullptr, *rho_init = nullptr;
+    ok &= dev(pool_, "fs_init", Ns * 16, &fs_init, &grew);
+    ok &= dev(pool_, "rho_init", Ms, &rho_init, &grew);
+    if (!ok) return fail(PVIO_ERR_OUT_OF_MEMORY, "device allocation failed");
+    if (check(hipMemcpyAsync(fs_init, h_init_fs_.data(), Ns * 16 * sizeof(double), hipMemcpyHostToDevice, stream_), "H2D state")) return PVIO_ERR_HIP;
+    if (M && check(hipMemcpyAsync(rho_init, h_init_rho_.data(), (size_t)M * sizeof(double), hipMemcpyHostToDevice, stream_), "H2D state")) return PVIO_ERR_HIP;
+    if (dm.prior_n > 0 && check(launch_prior_prep(v.prior_S, v.prior_s, (int)Dp, Lambda, eta, stream_), "k_prior_prep")) return PVIO_ERR_HIP;
+
+    const bool dims_changed = std::memcmp(&v.dm, &v_.dm, sizeof(Dims)) != 0;
+    if (grew || dims_changed || std::memcmp(&v, &v_, sizeof(View)) != 0) invalidate_graph();
+    v_ = v;
+    uploaded_ = true;
+    return check(hipStreamSynchronize(stream_), "upload sync");
+}
+
+int BASolver::enqueue_slot() {
+    hipError_t e;
+    View vl = v_;
+    if (world_ > 1) vl.back_part = v_.back_red; // k_linearize reads the all-reduced row
+    if ((e = launch_linearize(vl, stream_)) != hipSuccess) return check(e, "k_linearize");
+    if ((e = launch_reduce(v_, stream_)) != hipSuccess) return check(e, "k_reduce");
+    if (world_ > 1) {
+        const size_t n = (size_t)v_.dm.n_tasks * 9 + (size_t)kNumPoseVec * v_.dm.P6 + kNumLinScal;
+        // scalar 4 (max |b_l|) must not be summed: reduce it separately with max
+        if (comm_allreduce(comm_, v_.red + n - kNumLinScal + 4, 1, 1, stream_)) return fail(PVIO_ERR_COMM, "all-reduce(max) failed");
+        if (comm_allreduce(comm_, v_.red, n - kNumLinScal + 4, 0, stream_)) return fail(PVIO_ERR_COMM, "all-reduce failed");
+        if (comm_allreduce(comm_, v_.red + n - kNumLinScal + 5, 3, 0, stream_)) return fail(PVIO_ERR_COMM, "all-reduce failed");
+    }
+    if ((e = launch_dense(v_, stream_)) != hipSuccess) return check(e, "k_dense");
+    if ((e = launch_backsub(v_, stream_)) != hipSuccess) return check(e, "k_backsub");
+    if (world_ > 1) {
+        if ((e = launch_back_reduce(v_, stream_)) != hipSuccess) return check(e, "k_back_reduce");
+        if (comm_allreduce(comm_, v_.back_red, kNumBackScal, 0, stream_)) return fail(PVIO_ERR_COMM, "all-reduce failed");
+    }
+    return PVIO_OK;
+}
+
+int BASolver::run_slots(int n_slots) {
+    if (use_graph_ && world_ == 1) {
+        if (!graph_exec_ || graph_slots_ != n_slots) {
+            invalidate_graph();
+            if (check(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal), "begin capture")) return PVIO_ERR_HIP;
+            int rc = PVIO_OK;
+            for (int s = 0; s < n_slots && rc == PVIO_OK; ++s) rc = enqueue_slot();
+            hipError_t e = hipStreamEndCapture(stream_, &graph_);
+            if (rc != PVIO_OK) return rc;
+            if (check(e, "end capture")) return PVIO_ERR_HIP;
+            if (check(hipGraphInstantiate(&graph_exec_, graph_, nullptr, nullptr, 0), "graph instantiate")) return PVIO_ERR_HIP;
+            graph_slots_ = n_slots;
+        }
+        return check(hipGraphLaunch(graph_exec_, stream_), "graph launch");
+    }
+    for (int s = 0; s < n_slots; ++s) {
+        int rc = enqueue_slot();
+        if (rc != PVIO_OK) return rc;
+    }
+    return PVIO_OK;
+}
+
+int BASolver::solve(pvio_ba_summary *sum) {
+    if (!uploaded_) return fail(PVIO_ERR_INVALID_ARGUMENT, "no problem uploaded");
+    auto t0 = std::chrono::steady_clock::now();
+    if (check(hipSetDevice(device_), "hipSetDevice")) return PVIO_ERR_HIP;
+    const Dims &dm = v_.dm;
+    const size_t Ns = dm.N, Ms = std::max(dm.M, 1);
+    // trace states are optional and live in a separate buffer so that bench runs do not pay for them
+    const bool want_states = sum && sum->trace_states && sum->trace_capacity > 0;
+    {
+        double *ts = nullptr;
+        if (want_states) {
+            bool grew = false;
+            if (!dev(pool_, "trace_states", (size_t)trace_cap_ * (Ns * 16 + dm.M), &ts, &grew)) return fail(PVIO_ERR_OUT_OF_MEMORY, "trace_states");
+        }
+        if (ts != v_.trace_states) {
+            v_.trace_states = ts;
+            invalidate_graph();
+        }
+    }
+    // reset: state buffer 0 <- initial state, user state, control block
+    double *fs_init = static_cast<double *>(pool_.get("fs_init", Ns * 16 * sizeof(double)));
+    double *rho_init = static_cast<double *>(pool_.get("rho_init", Ms * sizeof(double)));
+    if (check(hipMemcpyAsync(v_.fs, fs_init, Ns * 16 * sizeof(double), hipMemcpyDeviceToDevice, stream_), "reset fs")) return PVIO_ERR_HIP;
+    if (check(hipMemcpyAsync(v_.fs_user, fs_init, Ns * 16 * sizeof(double), hipMemcpyDeviceToDevice, stream_), "reset user")) return PVIO_ERR_HIP;
+    if (dm.M && check(hipMemcpyAsync(v_.rho, rho_init, (size_t)dm.M * sizeof(double), hipMemcpyDeviceToDevice, stream_), "reset rho")) return PVIO_ERR_HIP;
+    std::memset(h_ctrl_, 0, sizeof(Ctrl));
+    h_ctrl_->mode = MODE_INIT;
+    h_ctrl_->radius = 1e4;        // initial_trust_region_radius
+    h_ctrl_->mu = 1e-8;           // DoglegStrategy kMinMu
+    h_ctrl_->termination = PVIO_TERM_NO_CONVERGENCE;
+    h_ctrl_->trace_cap = trace_cap_;
+    if (check(hipMemcpyAsync(v_.ctrl, h_ctrl_, sizeof(Ctrl), hipMemcpyHostToDevice, stream_), "reset ctrl")) return PVIO_ERR_HIP;
+    if (check(hipEventRecord(ev0_, stream_), "event")) return PVIO_ERR_HIP;
+    // every slot = one pass of [linearize, reduce, dense, backsub]; iteration 0 + max_iter iterations (+ slack for
+    // mu escalations); relaunch while the device has not reported done
+    const int n_slots = dm.max_iter + 2;
+    int rounds = 0;
+    for (;;) {
+        int rc = run_slots(n_slots);
+        if (rc != PVIO_OK) return rc;
+        if (check(hipMemcpyAsync(h_ctrl_, v_.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, stream_), "ctrl D2H")) return PVIO_ERR_HIP;
+        if (check(hipEventRecord(ev1_, stream_), "event")) return PVIO_ERR_HIP;
+        if (check(hipStreamSynchronize(stream_), "solve sync")) return PVIO_ERR_HIP;
+        if (h_ctrl_->done || ++rounds > 16) break;
+    }
+    if (!h_ctrl_->done) return fail(PVIO_ERR_HIP, "device state machine did not terminate");
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, ev0_, ev1_);
+    if (sum) {
+        sum->termination = h_ctrl_->termination;
+        sum->is_usable = h_ctrl_->termination != PVIO_TERM_FAILURE;
+        sum->num_iterations = h_ctrl_->iter;
+        sum->num_successful_steps = h_ctrl_->num_success;
+        sum->initial_cost = h_ctrl_->initial_cost;
+        sum->final_cost = h_ctrl_->x_cost;
+        sum->device_seconds = ms * 1e-3;
+        sum->trace_len = 0;
+        if (sum->trace && sum->trace_capacity > 0) {
+            const int n = std::min(std::min(h_ctrl_->trace_len, trace_cap_), sum->trace_capacity);
+            std::vector<TraceRec> tr(n);
+            if (n && check(hipMemcpy(tr.data(), v_.trace, n * sizeof(TraceRec), hipMemcpyDeviceToHost), "trace D2H")) return PVIO_ERR_HIP;
+            static_assert(sizeof(TraceRec) == sizeof(pvio_ba_iteration), "trace layout");
+            std::memcpy(sum->trace, tr.data(), n * sizeof(TraceRec));
+            sum->trace_len = n;
+            if (want_states && n)
+                if (check(hipMemcpy(sum->trace_states, v_.trace_states, (size_t)n * (Ns * 16 + dm.M) * sizeof(double), hipMemcpyDeviceToHost), "trace states D2H")) return PVIO_ERR_HIP;
+        }
+        sum->solve_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return PVIO_OK;
+}
+
+int BASolver::download(pvio_ba_state *st) {
+    if (!uploaded_ || !st) return fail(PVIO_ERR_INVALID_ARGUMENT, "nothing to download");
+    const Dims &dm = v_.dm;
+    const int cur = h_ctrl_->cur;
+    if (check(launch_quality(v_, stream_, 1, nullptr), "k_quality")) return PVIO_ERR_HIP;
+    if (check(hipMemcpyAsync(st->frame_state, v_.fs + (size_t)cur * dm.N * 16, (size_t)dm.N * 16 * sizeof(double), hipMemcpyDeviceToHost, stream_), "D2H")) return PVIO_ERR_HIP;
+    if (dm.M) {
+        if (check(hipMemcpyAsync(st->lm_inv_depth, v_.rho + (size_t)cur * dm.M, (size_t)dm.M * sizeof(double), hipMemcpyDeviceToHost, stream_), "D2H")) return PVIO_ERR_HIP;
+        std::vector<double> q;
+        std::vector<uint8_t> val;
+        if (st->lm_quality || st->lm_valid) {
+            q.resize(dm.M), val.resize(dm.M);
+            if (check(hipMemcpyAsync(q.data(), v_.lm_quality, (size_t)dm.M * sizeof(double), hipMemcpyDeviceToHost, stream_), "D2H")) return PVIO_ERR_HIP;
+            if (check(hipMemcpyAsync(val.data(), v_.lm_valid, (size_t)dm.M, hipMemcpyDeviceToHost, stream_), "D2H")) return PVIO_ERR_HIP;
+            if (check(hipStreamSynchronize(stream_), "sync")) return PVIO_ERR_HIP;
+            for (int l = 0; l < dm.M; ++l) {
+                if (st->lm_valid) st->lm_valid[l] = val[l];
+                if (st->lm_quality && val[l]) st->lm_quality[l] = q[l]; // invalidated landmarks keep their old quality (:294)
+            }
+        }
+    }
+    return check(hipStreamSynchronize(stream_), "download sync");
+}
+
+int BASolver::reprojection_error(double *out) {
+    if (!uploaded_ || !out) return fail(PVIO_ERR_INVALID_ARGUMENT, "nothing uploaded");
+    double *acc = static_cast<double *>(pool_.get("err_acc", 2 * sizeof(double)));
+    if (!acc) return fail(PVIO_ERR_OUT_OF_MEMORY, "err_acc");
+    if (check(hipMemsetAsync(acc, 0, 2 * sizeof(double), stream_), "memset")) return PVIO_ERR_HIP;
+    // evaluates the uploaded initial state (buffer 0 after a reset)
+    const size_t Ns = v_.dm.N, Ms = std::max(v_.dm.M, 1);
+    double *fs_init = static_cast<double *>(pool_.get("fs_init", Ns * 16 * sizeof(double)));
+    double *rho_init = static_cast<double *>(pool_.get("rho_init", Ms * sizeof(double)));
+    if (check(hipMemcpyAsync(v_.fs, fs_init, Ns * 16 * sizeof(double), hipMemcpyDeviceToDevice, stream_), "reset fs")) return PVIO_ERR_HIP;
+    if (v_.dm.M && check(hipMemcpyAsync(v_.rho, rho_init, (size_t)v_.dm.M * sizeof(double), hipMemcpyDeviceToDevice, stream_), "reset rho")) return PVIO_ERR_HIP;
+    if (check(launch_quality(v_, stream_, 0, acc), "k_quality")) return PVIO_ERR_HIP;
+    double h[2];
+    if (check(hipMemcpyAsync(h, acc, sizeof h, hipMemcpyDeviceToHost, stream_), "D2H")) return PVIO_ERR_HIP;
+    if (check(hipStreamSynchronize(stream_), "sync")) return PVIO_ERR_HIP;
+    *out = h[0] / std::max(h[1], 1.0);
+    return PVIO_OK;
+}
+
+} // namespace pvba
+
+namespace pvba {
+int BASolver::marginalize(const pvio_ba_problem *, const pvio_ba_state *, int, pvio_ba_prior *) {
+    return fail(PVIO_ERR_UNSUPPORTED, "marginalize_frame: not implemented yet");
+}
+} // namespace pvba

@@ -1,0 +1,74 @@
+// ba_solver.h -- host orchestration of the on-device bundle adjustment (one instance per pvio_hip_ctx).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/pvio_hip.h"
+#include "ba_types.h"
+
+namespace pvba {
+
+struct Comm; // RCCL communicator wrapper (ba_comm.cpp)
+int comm_unique_id(uint8_t id[128]);
+int comm_init(Comm **out, const uint8_t id[128], int rank, int world, int device);
+int comm_allreduce(Comm *c, double *buf, size_t n, int op_max, hipStream_t st);
+void comm_destroy(Comm *c);
+
+class DevicePool { // grow-only device allocations keyed by name
+  public:
+    ~DevicePool();
+    void *get(const char *name, size_t bytes, bool *grew = nullptr);
+    void release();
+    size_t total_bytes() const { return total_; }
+
+  private:
+    struct Slot {
+        std::string name;
+        void *ptr = nullptr;
+        size_t bytes = 0;
+    };
+    std::vector<Slot> slots_;
+    size_t total_ = 0;
+};
+
+class BASolver {
+  public:
+    BASolver(int device, int rank, int world, bool use_graph);
+    ~BASolver();
+    int upload(const pvio_ba_problem *pb, const pvio_ba_state *st);   // H2D of the flat problem + initial state
+    int solve(pvio_ba_summary *sum);                                   // runs from the uploaded initial state
+    int download(pvio_ba_state *st);                                   // D2H of the accepted iterate (+ quality pass)
+    int reprojection_error(double *out);
+    int marginalize(const pvio_ba_problem *pb, const pvio_ba_state *st, int victim, pvio_ba_prior *out);
+    void set_comm(Comm *c) { comm_ = c; }
+    const std::string &error() const { return err_; }
+    hipStream_t stream() const { return stream_; }
+
+  private:
+    int fail(int code, const std::string &msg);
+    int check(hipError_t e, const char *what);
+    int run_slots(int n_slots);
+    int enqueue_slot();
+    void invalidate_graph();
+
+    int device_, rank_, world_;
+    bool use_graph_;
+    hipStream_t stream_ = nullptr;
+    hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
+    DevicePool pool_;
+    View v_{};
+    Ctrl *h_ctrl_ = nullptr; // pinned
+    bool uploaded_ = false;
+    int trace_cap_ = 0;
+    bool want_trace_states_ = false;
+    hipGraph_t graph_ = nullptr;
+    hipGraphExec_t graph_exec_ = nullptr;
+    int graph_slots_ = 0;
+    Comm *comm_ = nullptr;
+    std::string err_;
+    std::vector<double> h_init_fs_, h_init_rho_;
+};
+
+} // namespace pvba

@@ -1,0 +1,134 @@
+// ba_types.h -- device-side views of one bundle-adjustment window and the on-device solver state.
+//
+// HBM layout (all FP64 unless noted; everything is SoA and stays resident for the whole solve):
+//   frames     fs[2][N][16]           two state buffers (accepted iterate / candidate), index ctrl->cur
+//              fs_user[N][16]         the reference's "user state" (live bias read, preintegration_error_cost.h:57-58)
+//   landmarks  rho[2][M]              inverse depths, accepted / candidate
+//              lin[2] x {Hll,bl,Dl,ghl,gnl}[M], Wa[M][6], Wt[F][6]   two linearization sets (accepted / speculative)
+//              cl[M]                  Jacobi column scale of the inverse-depth columns (computed once)
+//   factors    obs_frame[F] i32, obs_z[F][2], obs_lm[F] i32  -- landmark-major CSR (lm_ptr[M+1])
+//   partials   one row per workgroup of k_linearize: S tiles, 3 pose vectors, 8 scalars; summed by k_reduce
+//   dense      Smat[(dN)^2], vectors of length dN  (d = 6 vision-only, 15 with IMU / prior)
+#pragma once
+#include <stdint.h>
+
+namespace pvba {
+
+constexpr int kMaxFrames = 32;
+constexpr int kLinThreads = 256;   // workgroup size of k_linearize
+constexpr int kDenseThreads = 1024;
+constexpr int kNumLinScal = 8;     // cost, sum g^_l^2, |step_l|^2, |x_l|^2, max|b_l|, nonfinite, spare, spare
+constexpr int kNumBackScal = 8;    // sum gn_l^2, sum g^_l gn_l, Qvv, Qvy, Qyy, Gy, spare, spare
+constexpr int kNumPoseVec = 3;     // g_dir, rhs_schur, diagH_dir
+
+enum Mode : int32_t {
+    MODE_INIT = 0,       // evaluate + linearize the initial point (iteration 0)
+    MODE_CANDIDATE = 1,  // form the dogleg step, evaluate + speculatively linearize the candidate
+    MODE_RELIN = 2,      // re-linearize the accepted point (mu changed after a failed factorization / invalid step)
+    MODE_DONE = 3
+};
+enum LinResult : int32_t { LIN_NONE = 0, LIN_INIT = 1, LIN_CANDIDATE = 2, LIN_RELIN = 3, LIN_INVALID_STEP = 4 };
+
+struct TraceRec { // mirrors pvio_ba_iteration
+    int32_t iteration, step_is_valid, step_is_successful, reserved;
+    double cost, cost_change, gradient_max_norm, step_norm, relative_decrease, trust_region_radius, mu;
+};
+
+// Control block: the whole trust-region state machine lives on the device so that a solve needs no host
+// round trip per iteration (Ceres-1.14 TrustRegionMinimizer + DoglegStrategy semantics).
+struct Ctrl {
+    int32_t mode;            // what the next k_linearize does
+    int32_t lin_result;      // what the last k_linearize did
+    int32_t cur;             // state buffer of the accepted iterate
+    int32_t lin;             // linearization set of the accepted iterate
+    int32_t iter;            // trust-region iterations started so far
+    int32_t num_success;
+    int32_t invalid_steps;
+    int32_t termination;
+    int32_t done;
+    int32_t reuse;           // DoglegStrategy::reuse_
+    int32_t solve_ok;        // k_dense produced a Gauss-Newton step -> k_backsub must run
+    int32_t scaling_ready;   // Jacobi scaling has been computed (iteration 0)
+    int32_t trace_len, trace_cap;
+    int32_t retry_relin;     // RELIN triggered by a mu escalation inside one iteration (not a new iteration)
+    int32_t pad0;
+    double radius, mu;
+    double x_cost, x_norm2_pose, x_norm2_lm, grad_max;
+    double initial_cost;
+    // scalars of the current linearization (pose parts written by k_dense, landmark parts summed from k_backsub)
+    double pose_g2, pose_gn2, pose_gdot, pose_qvv, pose_qvy, pose_qyy, pose_gy;
+    double lm_g2;            // sum over landmarks of g^_l^2 of the accepted linearization
+    // current trust-region step (written by block 0 of k_linearize in MODE_CANDIDATE)
+    double ca, cb, dogleg_step_norm, model_cost_change;
+    double cand_step2_pose, cand_norm2_pose;
+    // bookkeeping for the record of the iteration in flight
+    double it_cost, it_cost_change, it_step_norm, it_rel;
+    int32_t it_valid, it_success;
+};
+
+struct Dims {
+    int32_t N, M, F;
+    int32_t d;          // tangent dims per frame in the dense system: 6 or 15
+    int32_t P;          // d * N
+    int32_t P6;         // 6 * N (pose part the landmark tiles live on)
+    int32_t n_tasks;    // 3x3 tile tasks: 4 * N (N + 1) / 2
+    int32_t n_chunks;   // landmark chunks
+    int32_t lm_slots;   // max landmarks per chunk (LDS budget)
+    int32_t n_plane, n_plane_chunks, plane_slots;
+    int32_t prior_n;
+    int32_t use_inertial;
+    int32_t max_iter;
+    int32_t G_lm, G_plane, G_pre, G_prior; // workgroups per role in k_linearize
+    int32_t G_back;
+    int32_t n_back_rows;  // rows of back partials k_linearize must sum (G_back, or 1 after an all-reduce)
+    int32_t world, rank;
+};
+
+struct View { // passed by value to every kernel
+    Dims dm;
+    Ctrl *ctrl;
+    // static problem
+    const uint8_t *frame_fixed;   // [N]
+    const uint8_t *pose_active;   // [N] pose block is free and referenced
+    const uint8_t *motion_active; // [N]
+    const double *cam_ext, *imu_ext, *sic, *intr;
+    const int32_t *lm_anchor, *lm_ptr, *obs_frame, *obs_lm;
+    const double *lm_zref, *obs_z;
+    const int32_t *chunk_lm;      // [n_chunks+1] landmark ranges
+    const int32_t *task_desc;     // [n_tasks] packed fi | fj<<8 | si<<16 | sj<<17
+    const uint8_t *pre_valid;     // [N]
+    const double *pre_delta, *pre_U, *pre_jac;
+    const int32_t *prior_frames;
+    const double *prior_S, *prior_s, *prior_lin, *prior_Lambda, *prior_eta;
+    const int32_t *plane_ptr, *plane_frame, *plane_chunk; // CSR + chunk ranges
+    const double *plane_z, *plane_normal, *plane_dist;
+    double plane_sic;
+    // state
+    double *fs;        // [2][N][16]
+    double *fs_user;   // [N][16]
+    double *bias0_lin; // [N][6] live biases the accepted linearization was evaluated with
+    double *rho;       // [2][M]
+    double *cl;        // [M]
+    double *Hll, *bl, *Dl, *ghl, *gnl, *Wa, *Wt; // [2] sets each
+    // partials and reduced quantities
+    double *part_S;    // [G][n_tasks*9]
+    double *part_vec;  // [G][3][P6]
+    double *part_scal; // [G][8]
+    double *red;       // [n_tasks*9 + 3*P6 + 8]  (the all-reduce payload)
+    double *back_part; // [G_back][8]
+    double *back_red;  // [8]
+    double *pre_H, *pre_g, *pre_cost;       // [N][900], [N][30], [N]
+    double *prior_H, *prior_g, *prior_cost; // [(15n)^2], [15n], [1]
+    // dense system
+    double *Smat;      // [P*P]
+    double *cp, *Dp, *gtot, *ghp, *vstep, *ystep; // [P] each
+    // trace
+    TraceRec *trace;
+    double *trace_states;
+    double *lm_quality;
+    uint8_t *lm_valid;
+};
+
+inline int lin_set_stride_M() { return 1; }
+
+} // namespace pvba

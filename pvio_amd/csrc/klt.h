@@ -1,0 +1,30 @@
+// klt.h -- device-resident image pyramids + pyramidal Lucas-Kanade tracker (host interface).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+
+namespace pvklt {
+
+struct Image; // device pyramid (klt.hip)
+
+class Klt {
+  public:
+    explicit Klt(int device);
+    ~Klt();
+    int create_image(const uint8_t *pixels, int w, int h, int stride, bool clahe, Image **out);
+    void release_image(Image *img);
+    int download_level(const Image *img, int level, uint8_t *pixels, int16_t *deriv, int32_t *w, int32_t *h);
+    int track(const Image *prev, const Image *next, int n, const float *prev_xy, float *next_xy, uint8_t *status);
+    const std::string &error() const { return err_; }
+
+  private:
+    int device_;
+    hipStream_t stream_ = nullptr;
+    std::string err_;
+    void *d_pts_ = nullptr;
+    size_t pts_cap_ = 0;
+};
+
+} // namespace pvklt

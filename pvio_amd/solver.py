@@ -1,0 +1,101 @@
+"""Thin ctypes driver over the C-ABI (include/pvio_hip.h) used by tests and bench.py.
+
+It adds nothing to the product path: every call goes straight into libpvio_hip.so.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .problem import BAState, BASummary
+
+
+class HipError(RuntimeError):
+    pass
+
+
+class HipContext:
+    def __init__(self, device=0, rank=0, world_size=1, use_graph=True, lib=None):
+        self.lib = lib or capi.load()
+        opts = capi.HipOpts()
+        opts.device, opts.rank, opts.world_size, opts.use_graph = device, rank, world_size, int(use_graph)
+        self.ctx = C.c_void_p()
+        rc = self.lib.pvio_hip_create(C.byref(opts), C.byref(self.ctx))
+        if rc != 0:
+            raise HipError("pvio_hip_create failed with status %d (no usable GPU? there is no CPU fallback)" % rc)
+        self._keep = None
+
+    def close(self):
+        if self.ctx:
+            self.lib.pvio_hip_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            msg = self.lib.pvio_hip_last_error(self.ctx)
+            raise HipError("%s failed: status %d (%s)" % (what, rc, msg.decode() if msg else ""))
+
+    # one-shot: upload + solve + download (what the BundleAdjustor adapter calls)
+    def solve(self, problem, state=None, summary=None, trace=True):
+        state = state or BAState(problem)
+        summary = summary or BASummary(problem, trace=trace)
+        pb, st = problem.as_c(), state.as_c()
+        self._check(self.lib.pvio_hip_ba_solve(self.ctx, C.byref(pb), C.byref(st), C.byref(summary.c)), "pvio_hip_ba_solve")
+        return state, summary
+
+    # device-resident variant (bench): upload once, solve many times from the same initial state
+    def upload(self, problem, state=None):
+        state = state or BAState(problem)
+        pb, st = problem.as_c(), state.as_c()
+        self._keep = (problem, state)
+        self._check(self.lib.pvio_hip_ba_upload(self.ctx, C.byref(pb), C.byref(st)), "pvio_hip_ba_upload")
+        return state
+
+    def solve_resident(self, summary):
+        self._check(self.lib.pvio_hip_ba_solve_resident(self.ctx, C.byref(summary.c)), "pvio_hip_ba_solve_resident")
+        return summary
+
+    def download(self, state):
+        st = state.as_c()
+        self._check(self.lib.pvio_hip_ba_download(self.ctx, C.byref(st)), "pvio_hip_ba_download")
+        return state
+
+    def reprojection_error(self, problem, state):
+        pb, st = problem.as_c(), state.as_c()
+        out = C.c_double(0)
+        self._check(self.lib.pvio_hip_ba_reprojection_error(self.ctx, C.byref(pb), C.byref(st), C.byref(out)), "reprojection_error")
+        return out.value
+
+    def marginalize(self, problem, state, victim, want_info=True):
+        pb, st = problem.as_c(), state.as_c()
+        n = problem.n_frames - 1
+        S, s = np.zeros((15 * n, 15 * n)), np.zeros(15 * n)
+        IM, iv = np.zeros((15 * n, 15 * n)), np.zeros(15 * n)
+        pr = capi.BAPriorC()
+        pr.S, pr.s = S.ctypes.data_as(capi.c_double_p), s.ctypes.data_as(capi.c_double_p)
+        if want_info:
+            pr.info_matrix, pr.info_vector = IM.ctypes.data_as(capi.c_double_p), iv.ctypes.data_as(capi.c_double_p)
+        self._check(self.lib.pvio_hip_ba_marginalize(self.ctx, C.byref(pb), C.byref(st), int(victim), C.byref(pr)), "pvio_hip_ba_marginalize")
+        return S, s, IM, iv
+
+
+def preintegrate(t, w, a, t_end, bg, ba, noise, lib=None):
+    """Product host-side pre-integration (pvio_preintegrate); same signature as oracle_py.preintegrate."""
+    lib = lib or capi.load()
+    f64 = lambda x: np.ascontiguousarray(x, dtype=np.float64)
+    t, w, a, bg, ba = f64(t), f64(w), f64(a), f64(bg), f64(ba)
+    delta, cov, U, jac = np.zeros(11), np.zeros(225), np.zeros(225), np.zeros(45)
+    nz = capi.ImuNoiseC()
+    for k in ("cov_w", "cov_a", "cov_bg", "cov_ba"):
+        getattr(nz, k)[:] = list(np.asarray(noise[k], float).ravel())
+    p = lambda x: x.ctypes.data_as(capi.c_double_p)
+    rc = lib.pvio_preintegrate(len(t), p(t), p(w), p(a), float(t_end), p(bg), p(ba), C.byref(nz), p(delta), p(cov), p(U), p(jac))
+    if rc != 0:
+        raise HipError("pvio_preintegrate failed: %d" % rc)
+    return delta, cov, U, jac

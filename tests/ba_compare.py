@@ -1,0 +1,62 @@
+"""Shared parity check: a C-ABI solve (real GPU library or the emulated test build) against the CPU oracle."""
+import numpy as np
+
+from pvio_amd import BAState, BASummary, synth
+
+# north_star: "pose/landmark states within 1e-6 per LM iteration"
+STATE_TOL = 1e-6
+
+CASES = {
+    "vision_small": dict(n_frames=4, n_landmarks=30),
+    "vision_partial": dict(n_frames=6, n_landmarks=40, visibility=3),
+    "vio_small": dict(n_frames=4, n_landmarks=30, use_inertial=True),
+    "vio_partial": dict(n_frames=6, n_landmarks=40, use_inertial=True, visibility=4),
+    "plane": dict(n_frames=5, n_landmarks=60, plane_fraction=0.5),
+    "vio_plane": dict(n_frames=5, n_landmarks=60, plane_fraction=0.4, use_inertial=True),
+    "vio_zero_bias_quirk": dict(n_frames=4, n_landmarks=30, use_inertial=True, bias_init="zero", perturb_scale=1.0),
+    # BASELINE.json configs[1]: 10 KF x 200 landmarks, reprojection factors only
+    "config1_10x200": dict(n_frames=10, n_landmarks=200),
+}
+BIG_CASES = {
+    # the configuration the metric is quoted on (10 KF x 1000 landmarks), vision-only and full VIO
+    "metric_10x1000_vision": dict(n_frames=10, n_landmarks=1000),
+    "metric_10x1000_vio": dict(n_frames=10, n_landmarks=1000, use_inertial=True),
+    "vio_plane_10x600": dict(n_frames=10, n_landmarks=600, use_inertial=True, plane_fraction=0.4, visibility=6),
+}
+
+
+def make(oracle, **kw):
+    if kw.get("use_inertial"):
+        kw = dict(kw, preintegrate=oracle.preintegrate)
+    return synth.make_window(**kw)
+
+
+def check_against_oracle(ctx, oracle, pb, state_tol=STATE_TOL, cost_rtol=1e-7):
+    st0, sm0 = BAState(pb), BASummary(pb)
+    oracle.solve(pb, st0, sm0)
+    st1, sm1 = ctx.solve(pb)
+    t0, t1 = sm0.trace(), sm1.trace()
+    assert sm1.termination == sm0.termination
+    assert sm1.num_iterations == sm0.num_iterations
+    assert sm1.num_successful_steps == sm0.num_successful_steps
+    assert len(t1) == len(t0)
+    for a, b in zip(t0, t1):
+        assert a["iteration"] == b["iteration"]
+        assert a["step_is_valid"] == b["step_is_valid"], (a, b)
+        assert a["step_is_successful"] == b["step_is_successful"], (a, b)
+        np.testing.assert_allclose(b["cost"], a["cost"], rtol=cost_rtol)
+        np.testing.assert_allclose(b["trust_region_radius"], a["trust_region_radius"], rtol=1e-6)
+        np.testing.assert_allclose(b["mu"], a["mu"], rtol=1e-12)
+        np.testing.assert_allclose(b["step_norm"], a["step_norm"], rtol=1e-5, atol=1e-9)
+        np.testing.assert_allclose(b["relative_decrease"], a["relative_decrease"], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(b["gradient_max_norm"], a["gradient_max_norm"], rtol=1e-5, atol=1e-7)
+    for k in range(len(t0)):  # states after EVERY iteration
+        np.testing.assert_allclose(sm1.trace_states[k], sm0.trace_states[k], rtol=0, atol=state_tol)
+    np.testing.assert_allclose(st1.frame_state, st0.frame_state, rtol=0, atol=state_tol)
+    np.testing.assert_allclose(st1.lm_inv_depth, st0.lm_inv_depth, rtol=0, atol=state_tol)
+    np.testing.assert_allclose(sm1.initial_cost, sm0.initial_cost, rtol=1e-8)
+    np.testing.assert_allclose(sm1.final_cost, sm0.final_cost, rtol=cost_rtol)
+    assert (st1.lm_valid == st0.lm_valid).all()
+    np.testing.assert_allclose(st1.lm_quality, st0.lm_quality, rtol=0, atol=1e-5)
+    worst = max(np.abs(sm1.trace_states[k] - sm0.trace_states[k]).max() for k in range(len(t0)))
+    return dict(worst_state_diff=worst, iterations=sm1.num_iterations, device_seconds=sm1.device_seconds)

@@ -1,0 +1,148 @@
+// hipemu_runtime.cpp -- fiber scheduler behind tests/hipemu/include/hip/hip_runtime.h (test infrastructure only).
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <ucontext.h>
+
+namespace hipemu {
+
+ThreadCtx *g_cur = nullptr;
+alignas(64) static char dyn_smem_pool[160 * 1024];
+char *g_dyn_smem = dyn_smem_pool;
+
+namespace {
+constexpr size_t kStack = 256 * 1024;
+struct Fiber {
+    ucontext_t ctx;
+    ThreadCtx tc;
+    bool done = false;
+    char *stack = nullptr;
+};
+struct WaveState {
+    unsigned char buf[64 * 32];
+    int arrived = 0, generation = 0, alive = 0, readers = 0;
+};
+std::vector<Fiber> fibers;
+std::vector<WaveState> waves;
+ucontext_t sched_ctx;
+int n_threads = 0, bar_arrived = 0, bar_generation = 0, n_done = 0;
+std::function<void()> *cur_body = nullptr;
+Fiber *cur_fiber = nullptr;
+
+void yield() {
+    Fiber *f = cur_fiber;
+    swapcontext(&f->ctx, &sched_ctx);
+}
+void trampoline() {
+    (*cur_body)();
+    cur_fiber->done = true;
+    ++n_done;
+    waves[cur_fiber->tc.wave].alive--;
+    swapcontext(&cur_fiber->ctx, &sched_ctx);
+}
+} // namespace
+
+void syncthreads() {
+    if (n_done != 0) {
+        std::fprintf(stderr, "hipemu: __syncthreads() reached after %d thread(s) of the block already returned\n", n_done);
+        std::abort();
+    }
+    int gen = bar_generation;
+    if (++bar_arrived == n_threads) {
+        bar_arrived = 0;
+        ++bar_generation;
+    } else {
+        while (bar_generation == gen) yield();
+    }
+}
+
+void wave_exchange(const void *in, void *out_all, size_t elem) {
+    WaveState &w = waves[g_cur->wave];
+    if (elem > 32) std::abort();
+    // phase 0: wait until the previous exchange has been fully read
+    while (w.readers != 0) yield();
+    std::memcpy(w.buf + (size_t)g_cur->lane * elem, in, elem);
+    int gen = w.generation;
+    int n_in_wave = w.alive;
+    if (++w.arrived == n_in_wave) {
+        w.arrived = 0;
+        w.readers = n_in_wave;
+        ++w.generation;
+    } else {
+        while (w.generation == gen) yield();
+    }
+    std::memcpy(out_all, w.buf, 64 * elem);
+    --w.readers;
+}
+
+double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+void launch(dim3 grid, dim3 block, size_t shmem, Stream *s, std::function<void()> body) {
+    auto run = [grid, block, shmem, body]() mutable {
+        const int nt = (int)(block.x * block.y * block.z);
+        if (shmem > sizeof(dyn_smem_pool)) {
+            std::fprintf(stderr, "hipemu: dynamic LDS request %zu exceeds 160 KiB\n", shmem);
+            std::abort();
+        }
+        if ((int)fibers.size() < nt) {
+            size_t old = fibers.size();
+            fibers.resize(nt);
+            for (size_t i = old; i < fibers.size(); ++i) fibers[i].stack = (char *)std::malloc(kStack);
+        }
+        waves.resize((nt + 63) / 64);
+        for (unsigned bz = 0; bz < grid.z; ++bz)
+            for (unsigned by = 0; by < grid.y; ++by)
+                for (unsigned bx = 0; bx < grid.x; ++bx) {
+                    n_threads = nt;
+                    bar_arrived = 0;
+                    n_done = 0;
+                    for (auto &w : waves) w.arrived = 0, w.alive = 0, w.readers = 0;
+                    cur_body = &body;
+                    for (int t = 0; t < nt; ++t) {
+                        Fiber &f = fibers[t];
+                        f.done = false;
+                        f.tc.tIdx = {(unsigned)(t % block.x), (unsigned)((t / block.x) % block.y), (unsigned)(t / (block.x * block.y))};
+                        f.tc.bIdx = {bx, by, bz};
+                        f.tc.bDim = block;
+                        f.tc.gDim = grid;
+                        f.tc.linear_tid = t;
+                        f.tc.lane = t & 63;
+                        f.tc.wave = t >> 6;
+                        waves[t >> 6].alive++;
+                        getcontext(&f.ctx);
+                        f.ctx.uc_stack.ss_sp = f.stack;
+                        f.ctx.uc_stack.ss_size = kStack;
+                        f.ctx.uc_link = &sched_ctx;
+                        makecontext(&f.ctx, trampoline, 0);
+                    }
+                    int remaining = nt;
+                    long spins = 0;
+                    while (remaining > 0) {
+                        int progressed = 0;
+                        for (int t = 0; t < nt; ++t) {
+                            Fiber &f = fibers[t];
+                            if (f.done) continue;
+                            cur_fiber = &f;
+                            g_cur = &f.tc;
+                            swapcontext(&sched_ctx, &f.ctx);
+                            if (f.done) {
+                                --remaining;
+                                ++progressed;
+                            }
+                        }
+                        if (!progressed && ++spins > 2000000) {
+                            std::fprintf(stderr, "hipemu: block (%u,%u,%u) deadlocked (divergent barrier / shuffle?)\n", bx, by, bz);
+                            std::abort();
+                        }
+                        if (progressed) spins = 0;
+                    }
+                }
+        g_cur = nullptr;
+    };
+    if (s && s->capturing)
+        s->graph->push_back(run);
+    else
+        run();
+}
+
+} // namespace hipemu

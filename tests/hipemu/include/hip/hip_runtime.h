@@ -1,0 +1,299 @@
+// hipemu -- a tiny single-threaded (fiber based) stand-in for <hip/hip_runtime.h>.
+//
+// TEST INFRASTRUCTURE ONLY.  It exists because the build container has no GPU and GPU-box minutes are
+// scarce: compiling pvio_amd/csrc/*.hip against this header with g++ (-Itests/hipemu/include placed first)
+// lets `pytest -m "not gpu"` exercise the kernels' indexing / reduction / control logic on the CPU and compare
+// it with the oracle.  It is NOT a backend, NOT a fallback and NOT shipped: libpvio_hip.so is always built
+// with hipcc for gfx950 and never sees this file; the emulated build produces a differently named test
+// library (tests/hipemu/libpvio_hipemu.so) that pvio_amd/capi.py will not load by default.
+//
+// Model: one OS thread; every GPU thread of a block is a ucontext fiber; blocks run one after another;
+// __syncthreads()/wave shuffles are cooperative yields.  Deterministic, no data races by construction
+// (so it cannot find memory-model bugs -- those are left to the GPU tests).
+#pragma once
+#define PV_HIPEMU 1
+#include <algorithm>
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __shared__ static
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __constant__ static
+#ifndef __restrict__
+#define __restrict__ __restrict
+#endif
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct hipemu_uint3 {
+    unsigned x, y, z;
+};
+
+typedef int hipError_t;
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNoDevice = 100, hipErrorNotReady = 600 };
+enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
+enum hipStreamCaptureMode { hipStreamCaptureModeGlobal, hipStreamCaptureModeThreadLocal, hipStreamCaptureModeRelaxed };
+
+namespace hipemu {
+struct Stream {
+    bool capturing = false;
+    std::vector<std::function<void()>> *graph = nullptr;
+};
+struct Graph {
+    std::vector<std::function<void()>> nodes;
+};
+struct Event {
+    double t = 0;
+};
+struct ThreadCtx {
+    hipemu_uint3 tIdx, bIdx;
+    dim3 bDim, gDim;
+    int linear_tid, lane, wave;
+};
+extern ThreadCtx *g_cur;
+extern char *g_dyn_smem;
+void launch(dim3 grid, dim3 block, size_t shmem, Stream *s, std::function<void()> body);
+void syncthreads();
+void wave_exchange(const void *in, void *out_all, size_t elem); // every lane contributes, receives all 64 values
+double now_ms();
+} // namespace hipemu
+
+typedef hipemu::Stream *hipStream_t;
+typedef hipemu::Event *hipEvent_t;
+typedef hipemu::Graph *hipGraph_t;
+typedef hipemu::Graph *hipGraphExec_t;
+
+#define threadIdx (hipemu::g_cur->tIdx)
+#define blockIdx (hipemu::g_cur->bIdx)
+#define blockDim (hipemu::g_cur->bDim)
+#define gridDim (hipemu::g_cur->gDim)
+using std::isfinite;
+using std::max;
+using std::min;
+#define warpSize 64
+
+#define HIP_DYNAMIC_SHARED(type, var) type *var = reinterpret_cast<type *>(hipemu::g_dyn_smem);
+#define HIP_KERNEL_NAME(...) __VA_ARGS__
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+    hipemu::launch((grid), (block), (shmem), (stream), [=]() { kernel(__VA_ARGS__); })
+
+// ---- device intrinsics ---------------------------------------------------------------------------------
+inline void __syncthreads() { hipemu::syncthreads(); }
+inline void __threadfence() {}
+inline void __threadfence_block() {}
+template <typename T>
+inline T __shfl(T v, int src, int width = 64) {
+    T all[64];
+    hipemu::wave_exchange(&v, all, sizeof(T));
+    int lane = hipemu::g_cur->lane;
+    int base = lane & ~(width - 1);
+    return all[base + (src & (width - 1))];
+}
+template <typename T>
+inline T __shfl_xor(T v, int mask, int width = 64) {
+    T all[64];
+    hipemu::wave_exchange(&v, all, sizeof(T));
+    int lane = hipemu::g_cur->lane;
+    (void)width;
+    return all[lane ^ mask];
+}
+template <typename T>
+inline T __shfl_down(T v, unsigned delta, int width = 64) {
+    T all[64];
+    hipemu::wave_exchange(&v, all, sizeof(T));
+    int lane = hipemu::g_cur->lane;
+    int idx = lane + (int)delta;
+    if ((idx & ~(width - 1)) != (lane & ~(width - 1)) || idx >= 64) idx = lane;
+    return all[idx];
+}
+template <typename T>
+inline T __shfl_up(T v, unsigned delta, int width = 64) {
+    T all[64];
+    hipemu::wave_exchange(&v, all, sizeof(T));
+    int lane = hipemu::g_cur->lane;
+    int idx = lane - (int)delta;
+    if (idx < (lane & ~(width - 1))) idx = lane;
+    return all[idx];
+}
+inline unsigned long long __ballot(int pred) {
+    int all[64];
+    hipemu::wave_exchange(&pred, all, sizeof(int));
+    unsigned long long m = 0;
+    for (int i = 0; i < 64; ++i)
+        if (all[i]) m |= 1ull << i;
+    return m;
+}
+template <typename T>
+inline T atomicAdd(T *p, T v) {
+    T old = *p;
+    *p = old + v;
+    return old;
+}
+inline unsigned atomicInc(unsigned *p, unsigned lim) {
+    unsigned old = *p;
+    *p = old >= lim ? 0 : old + 1;
+    return old;
+}
+template <typename T>
+inline T atomicMax(T *p, T v) {
+    T old = *p;
+    if (v > old) *p = v;
+    return old;
+}
+template <typename T>
+inline T atomicExch(T *p, T v) {
+    T old = *p;
+    *p = v;
+    return old;
+}
+// v_mfma_f64_16x16x4_f64: D = A(16x4) B(4x16) + C.  Lane l supplies A[l&15][l>>4] and B[l>>4][l&15];
+// receives D[(l>>4)+4*r][l&15] in element r (cdna_hip_programming.md section 3, f64 layout).
+typedef double hipemu_double4 __attribute__((vector_size(32)));
+inline hipemu_double4 __builtin_amdgcn_mfma_f64_16x16x4f64(double a, double b, hipemu_double4 c, int, int, int) {
+    double A[64], B[64];
+    hipemu::wave_exchange(&a, A, sizeof(double));
+    hipemu::wave_exchange(&b, B, sizeof(double));
+    int lane = hipemu::g_cur->lane;
+    int col = lane & 15;
+    hipemu_double4 d = c;
+    for (int r = 0; r < 4; ++r) {
+        int row = (lane >> 4) + 4 * r;
+        double acc = c[r];
+        for (int k = 0; k < 4; ++k) acc = fma(A[16 * k + row], B[16 * k + col], acc);
+        d[r] = acc;
+    }
+    return d;
+}
+
+// ---- host API -------------------------------------------------------------------------------------------
+inline const char *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "hipemu error"; }
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline hipError_t hipGetDeviceCount(int *n) {
+    *n = 1;
+    return hipSuccess;
+}
+inline hipError_t hipSetDevice(int) { return hipSuccess; }
+struct hipDeviceProp_t {
+    char name[256];
+    int multiProcessorCount;
+    size_t totalGlobalMem;
+    char gcnArchName[256];
+};
+inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) {
+    std::snprintf(p->name, sizeof p->name, "hipemu (CPU fibers)");
+    std::snprintf(p->gcnArchName, sizeof p->gcnArchName, "hipemu");
+    p->multiProcessorCount = 8; // keep emulated grids small
+    p->totalGlobalMem = 1ull << 34;
+    return hipSuccess;
+}
+template <typename T>
+inline hipError_t hipMalloc(T **p, size_t n) {
+    *p = (T *)std::malloc(n ? n : 1);
+    if (*p) std::memset((void *)*p, 0xA5, n); // poison: catches reads of never-written device memory
+    return *p ? hipSuccess : hipErrorOutOfMemory;
+}
+template <typename T>
+inline hipError_t hipHostMalloc(T **p, size_t n, unsigned = 0) {
+    *p = (T *)std::malloc(n ? n : 1);
+    return *p ? hipSuccess : hipErrorOutOfMemory;
+}
+inline hipError_t hipFree(void *p) {
+    std::free(p);
+    return hipSuccess;
+}
+inline hipError_t hipHostFree(void *p) {
+    std::free(p);
+    return hipSuccess;
+}
+inline void hipemu_enqueue(hipStream_t s, std::function<void()> f) {
+    if (s && s->capturing)
+        s->graph->push_back(std::move(f));
+    else
+        f();
+}
+inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) {
+    std::memcpy(d, s, n);
+    return hipSuccess;
+}
+inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t st = nullptr) {
+    hipemu_enqueue(st, [=]() { std::memcpy(d, s, n); });
+    return hipSuccess;
+}
+inline hipError_t hipMemset(void *d, int v, size_t n) {
+    std::memset(d, v, n);
+    return hipSuccess;
+}
+inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t st = nullptr) {
+    hipemu_enqueue(st, [=]() { std::memset(d, v, n); });
+    return hipSuccess;
+}
+inline hipError_t hipStreamCreate(hipStream_t *s) {
+    *s = new hipemu::Stream();
+    return hipSuccess;
+}
+inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { return hipStreamCreate(s); }
+#define hipStreamNonBlocking 1
+inline hipError_t hipStreamDestroy(hipStream_t s) {
+    delete s;
+    return hipSuccess;
+}
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+inline hipError_t hipEventCreate(hipEvent_t *e) {
+    *e = new hipemu::Event();
+    return hipSuccess;
+}
+inline hipError_t hipEventDestroy(hipEvent_t e) {
+    delete e;
+    return hipSuccess;
+}
+inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = nullptr) {
+    e->t = hipemu::now_ms();
+    return hipSuccess;
+}
+inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) {
+    *ms = (float)(b->t - a->t);
+    return hipSuccess;
+}
+inline hipError_t hipStreamBeginCapture(hipStream_t s, hipStreamCaptureMode) {
+    s->capturing = true;
+    s->graph = new std::vector<std::function<void()>>();
+    return hipSuccess;
+}
+inline hipError_t hipStreamEndCapture(hipStream_t s, hipGraph_t *g) {
+    *g = new hipemu::Graph();
+    (*g)->nodes = std::move(*s->graph);
+    delete s->graph;
+    s->graph = nullptr;
+    s->capturing = false;
+    return hipSuccess;
+}
+inline hipError_t hipGraphInstantiate(hipGraphExec_t *e, hipGraph_t g, void *, void *, size_t) {
+    *e = new hipemu::Graph(*g);
+    return hipSuccess;
+}
+inline hipError_t hipGraphLaunch(hipGraphExec_t e, hipStream_t) {
+    for (auto &f : e->nodes) f();
+    return hipSuccess;
+}
+inline hipError_t hipGraphDestroy(hipGraph_t g) {
+    delete g;
+    return hipSuccess;
+}
+inline hipError_t hipGraphExecDestroy(hipGraphExec_t g) {
+    delete g;
+    return hipSuccess;
+}

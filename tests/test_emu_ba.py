@@ -1,0 +1,59 @@
+"""Kernel-logic check WITHOUT a GPU: the product sources (pvio_amd/csrc) compiled against the fiber emulator
+(tests/hipemu, test infrastructure only) must reproduce the oracle iteration by iteration.  The real parity
+tests are tests/test_gpu_ba.py (-m gpu, same checks through libpvio_hip.so)."""
+import os
+import subprocess
+
+import pytest
+
+import ba_compare
+from pvio_amd import capi
+from pvio_amd.solver import HipContext
+
+EMU_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hipemu")
+
+
+@pytest.fixture(scope="module")
+def emu_ctx():
+    subprocess.check_call(["make", "-s", "-C", EMU_DIR, "libpvio_hipemu.so"])
+    lib = capi.load(os.path.join(EMU_DIR, "libpvio_hipemu.so"))
+    ctx = HipContext(lib=lib, use_graph=True)
+    yield ctx
+    ctx.close()
+
+
+@pytest.mark.parametrize("name", sorted(ba_compare.CASES))
+def test_emulated_kernels_match_oracle(emu_ctx, oracle, name):
+    pb = ba_compare.make(oracle, **ba_compare.CASES[name])
+    ba_compare.check_against_oracle(emu_ctx, oracle, pb)
+
+
+def test_emulated_eager_launches_match_graph_replay(emu_ctx, oracle):
+    pb = ba_compare.make(oracle, **ba_compare.CASES["vio_partial"])
+    eager = HipContext(lib=emu_ctx.lib, use_graph=False)
+    st_a, sm_a = emu_ctx.solve(pb)
+    st_b, sm_b = eager.solve(pb)
+    assert (st_a.frame_state == st_b.frame_state).all() and (st_a.lm_inv_depth == st_b.lm_inv_depth).all()
+    eager.close()
+
+
+def test_emulated_resident_solve_is_repeatable(emu_ctx, oracle):
+    from pvio_amd import BAState, BASummary
+    pb = ba_compare.make(oracle, **ba_compare.CASES["vio_small"])
+    emu_ctx.upload(pb)
+    outs = []
+    for _ in range(2):
+        sm = BASummary(pb)
+        emu_ctx.solve_resident(sm)
+        st = BAState(pb)
+        emu_ctx.download(st)
+        outs.append((st.frame_state.copy(), st.lm_inv_depth.copy(), sm.num_iterations))
+    assert (outs[0][0] == outs[1][0]).all() and (outs[0][1] == outs[1][1]).all() and outs[0][2] == outs[1][2]
+
+
+def test_rejects_bad_input(emu_ctx, oracle):
+    from pvio_amd.solver import HipError
+    pb = ba_compare.make(oracle, **ba_compare.CASES["vision_small"])
+    pb.obs_frame[1] = pb.obs_frame[0]  # same target frame twice for one landmark
+    with pytest.raises(HipError):
+        emu_ctx.solve(pb)
