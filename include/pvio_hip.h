@@ -186,6 +186,14 @@ int32_t pvio_hip_ba_upload(pvio_hip_ctx *ctx, const pvio_ba_problem *problem, co
 int32_t pvio_hip_ba_solve_resident(pvio_hip_ctx *ctx, pvio_ba_summary *summary);
 int32_t pvio_hip_ba_download(pvio_hip_ctx *ctx, pvio_ba_state *state);
 
+/* Per-kernel timing of one resident solve (bench.py roofline leg): the same kernels, launched eagerly one slot at a
+ * time with hipEvents on the solver's own stream around every launch.  Index: 0 linearize, 1 reduce, 2 dense, 3 backsub. */
+typedef struct pvio_ba_kernel_times {
+    double total_ms[4];
+    int32_t launches[4];
+} pvio_ba_kernel_times;
+int32_t pvio_hip_ba_profile_resident(pvio_hip_ctx *ctx, pvio_ba_summary *summary, pvio_ba_kernel_times *times);
+
 /* multi-GPU (landmark shards, one process per GPU): RCCL communicator bootstrap.
  * rank 0 creates the 128-byte unique id, the launcher broadcasts it (torch.distributed), every rank inits. */
 int32_t pvio_hip_comm_unique_id(uint8_t id[128]);

@@ -67,6 +67,10 @@ class BAPriorC(C.Structure):
                 ("info_matrix", c_double_p), ("info_vector", c_double_p)]
 
 
+class BAKernelTimesC(C.Structure):
+    _fields_ = [("total_ms", C.c_double * 4), ("launches", C.c_int32 * 4)]
+
+
 class ImuNoiseC(C.Structure):
     _fields_ = [("cov_w", C.c_double * 9), ("cov_a", C.c_double * 9), ("cov_bg", C.c_double * 9),
                 ("cov_ba", C.c_double * 9)]
@@ -76,7 +80,7 @@ class ImuNoiseC(C.Structure):
 EXPORTS = [
     "pvio_hip_create", "pvio_hip_destroy", "pvio_hip_last_error", "pvio_hip_version",
     "pvio_hip_ba_solve", "pvio_hip_ba_marginalize", "pvio_hip_ba_reprojection_error",
-    "pvio_hip_ba_upload", "pvio_hip_ba_solve_resident", "pvio_hip_ba_download",
+    "pvio_hip_ba_upload", "pvio_hip_ba_solve_resident", "pvio_hip_ba_download", "pvio_hip_ba_profile_resident",
     "pvio_hip_comm_unique_id", "pvio_hip_comm_init", "pvio_preintegrate",
     "pvio_hip_image_create", "pvio_hip_image_release", "pvio_hip_image_download_level", "pvio_hip_klt_track",
 ]
@@ -114,6 +118,8 @@ def load(path=None):
     lib.pvio_hip_ba_upload.restype = C.c_int32
     lib.pvio_hip_ba_solve_resident.argtypes = [vp, C.POINTER(BASummaryC)]
     lib.pvio_hip_ba_solve_resident.restype = C.c_int32
+    lib.pvio_hip_ba_profile_resident.argtypes = [vp, C.POINTER(BASummaryC), C.POINTER(BAKernelTimesC)]
+    lib.pvio_hip_ba_profile_resident.restype = C.c_int32
     lib.pvio_hip_ba_download.argtypes = [vp, C.POINTER(BAStateC)]
     lib.pvio_hip_ba_download.restype = C.c_int32
     lib.pvio_hip_comm_unique_id.argtypes = [c_uint8_p]

@@ -295,12 +295,15 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st) {
     return check(hipStreamSynchronize(stream_), "upload sync");
 }
 
-int BASolver::enqueue_slot() {
+int BASolver::enqueue_slot(hipEvent_t *ev) {
     hipError_t e;
     View vl = v_;
     if (world_ > 1) vl.back_part = v_.back_red; // k_linearize reads the all-reduced row
+    if (ev) (void)hipEventRecord(ev[0], stream_);
     if ((e = launch_linearize(vl, stream_)) != hipSuccess) return check(e, "k_linearize");
+    if (ev) (void)hipEventRecord(ev[1], stream_);
     if ((e = launch_reduce(v_, stream_)) != hipSuccess) return check(e, "k_reduce");
+    if (ev) (void)hipEventRecord(ev[2], stream_);
     if (world_ > 1) {
         const size_t n = (size_t)v_.dm.n_tasks * 9 + (size_t)kNumPoseVec * v_.dm.P6 + kNumLinScal;
         // scalar 4 (max |b_l|) must not be summed: reduce it separately with max
@@ -308,8 +311,11 @@ int BASolver::enqueue_slot() {
         if (comm_allreduce(comm_, v_.red, n - kNumLinScal + 4, 0, stream_)) return fail(PVIO_ERR_COMM, "all-reduce failed");
         if (comm_allreduce(comm_, v_.red + n - kNumLinScal + 5, 3, 0, stream_)) return fail(PVIO_ERR_COMM, "all-reduce failed");
     }
+    if (ev) (void)hipEventRecord(ev[3], stream_);
     if ((e = launch_dense(v_, stream_)) != hipSuccess) return check(e, "k_dense");
+    if (ev) (void)hipEventRecord(ev[4], stream_);
     if ((e = launch_backsub(v_, stream_)) != hipSuccess) return check(e, "k_backsub");
+    if (ev) (void)hipEventRecord(ev[5], stream_);
     if (world_ > 1) {
         if ((e = launch_back_reduce(v_, stream_)) != hipSuccess) return check(e, "k_back_reduce");
         if (comm_allreduce(comm_, v_.back_red, kNumBackScal, 0, stream_)) return fail(PVIO_ERR_COMM, "all-reduce failed");
@@ -339,7 +345,7 @@ int BASolver::run_slots(int n_slots) {
     return PVIO_OK;
 }
 
-int BASolver::solve(pvio_ba_summary *sum) {
+int BASolver::solve(pvio_ba_summary *sum, pvio_ba_kernel_times *prof) {
     if (!uploaded_) return fail(PVIO_ERR_INVALID_ARGUMENT, "no problem uploaded");
     auto t0 = std::chrono::steady_clock::now();
     if (check(hipSetDevice(device_), "hipSetDevice")) return PVIO_ERR_HIP;
@@ -376,14 +382,37 @@ int BASolver::solve(pvio_ba_summary *sum) {
     // mu escalations); relaunch while the device has not reported done
     const int n_slots = dm.max_iter + 2;
     int rounds = 0;
+    hipEvent_t pev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (prof) {
+        std::memset(prof, 0, sizeof *prof);
+        for (auto &e : pev) (void)hipEventCreate(&e);
+    }
     for (;;) {
-        int rc = run_slots(n_slots);
+        int rc;
+        if (prof) { // one slot at a time, events around every launch; counts only slots that did work
+            rc = enqueue_slot(pev);
+            if (rc == PVIO_OK && check(hipStreamSynchronize(stream_), "profile sync")) rc = PVIO_ERR_HIP;
+            if (rc == PVIO_OK) {
+                const int ia[4] = {0, 1, 3, 4}, ib[4] = {1, 2, 4, 5};
+                for (int k = 0; k < 4; ++k) {
+                    float ms1 = 0;
+                    (void)hipEventElapsedTime(&ms1, pev[ia[k]], pev[ib[k]]);
+                    prof->total_ms[k] += ms1;
+                    prof->launches[k] += 1;
+                }
+            }
+            --rounds; // the round cap below is for graph replays
+        } else {
+            rc = run_slots(n_slots);
+        }
         if (rc != PVIO_OK) return rc;
         if (check(hipMemcpyAsync(h_ctrl_, v_.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, stream_), "ctrl D2H")) return PVIO_ERR_HIP;
         if (check(hipEventRecord(ev1_, stream_), "event")) return PVIO_ERR_HIP;
         if (check(hipStreamSynchronize(stream_), "solve sync")) return PVIO_ERR_HIP;
         if (h_ctrl_->done || ++rounds > 16) break;
     }
+    if (prof)
+        for (auto &e : pev) (void)hipEventDestroy(e);
     if (!h_ctrl_->done) return fail(PVIO_ERR_HIP, "device state machine did not terminate");
     float ms = 0;
     (void)hipEventElapsedTime(&ms, ev0_, ev1_);

@@ -38,7 +38,7 @@ class BASolver {
     BASolver(int device, int rank, int world, bool use_graph);
     ~BASolver();
     int upload(const pvio_ba_problem *pb, const pvio_ba_state *st);   // H2D of the flat problem + initial state
-    int solve(pvio_ba_summary *sum);                                   // runs from the uploaded initial state
+    int solve(pvio_ba_summary *sum, pvio_ba_kernel_times *prof = nullptr); // runs from the uploaded initial state
     int download(pvio_ba_state *st);                                   // D2H of the accepted iterate (+ quality pass)
     int reprojection_error(double *out);
     int marginalize(const pvio_ba_problem *pb, const pvio_ba_state *st, int victim, pvio_ba_prior *out);
@@ -50,7 +50,7 @@ class BASolver {
     int fail(int code, const std::string &msg);
     int check(hipError_t e, const char *what);
     int run_slots(int n_slots);
-    int enqueue_slot();
+    int enqueue_slot(hipEvent_t *ev = nullptr);
     void invalidate_graph();
 
     int device_, rank_, world_;

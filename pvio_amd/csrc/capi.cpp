@@ -67,6 +67,10 @@ int32_t pvio_hip_ba_solve_resident(pvio_hip_ctx *ctx, pvio_ba_summary *summary) 
     if (!ctx) return PVIO_ERR_INVALID_ARGUMENT;
     return ctx->ba->solve(summary);
 }
+int32_t pvio_hip_ba_profile_resident(pvio_hip_ctx *ctx, pvio_ba_summary *summary, pvio_ba_kernel_times *times) {
+    if (!ctx || !times) return PVIO_ERR_INVALID_ARGUMENT;
+    return ctx->ba->solve(summary, times);
+}
 int32_t pvio_hip_ba_download(pvio_hip_ctx *ctx, pvio_ba_state *state) {
     if (!ctx) return PVIO_ERR_INVALID_ARGUMENT;
     return ctx->ba->download(state);

@@ -61,6 +61,13 @@ class HipContext:
         self._check(self.lib.pvio_hip_ba_solve_resident(self.ctx, C.byref(summary.c)), "pvio_hip_ba_solve_resident")
         return summary
 
+    def profile_resident(self, summary):
+        """One resident solve with hipEvents around every kernel launch -> {kernel: (total_ms, launches)}."""
+        kt = capi.BAKernelTimesC()
+        self._check(self.lib.pvio_hip_ba_profile_resident(self.ctx, C.byref(summary.c), C.byref(kt)), "pvio_hip_ba_profile_resident")
+        names = ["k_linearize", "k_reduce", "k_dense", "k_backsub"]
+        return {n: (kt.total_ms[i], kt.launches[i]) for i, n in enumerate(names)}
+
     def download(self, state):
         st = state.as_c()
         self._check(self.lib.pvio_hip_ba_download(self.ctx, C.byref(st)), "pvio_hip_ba_download")
