@@ -191,6 +191,7 @@ int32_t pvio_hip_ba_download(pvio_hip_ctx *ctx, pvio_ba_state *state);
 typedef struct pvio_ba_kernel_times {
     double total_ms[4];
     int32_t launches[4];
+    int64_t phase_ticks[4][32]; /* shader-clock timestamps of the LAST working slot, block 0 (kernel phase breakdown) */
 } pvio_ba_kernel_times;
 int32_t pvio_hip_ba_profile_resident(pvio_hip_ctx *ctx, pvio_ba_summary *summary, pvio_ba_kernel_times *times);
 

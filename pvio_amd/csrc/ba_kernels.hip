@@ -33,6 +33,12 @@ namespace pvba {
 
 using namespace pv;
 
+// phase timestamps for the profiling entry point (View::dbg != nullptr): block 0 / thread 0 only
+#define PV_STAMP(kern, idx)                                                                      \
+    do {                                                                                         \
+        if (v.dbg && blockIdx.x == 0 && threadIdx.x == 0) v.dbg[(kern)*32 + (idx)] = clock64(); \
+    } while (0)
+
 // ------------------------------------------------------------------------------------------------------
 // small reductions
 // ------------------------------------------------------------------------------------------------------
@@ -40,6 +46,22 @@ __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
+}
+// 1/sqrt(x) for the pivot chain of the block factorization: v_rsq_f64 (~2^-23 relative) + two Newton steps
+// (-> ~1 ulp).  ocml's correctly rounded sqrt + divide is ~40 dependent FP64 instructions per pivot.
+__device__ __forceinline__ double fast_rsqrt(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    y = y * fma(-0.5 * x, y * y, 1.5);
+    y = y * fma(-0.5 * x, y * y, 1.5);
+    return y;
+}
+// broadcast lane `src` (wave-uniform) of a double: two v_readlane_b32
+__device__ __forceinline__ double readlane_f64(double x, int src) {
+    union { double d; int i[2]; } u;
+    u.d = x;
+    u.i[0] = __builtin_amdgcn_readlane(u.i[0], src);
+    u.i[1] = __builtin_amdgcn_readlane(u.i[1], src);
+    return u.d;
 }
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
@@ -181,7 +203,8 @@ __device__ __forceinline__ void unpack_task(int t, int &fi, int &fj, int &si, in
     fi = t & 255, fj = (t >> 8) & 255, si = (t >> 16) & 1, sj = (t >> 17) & 1;
 }
 
-// per-landmark LDS record (doubles): U[6N] JT[12N] JR[12N] GT[6N] FD[4N] HAA[36] GA[6] SC[4]
+// per-landmark LDS record (doubles): U[6N] JT[12N] Z[16N] GT[6N] HAA[36] GA[6] SC[4]
+// Z[f] = [Jd0 Jd1 r0 r1 | J_ref row 0 (6) | J_ref row 1 (6)] of the factor targeting frame f (zero if none)
 __device__ __forceinline__ int lm_rec_doubles(int N) { return 40 * N + 46; }
 
 template <int T>
@@ -218,6 +241,7 @@ __device__ void role_landmarks(const View &v, double *lds, const Pro *pro, int w
     for (int ck = wg; ck < v.dm.n_chunks; ck += n_wg) {
         const int l0 = v.chunk_lm[ck], l1 = v.chunk_lm[ck + 1], ns = l1 - l0;
         const int o0 = v.lm_ptr[l0], nf = v.lm_ptr[l1] - o0;
+        PV_STAMP(0, 2);
         // ---- phase 0: clear the chunk records, evaluation-point inverse depths ----
         for (int e = tid; e < ns * rec; e += kLinThreads) chunk[e] = 0.0;
         if (tid < ns) {
@@ -236,6 +260,7 @@ __device__ void role_landmarks(const View &v, double *lds, const Pro *pro, int w
             anch[tid] = v.lm_anchor[l];
         }
         __syncthreads();
+        PV_STAMP(0, 3);
         // ---- phase 1: one thread per reprojection factor ----
         if (tid < nf) {
             const int o = o0 + tid, l = v.obs_lm[o], s = l - l0, t = v.obs_frame[o], a = anch[s];
@@ -256,7 +281,7 @@ __device__ void role_landmarks(const View &v, double *lds, const Pro *pro, int w
             }
             s_bad += bad;
             double *R = chunk + (size_t)s * rec;
-            double *U = R, *JT = R + 6 * N + 12 * t, *JR = R + 18 * N + 12 * t, *GT = R + 30 * N + 6 * t, *FD = R + 36 * N + 4 * t;
+            double *U = R, *JT = R + 6 * N + 12 * t, *Z = R + 18 * N + 16 * t, *GT = R + 34 * N + 6 * t;
             double wt[6];
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
@@ -268,39 +293,46 @@ __device__ void role_landmarks(const View &v, double *lds, const Pro *pro, int w
             // duplicates of one (landmark, frame) pair are rare; the records hold the LAST factor's J (used only for
             // the direct blocks), so refuse duplicates at upload time instead of silently mis-summing.
 #pragma unroll
-            for (int k = 0; k < 12; ++k) JT[k] = Jt[k], JR[k] = Jr[k];
-            FD[0] = Jd[0], FD[1] = Jd[1], FD[2] = r[0], FD[3] = r[1];
+            for (int k = 0; k < 12; ++k) JT[k] = Jt[k], Z[4 + k] = Jr[k];
+            Z[0] = Jd[0], Z[1] = Jd[1], Z[2] = r[0], Z[3] = r[1];
         }
         __syncthreads();
+        PV_STAMP(0, 4);
         // ---- phase 1b: per-landmark sums over its factors (50 outputs per landmark) ----
+        // every output is sum_f Z[f][p] Z[f][q] + Z[f][p2] Z[f][q2] for an index quadruple that depends only on k:
+        // branch-free, two independent accumulators so that the LDS reads of consecutive frames overlap
         for (int e = tid; e < ns * 50; e += kLinThreads) {
             const int s = e / 50, k = e - 50 * s;
-            const double *R = chunk + (size_t)s * rec, *JR = R + 18 * N, *FD = R + 36 * N;
-            double sum = 0;
-            if (k == 0) {
-                for (int f = 0; f < N; ++f) sum += FD[4 * f] * FD[4 * f] + FD[4 * f + 1] * FD[4 * f + 1];
-            } else if (k == 1) {
-                for (int f = 0; f < N; ++f) sum += FD[4 * f] * FD[4 * f + 2] + FD[4 * f + 1] * FD[4 * f + 3];
-            } else if (k < 8) {
-                const int c = k - 2;
-                for (int f = 0; f < N; ++f) sum += FD[4 * f] * JR[12 * f + c] + FD[4 * f + 1] * JR[12 * f + 6 + c];
-            } else if (k < 14) {
-                const int c = k - 8;
-                for (int f = 0; f < N; ++f) sum += JR[12 * f + c] * FD[4 * f + 2] + JR[12 * f + 6 + c] * FD[4 * f + 3];
-            } else {
+            int p, q, p2, q2;
+            if (k == 0) p = 0, q = 0, p2 = 1, q2 = 1;                       // Hll  = Jd . Jd
+            else if (k == 1) p = 0, q = 2, p2 = 1, q2 = 3;                  // bl   = Jd . r
+            else if (k < 8) p = 0, q = 2 + k, p2 = 1, q2 = 8 + k;           // Wa_c = Jd . Jr[:, c]      (c = k - 2)
+            else if (k < 14) p = k - 4, q = 2, p2 = k + 2, q2 = 3;          // GA_c = Jr[:, c] . r       (c = k - 8)
+            else {                                                           // HAA_ij = Jr[:, i] . Jr[:, j]
                 const int i = (k - 14) / 6, j = (k - 14) - 6 * i;
-                for (int f = 0; f < N; ++f) sum += JR[12 * f + i] * JR[12 * f + j] + JR[12 * f + 6 + i] * JR[12 * f + 6 + j];
+                p = 4 + i, q = 4 + j, p2 = 10 + i, q2 = 10 + j;
             }
+            const double *Z = chunk + (size_t)s * rec + 18 * N;
+            double s0 = 0, s1 = 0;
+            int f = 0;
+            for (; f + 1 < N; f += 2) {
+                const double *Za = Z + 16 * f, *Zb = Za + 16;
+                s0 += Za[p] * Za[q] + Za[p2] * Za[q2];
+                s1 += Zb[p] * Zb[q] + Zb[p2] * Zb[q2];
+            }
+            if (f < N) s0 += Z[16 * f + p] * Z[16 * f + q] + Z[16 * f + p2] * Z[16 * f + q2];
+            const double sum = s0 + s1;
             double *W = chunk + (size_t)s * rec + 40 * N; // HAA[36] GA[6] SC[4]
             if (k == 0) W[42 + 3] = sum;        // Hll
             else if (k == 1) W[42 + 1] = sum;   // bl
-            else if (k < 8) {                   // Wa -> anchor columns of U (added below), keep a copy in GA slot? no: stage in SC area
+            else if (k < 8) {                   // Wa: anchor columns of the landmark's row + global copy for k_backsub
                 o_Wa[(size_t)(l0 + s) * 6 + (k - 2)] = sum;
                 chunk[(size_t)s * rec + 6 * anch[s] + (k - 2)] += sum; // anchor is never a target of its own landmark
             } else if (k < 14) W[36 + (k - 8)] = sum;
             else W[k - 14] = sum;
         }
         __syncthreads();
+        PV_STAMP(0, 5);
         // ---- phase 1c: per-landmark scalars: Jacobi scale, dogleg diagonal, Schur weight ----
         if (tid < ns) {
             const int l = l0 + tid;
@@ -326,51 +358,50 @@ __device__ void role_landmarks(const View &v, double *lds, const Pro *pro, int w
             }
         }
         __syncthreads();
+        PV_STAMP(0, 6);
         // ---- phase 2: output-stationary tile accumulation over the chunk's landmarks ----
+        // direct-term operand offsets per task (relative to the landmark record); which pair applies depends on the
+        // landmark's anchor only:  fi == fj      : Jt(fi)^T Jt(fi)  [+ HAA when the anchor is fi]
+        //                          anchor == fj  : Jt(fi)^T Jr(fi)      anchor == fi : Jr(fj)^T Jt(fj)
         for (int s = 0; s < ns; ++s) {
             const double *R = chunk + (size_t)s * rec;
-            const double *U = R, *JT = R + 6 * N, *JR = R + 18 * N, *HAA = R + 40 * N, *SC = HAA + 42;
+            const double *U = R, *HAA = R + 40 * N, *SC = HAA + 42;
             const double w = SC[0];
             const int a = anch[s];
 #pragma unroll
             for (int k = 0; k < T; ++k) {
                 if (k * kLinThreads + tid >= n_tasks) continue;
-                const int fi = tfi[k], fj = tfj[k], r0 = 6 * fi + 3 * tsi[k], c0 = 6 * fj + 3 * tsj[k];
+                const int fi = tfi[k], fj = tfj[k], si = tsi[k], sj = tsj[k], r0 = 6 * fi + 3 * si, c0 = 6 * fj + 3 * sj;
+                const bool diag = fi == fj, a_is_j = a == fj, a_is_i = a == fi;
+                // JT(f) at 6N + 12 f, JR(f) at 18N + 16 f + 4 ; second row is +6 in both
+                const int xo = (diag || a_is_j) ? 6 * N + 12 * fi + 3 * si : 18 * N + 16 * fj + 4 + 3 * si;
+                const int yo = diag ? 6 * N + 12 * fi + 3 * sj : (a_is_j ? 18 * N + 16 * fi + 4 + 3 * sj : 6 * N + 12 * fj + 3 * sj);
+                const double fl = (diag || a_is_j || a_is_i) ? 1.0 : 0.0, hf = (diag && a_is_i) ? 1.0 : 0.0;
                 const double ur0 = w * U[r0], ur1 = w * U[r0 + 1], ur2 = w * U[r0 + 2];
                 const double uc0 = U[c0], uc1 = U[c0 + 1], uc2 = U[c0 + 2];
-                acc[k][0] -= ur0 * uc0, acc[k][1] -= ur0 * uc1, acc[k][2] -= ur0 * uc2;
-                acc[k][3] -= ur1 * uc0, acc[k][4] -= ur1 * uc1, acc[k][5] -= ur1 * uc2;
-                acc[k][6] -= ur2 * uc0, acc[k][7] -= ur2 * uc1, acc[k][8] -= ur2 * uc2;
-                const double *X = nullptr, *Y = nullptr;
-                if (fi == fj) {
-                    X = JT + 12 * fi + 3 * tsi[k], Y = JT + 12 * fi + 3 * tsj[k];
-                } else if (a == fj) {
-                    X = JT + 12 * fi + 3 * tsi[k], Y = JR + 12 * fi + 3 * tsj[k];
-                } else if (a == fi) {
-                    X = JR + 12 * fj + 3 * tsi[k], Y = JT + 12 * fj + 3 * tsj[k];
-                }
-                if (X) {
-#pragma unroll
-                    for (int i = 0; i < 3; ++i)
-#pragma unroll
-                        for (int j = 0; j < 3; ++j) acc[k][3 * i + j] += X[i] * Y[j] + X[6 + i] * Y[6 + j];
-                }
-                if (fi == fj && a == fi) {
-#pragma unroll
-                    for (int i = 0; i < 3; ++i)
-#pragma unroll
-                        for (int j = 0; j < 3; ++j) acc[k][3 * i + j] += HAA[(3 * tsi[k] + i) * 6 + 3 * tsj[k] + j];
-                }
+                const double *X = R + xo, *Y = R + yo, *Hh = HAA + 18 * si + 3 * sj;
+                const double x0 = fl * X[0], x1 = fl * X[1], x2 = fl * X[2], x3 = fl * X[6], x4 = fl * X[7], x5 = fl * X[8];
+                const double y0 = Y[0], y1 = Y[1], y2 = Y[2], y3 = Y[6], y4 = Y[7], y5 = Y[8];
+                acc[k][0] += x0 * y0 + x3 * y3 + hf * Hh[0] - ur0 * uc0;
+                acc[k][1] += x0 * y1 + x3 * y4 + hf * Hh[1] - ur0 * uc1;
+                acc[k][2] += x0 * y2 + x3 * y5 + hf * Hh[2] - ur0 * uc2;
+                acc[k][3] += x1 * y0 + x4 * y3 + hf * Hh[6] - ur1 * uc0;
+                acc[k][4] += x1 * y1 + x4 * y4 + hf * Hh[7] - ur1 * uc1;
+                acc[k][5] += x1 * y2 + x4 * y5 + hf * Hh[8] - ur1 * uc2;
+                acc[k][6] += x2 * y0 + x5 * y3 + hf * Hh[12] - ur2 * uc0;
+                acc[k][7] += x2 * y1 + x5 * y4 + hf * Hh[13] - ur2 * uc1;
+                acc[k][8] += x2 * y2 + x5 * y5 + hf * Hh[14] - ur2 * uc2;
             }
             if (tid < P6) {
                 const int f = tid / 6, c = tid - 6 * f;
-                const double *GT = R + 30 * N, *GA = HAA + 36;
+                const double *JT = R + 6 * N, *GT = R + 34 * N, *GA = HAA + 36;
                 vg += GT[6 * f + c] + (a == f ? GA[c] : 0.0);
                 vrhs += w * SC[1] * U[tid];
                 vdiag += JT[12 * f + c] * JT[12 * f + c] + JT[12 * f + 6 + c] * JT[12 * f + 6 + c] + (a == f ? HAA[7 * c] : 0.0);
             }
         }
         __syncthreads();
+        PV_STAMP(0, 7);
     }
     // ---- flush this WG's partial ----
     double *pS = v.part_S + (size_t)wg * n_tasks * 9;
@@ -391,6 +422,7 @@ __device__ void role_landmarks(const View &v, double *lds, const Pro *pro, int w
         double *ps = v.part_scal + (size_t)wg * kNumLinScal;
         ps[0] = sc[0], ps[1] = sc[1], ps[2] = sc[2], ps[3] = sc[3], ps[4] = sc[5], ps[5] = sc[4], ps[6] = 0, ps[7] = 0;
     }
+    PV_STAMP(0, 8);
 }
 
 // ---- plane-distance factors: one thread per factor, rows staged in LDS, same tile machinery (sign +) ----
@@ -539,15 +571,19 @@ __device__ void role_prior(const View &v, double *lds, const Pro *pro, int b, in
     if (b == 0) {
         // r = S e + s ; cost = |r|^2 / 2 ; g = B^T (Lambda e + eta)
         double c2 = 0;
+        // thread per row, but walking COLUMNS of S^T / Lambda (= rows, Lambda is symmetric) so that a wave reads
+        // consecutive addresses; 4-way unrolled independent accumulators
         for (int row = tid; row < D; row += kLinThreads) {
-            double s = v.prior_s[row];
-            const double *Sr = v.prior_S + (size_t)row * D;
-            for (int k = 0; k < D; ++k) s += Sr[k] * e[k];
+            double s0 = v.prior_s[row], s1 = 0, t0 = v.prior_eta[row], t1 = 0;
+            int k = 0;
+            for (; k + 1 < D; k += 2) {
+                s0 += v.prior_ST[(size_t)k * D + row] * e[k], s1 += v.prior_ST[(size_t)(k + 1) * D + row] * e[k + 1];
+                t0 += v.prior_Lambda[(size_t)k * D + row] * e[k], t1 += v.prior_Lambda[(size_t)(k + 1) * D + row] * e[k + 1];
+            }
+            if (k < D) s0 += v.prior_ST[(size_t)k * D + row] * e[k], t0 += v.prior_Lambda[(size_t)k * D + row] * e[k];
+            const double s = s0 + s1;
             c2 += s * s;
-            double t = v.prior_eta[row];
-            const double *Lr = v.prior_Lambda + (size_t)row * D;
-            for (int k = 0; k < D; ++k) t += Lr[k] * e[k];
-            rr[row] = t;
+            rr[row] = t0 + t1;
         }
         double sc[1] = {c2};
         block_sum<1>(sc, scratch); // also orders the rr writes
@@ -592,8 +628,11 @@ template <int T>
 __global__ void __launch_bounds__(kLinThreads) k_linearize(View v) {
     HIP_DYNAMIC_SHARED(double, lds)
     if (v.ctrl->done) return;
+    PV_STAMP(0, 0);
+    if (v.dbg && blockIdx.x == 0 && threadIdx.x == 0) v.dbg[30] = wall_clock64();
     Pro *pro;
     lin_prologue(v, lds, pro);
+    PV_STAMP(0, 1);
     if (!pro->valid) return; // invalid trust-region step: k_dense handles it (HandleInvalidStep)
     const int b = blockIdx.x, g0 = v.dm.G_lm, g1 = g0 + v.dm.G_plane, g2 = g1 + v.dm.G_pre;
     if (b < g0) role_landmarks<T>(v, lds, pro, b, g0);
@@ -602,31 +641,50 @@ __global__ void __launch_bounds__(kLinThreads) k_linearize(View v) {
         const int j = b - g1 + 1;
         if (v.pre_valid[j]) role_preint(v, lds, pro, j);
     } else role_prior(v, lds, pro, b - g2, v.dm.G_prior);
+    PV_STAMP(0, 9);
+    if (v.dbg && blockIdx.x == 0 && threadIdx.x == 0) v.dbg[31] = wall_clock64();
 }
 
 // ------------------------------------------------------------------------------------------------------
 // k_reduce: fixed-order sums of the WG partials -> red = [S tiles (element-major) | 3 pose vectors | 8 scalars]
 // ------------------------------------------------------------------------------------------------------
-__global__ void k_reduce(View v) {
+constexpr int kRedElems = 64, kRedGroups = 16; // one block = 64 output elements x 16 partial groups
+__global__ void __launch_bounds__(kRedElems *kRedGroups) k_reduce(View v) {
     if (v.ctrl->done || v.ctrl->lin_result == LIN_INVALID_STEP) return;
+    __shared__ double part[kRedGroups][kRedElems];
     const int G = v.dm.G_lm + v.dm.G_plane;
     const size_t nS = (size_t)v.dm.n_tasks * 9, nV = (size_t)kNumPoseVec * v.dm.P6;
     const size_t total = nS + nV + kNumLinScal;
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
-        double s = 0;
-        if (e < nS) {
-            for (int g = 0; g < G; ++g) s += v.part_S[(size_t)g * nS + e];
-        } else if (e < nS + nV) {
-            for (int g = 0; g < G; ++g) s += v.part_vec[(size_t)g * nV + (e - nS)];
-        } else {
-            const int k = (int)(e - nS - nV);
-            if (k == 4) {
-                for (int g = 0; g < G; ++g) s = fmax(s, v.part_scal[(size_t)g * kNumLinScal + k]);
-            } else {
-                for (int g = 0; g < G; ++g) s += v.part_scal[(size_t)g * kNumLinScal + k];
+    const int el = threadIdx.x & (kRedElems - 1), gg = threadIdx.x / kRedElems;
+    const size_t e = (size_t)blockIdx.x * kRedElems + el;
+    // stage 1: group gg sums partials g = gg, gg + 16, ... (coalesced across el), four independent accumulators
+    double s = 0;
+    if (e < nS + nV) {
+        const double *src = e < nS ? v.part_S + e : v.part_vec + (e - nS);
+        const size_t stride = e < nS ? nS : nV;
+        // <= 16 values per thread per round, all loads issued before the first add (one memory latency per round)
+        for (int g0 = gg; g0 < G; g0 += 16 * kRedGroups) {
+            double vals[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int g = g0 + k * kRedGroups;
+                vals[k] = g < G ? src[(size_t)g * stride] : 0.0;
             }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) s += vals[k];
         }
-        v.red[e] = s;
+    } else if (e < total) {
+        const int k = (int)(e - nS - nV);
+        for (int g = gg; g < G; g += kRedGroups) s = (k == 4) ? fmax(s, v.part_scal[(size_t)g * kNumLinScal + k]) : s + v.part_scal[(size_t)g * kNumLinScal + k];
+    }
+    part[gg][el] = s;
+    __syncthreads();
+    // stage 2: fixed-order combination of the 16 group sums
+    if (gg == 0 && e < total) {
+        const bool is_max = e >= nS + nV && (int)(e - nS - nV) == 4;
+        double r = part[0][el];
+        for (int k = 1; k < kRedGroups; ++k) r = is_max ? fmax(r, part[k][el]) : r + part[k][el];
+        v.red[e] = r;
     }
 }
 
@@ -649,7 +707,10 @@ struct DenseShared {
     double x_cost_new;
 };
 
+constexpr int kPanel = 8; // Cholesky panel width
+
 __global__ void __launch_bounds__(kDenseThreads) k_dense(View v, int lds_matrix) {
+    // 256 threads = one wave per SIMD: the redundant 8 x 8 block factorization then costs each SIMD exactly once
     HIP_DYNAMIC_SHARED(double, lds)
     Ctrl *c = v.ctrl;
     if (c->done) return;
@@ -657,16 +718,22 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(View v, int lds_matrix)
     const int n_tasks = v.dm.n_tasks;
     const size_t nS = (size_t)n_tasks * 9;
     const double *redV = v.red + nS, *redS = v.red + nS + (size_t)kNumPoseVec * P6;
-    // layout of dynamic LDS: [header 128][vec area 8 x (P+1)][A: (P+1) x ld if lds_matrix]  (no static LDS: keeps the
-    // dynamic base 16-byte aligned, cdna_hip_programming.md Guideline 17)
+    // dynamic LDS: [header 128][8 vectors of P+1][A: packed lower triangle of the (P+1) x (P+1) augmented matrix]
+    // (no static LDS: keeps the dynamic base 16-byte aligned, cdna_hip_programming.md Guideline 17).  Row P of A is
+    // the right-hand side, so the factorization performs the forward substitution on the fly.
     DenseShared &sh = *reinterpret_cast<DenseShared *>(lds);
     double *red_scratch = lds + 16; // 6 * 16 doubles
     int &sh_fail = *reinterpret_cast<int *>(lds + 120);
     const int ld = P + 1;
     double *vec = lds + 128;
     double *A = lds_matrix ? vec + 8 * (size_t)ld : v.Smat;
-    double *diagH = vec, *gtot = vec + ld, *rhs = vec + 2 * ld, *yv = vec + 3 * ld, *vv = vec + 4 * ld, *act = vec + 5 * ld, *tmp = vec + 6 * ld;
+    double *diagH = vec, *gtot = vec + ld, *rhs = vec + 2 * ld, *yv = vec + 3 * ld, *vv = vec + 4 * ld, *act = vec + 5 * ld, *tmp = vec + 6 * ld,
+           *cpl = vec + 7 * ld;
+    auto IDX = [](int i, int k) -> size_t { return (size_t)i * (i + 1) / 2 + k; }; // k <= i
+    const int tx = tid & 31, ty = tid >> 5, ny = nthr >> 5;
 
+    PV_STAMP(2, 0);
+    if (v.dbg && threadIdx.x == 0) v.dbg[2 * 32 + 30] = wall_clock64();
     // ---------------- control (thread 0): Finalize the iteration in flight, decide what comes next ----------------
     if (tid == 0) {
         const int lr = c->lin_result;
@@ -750,57 +817,55 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(View v, int lds_matrix)
         if (tid == 0) c->mode = MODE_DONE;
         return;
     }
+    PV_STAMP(2, 1);
     const bool need_build = sh.accepted || sh.do_solve; // a new accepted linearization (or RELIN) is in `red`
-    // ---------------- assemble the unscaled totals: diag(H), gradient, Schur rhs, matrix ----------------
+    // ---------------- assemble the unscaled totals: diag(H), gradient, Schur rhs, lower triangle ----------------
     if (need_build) {
         for (int a = tid; a < P; a += nthr) {
             const int f = a / d, k = a - d * f;
             double dg = 0, g = 0, rs = 0;
-            if (k < 6) {
-                dg = redV[2 * P6 + 6 * f + k], g = redV[6 * f + k], rs = redV[P6 + 6 * f + k];
-            }
+            if (k < 6) dg = redV[2 * P6 + 6 * f + k], g = redV[6 * f + k], rs = redV[P6 + 6 * f + k];
             act[a] = (k < 6 ? v.pose_active[f] : v.motion_active[f]) ? 1.0 : 0.0;
-            diagH[a] = dg, gtot[a] = g, rhs[a] = -rs;
+            diagH[a] = dg, gtot[a] = g, rhs[a] = g - rs; // rhs_u = g_total - sum_l w_l W_l^T b_l
         }
-        for (size_t e = tid; e < (size_t)(P + 1) * ld; e += nthr) A[e] = 0.0;
+        const size_t npk = IDX(P, P) + 1;
+        for (size_t e = tid; e < npk; e += nthr) A[e] = 0.0;
         __syncthreads();
-        // landmark + plane tiles (upper block triangle, element-major) -> both triangles of A
+        // landmark + plane tiles (upper block triangle, element-major) -> lower triangle of A
         for (size_t e = tid; e < nS; e += nthr) {
             const int el = (int)(e / n_tasks), t = (int)(e - (size_t)el * n_tasks);
             int fi, fj, si, sj;
             unpack_task(v.task_desc[t], fi, fj, si, sj);
             const int r = d * fi + 3 * si + el / 3, cc = d * fj + 3 * sj + el % 3;
-            const double val = v.red[e];
-            if (fi == fj) {
-                A[(size_t)r * ld + cc] = val; // diagonal blocks are computed in full (all four 3x3 sub tiles)
-            } else {
-                A[(size_t)r * ld + cc] = val;
-                A[(size_t)cc * ld + r] = val;
-            }
+            if (fi != fj) A[IDX(cc, r)] = v.red[e];       // fi < fj  =>  r < cc
+            else if (r >= cc) A[IDX(r, cc)] = v.red[e];   // diagonal blocks come in full; keep the lower half
         }
         __syncthreads();
-        // IMU pre-integration blocks (30 x 30 on frames j-1, j) and the prior: one thread per output element
         if (d == 15) {
-            for (int j = 1; j < N; ++j) {
-                if (!(v.dm.G_pre && v.pre_valid[j])) continue;
-                const double *H = v.pre_H + (size_t)j * 900;
-                for (int e = tid; e < 900; e += nthr) {
-                    const int a = e / 30, b = e - 30 * a;
-                    A[(size_t)(15 * (j - 1) + a) * ld + 15 * (j - 1) + b] += H[e];
-                }
-                if (tid < 30) {
-                    diagH[15 * (j - 1) + tid] += H[31 * tid];
-                    gtot[15 * (j - 1) + tid] += v.pre_g[(size_t)j * 30 + tid];
-                    rhs[15 * (j - 1) + tid] += v.pre_g[(size_t)j * 30 + tid];
+            // IMU pre-integration blocks (30 x 30 on frames j-1, j); consecutive factors overlap -> one at a time
+            for (int par = 0; par < 2; ++par) { // factors of equal parity touch disjoint blocks
+                for (int e = tid; e < 900 * (N / 2 + 1); e += nthr) {
+                    const int j = 1 + par + 2 * (e / 900), el = e % 900;
+                    if (j >= N || !(v.dm.G_pre && v.pre_valid[j])) continue;
+                    const int a = el / 30, b = el - 30 * a;
+                    const double h = v.pre_H[(size_t)j * 900 + el];
+                    if (a >= b) A[IDX(15 * (j - 1) + a, 15 * (j - 1) + b)] += h;
+                    if (a == b) diagH[15 * (j - 1) + a] += h;
+                    if (b == 0) {
+                        const double g = v.pre_g[(size_t)j * 30 + a];
+                        gtot[15 * (j - 1) + a] += g, rhs[15 * (j - 1) + a] += g;
+                    }
                 }
                 __syncthreads();
             }
             if (v.dm.prior_n > 0) {
                 const int n = v.dm.prior_n, D = 15 * n;
-                for (int e = tid; e < D * D; e += nthr) {
-                    const int a = e / D, b = e - D * a;
-                    const int ga = 15 * v.prior_frames[a / 15] + a % 15, gb = 15 * v.prior_frames[b / 15] + b % 15;
-                    A[(size_t)ga * ld + gb] += v.prior_H[e];
+                for (int a = ty; a < D; a += ny) {
+                    const int ga = 15 * v.prior_frames[a / 15] + a % 15;
+                    for (int b = tx; b < D; b += 32) {
+                        const int gb = 15 * v.prior_frames[b / 15] + b % 15;
+                        if (ga >= gb) A[IDX(ga, gb)] += v.prior_H[(size_t)a * D + b];
+                    }
                 }
                 for (int a = tid; a < D; a += nthr) {
                     const int ga = 15 * v.prior_frames[a / 15] + a % 15;
@@ -811,12 +876,6 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(View v, int lds_matrix)
                 __syncthreads();
             }
         }
-        // rhs so far = -rhs_schur + aux gradients; add the direct landmark gradient
-        for (int a = tid; a < P; a += nthr) {
-            const int f = a / d, k = a - d * f;
-            if (k < 6) rhs[a] += redV[6 * f + k];
-        }
-        __syncthreads();
         // gradient_max_norm = max | x - (x (+) -g) | over the free blocks (ambient coordinates)
         double gm = 0;
         if (tid < N) {
@@ -836,6 +895,7 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(View v, int lds_matrix)
         }
         __syncthreads();
     }
+    PV_STAMP(2, 2);
     // ---------------- Finalize: record, state-updating callback, termination tests ----------------
     if (tid == 0 && sh.do_trace) {
         const int lr = c->lin_result;
@@ -881,110 +941,195 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(View v, int lds_matrix)
     }
     if (!sh.do_solve) return;
 
+    PV_STAMP(2, 3);
     // ---------------- Jacobi scaling (once), dogleg diagonal, scaled system ----------------
-    if (!c->scaling_ready)
-        for (int a = tid; a < P; a += nthr) v.cp[a] = act[a] != 0.0 ? 1.0 / (1.0 + sqrt(diagH[a])) : 1.0;
-    __syncthreads();
+    const bool first_scaling = !c->scaling_ready;
     const double mu = c->mu;
     for (int a = tid; a < P; a += nthr) {
-        const double cpa = v.cp[a];
+        double cpa;
+        if (first_scaling) {
+            cpa = act[a] != 0.0 ? 1.0 / (1.0 + sqrt(diagH[a])) : 1.0; // jacobi_scaling = 1 / (1 + sqrt(col norm^2)), once
+            v.cp[a] = cpa;
+        } else {
+            cpa = v.cp[a];
+        }
+        cpl[a] = cpa;
         const double d2 = cpa * cpa * diagH[a];
         const double Da = sqrt(fmin(fmax(d2, 1e-6), 1e32));
         v.Dp[a] = Da;
         const double gh = act[a] != 0.0 ? cpa * gtot[a] / Da : 0.0;
         v.ghp[a] = gh;
-        vv[a] = gh / Da;           // v = g^ / D
-        tmp[a] = cpa * gtot[a];    // scaled gradient g_s
-        A[(size_t)P * ld + a] = act[a] != 0.0 ? cpa * rhs[a] : 0.0; // augmented row: scaled reduced rhs
+        vv[a] = gh / Da;                                                // v = g^ / D
+        tmp[a] = Da;
+        A[IDX(P, a)] = act[a] != 0.0 ? cpa * rhs[a] : 0.0;              // augmented row: scaled reduced rhs
     }
     __syncthreads();
-    for (size_t e = tid; e < (size_t)P * P; e += nthr) {
-        const int a = (int)(e / P), b = (int)(e - (size_t)a * P);
-        double val = A[(size_t)a * ld + b];
-        if (act[a] == 0.0 || act[b] == 0.0) val = (a == b) ? 1.0 : 0.0;
-        else val *= v.cp[a] * v.cp[b];
-        A[(size_t)a * ld + b] = val;
+    for (int a = ty; a < P; a += ny) {
+        const double ca_ = cpl[a], aa = act[a];
+        for (int b = tx; b <= a; b += 32) {
+            double val = A[IDX(a, b)];
+            if (aa == 0.0 || act[b] == 0.0) val = (a == b) ? 1.0 : 0.0;
+            else val *= ca_ * cpl[b];
+            A[IDX(a, b)] = val;
+        }
     }
     __syncthreads();
-    // pose quadratic forms with the Schur-reduced scaled matrix (mu D^2 not yet added): v^T S v
+    // pose quadratic form with the Schur-reduced scaled matrix (mu D^2 not yet added): S v, 4 lanes per row
     {
         double q = 0;
-        for (int a = tid; a < P; a += nthr) {
+        const int seg = tid & 3;
+        for (int a0 = 0; a0 < P; a0 += (nthr >> 2)) {
+            const int a = a0 + (tid >> 2);
             double row = 0;
-            for (int b = 0; b < P; ++b) row += A[(size_t)a * ld + b] * vv[b];
-            yv[a] = row; // S v
-            q += act[a] != 0.0 ? vv[a] * row : 0.0;
+            if (a < P)
+                for (int b = seg; b < P; b += 4) row += (b <= a ? A[IDX(a, b)] : A[IDX(b, a)]) * vv[b];
+            row += __shfl_xor(row, 1);
+            row += __shfl_xor(row, 2);
+            if (a < P && seg == 0) {
+                diagH[a] = row; // S v  (diagH is free from here on)
+                q += act[a] != 0.0 ? vv[a] * row : 0.0;
+            }
         }
         double s1[1] = {q};
         block_sum<1>(s1, red_scratch);
         if (tid == 0) c->pose_qvv = s1[0];
     }
-    // keep S v for q_vy: copy to tmp2 region (reuse diagH which is no longer needed after Dp)
-    for (int a = tid; a < P; a += nthr) diagH[a] = yv[a];
-    __syncthreads();
     for (int a = tid; a < P; a += nthr)
-        if (act[a] != 0.0) A[(size_t)a * ld + a] += mu * v.Dp[a] * v.Dp[a];
+        if (act[a] != 0.0) A[IDX(a, a)] += mu * tmp[a] * tmp[a];
     __syncthreads();
-    // ---------------- Cholesky of the augmented matrix: one barrier per column ----------------
-    // a_ik -= a_ij a_kj / a_jj keeps columns unscaled; row P carries the right-hand side (forward substitution)
+    PV_STAMP(2, 4);
+    // ---------------- panel Cholesky (width 8), two barriers per panel ----------------
+    // Every thread factors the 8 x 8 diagonal block redundantly in registers (no communication), then the thread that
+    // owns row i turns its panel entries into L (row P = right-hand side -> forward substitution for free), then all
+    // threads apply the rank-8 update to the trailing lower triangle.
     int fail = 0;
-    for (int j = 0; j < P; ++j) {
-        const double piv = A[(size_t)j * ld + j];
-        if (!(piv > 0.0) || !isfinite(piv)) {
-            fail = 1;
-            break;
+    for (int j0 = 0; j0 < P && !fail; j0 += kPanel) {
+        const int nb = min(kPanel, P - j0);
+        double Ld[kPanel][kPanel], inv[kPanel];
+#pragma unroll
+        for (int r = 0; r < kPanel; ++r)
+#pragma unroll
+            for (int cc = 0; cc <= r; ++cc) Ld[r][cc] = (r < nb) ? A[IDX(j0 + r, j0 + cc)] : (r == cc ? 1.0 : 0.0);
+#pragma unroll
+        for (int cc = 0; cc < kPanel; ++cc) {
+            double dd = Ld[cc][cc];
+#pragma unroll
+            for (int k = 0; k < cc; ++k) dd -= Ld[cc][k] * Ld[cc][k];
+            if (!(dd > 0.0) || !isfinite(dd)) fail = 1;
+            inv[cc] = fast_rsqrt(dd);
+            Ld[cc][cc] = dd * inv[cc];
+#pragma unroll
+            for (int r = cc + 1; r < kPanel; ++r) {
+                double x = Ld[r][cc];
+#pragma unroll
+                for (int k = 0; k < cc; ++k) x -= Ld[r][k] * Ld[cc][k];
+                Ld[r][cc] = x * inv[cc];
+            }
         }
-        const double ip = 1.0 / piv;
-        const int m = P - j; // rows j+1 .. P  (P = rhs row)
-        const int npairs = m * (m + 1) / 2 - 0;
-        // pairs (i,k), j < k <= i <= P, k <= P-1 ; enumerate i over [j+1, P], k over [j+1, min(i, P-1)]
-        for (int e = tid; e < npairs; e += nthr) {
-            // invert e -> (ii, kk) with 0 <= kk <= ii < m : e = ii (ii+1)/2 + kk
-            int ii = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
-            while ((ii + 1) * (ii + 2) / 2 <= e) ++ii;
-            while (ii * (ii + 1) / 2 > e) --ii;
-            const int kk = e - ii * (ii + 1) / 2;
-            const int i = j + 1 + ii, k = j + 1 + kk;
-            if (k >= P) continue; // the rhs row has no column of its own
-            A[(size_t)i * ld + k] -= A[(size_t)i * ld + j] * A[(size_t)k * ld + j] * ip;
+        if (fail) break; // uniform: every thread factored the same block
+#pragma unroll
+        for (int cc = 0; cc < kPanel; ++cc)
+            if (tid == cc && cc < nb) tmp[j0 + cc] = inv[cc]; // 1 / L_jj for the back substitution
+        const int k0 = j0 + nb;
+        double x[kPanel];
+        const int irow = j0 + tid; // row owner
+        if (irow <= P) {
+#pragma unroll
+            for (int cc = 0; cc < kPanel; ++cc) x[cc] = (cc < nb && j0 + cc <= irow) ? A[IDX(irow, j0 + cc)] : 0.0;
+#pragma unroll
+            for (int cc = 0; cc < kPanel; ++cc) {
+                double t = x[cc];
+#pragma unroll
+                for (int k = 0; k < cc; ++k) t -= x[k] * Ld[cc][k];
+                x[cc] = t * inv[cc];
+            }
+            // rows below the panel can be written now; the panel's own rows ARE the diagonal block other threads may
+            // still be reading, so they go back only after the barrier (nothing in the update reads them)
+            if (irow >= k0) {
+#pragma unroll
+                for (int cc = 0; cc < kPanel; ++cc)
+                    if (cc < nb) A[IDX(irow, j0 + cc)] = x[cc];
+            }
+        }
+        __syncthreads();
+        if (irow < k0) {
+#pragma unroll
+            for (int cc = 0; cc < kPanel; ++cc)
+                if (cc < nb && j0 + cc <= irow) A[IDX(irow, j0 + cc)] = x[cc];
+        }
+        for (int i = k0 + ty; i <= P; i += ny) {
+            double li[kPanel];
+#pragma unroll
+            for (int cc = 0; cc < kPanel; ++cc) li[cc] = cc < nb ? A[IDX(i, j0 + cc)] : 0.0;
+            const int kmax = i < P ? i : P - 1;
+            for (int k = k0 + tx; k <= kmax; k += 32) {
+                const double *Lk = A + IDX(k, j0);
+                double sacc = 0;
+#pragma unroll
+                for (int cc = 0; cc < kPanel; ++cc) sacc += cc < nb ? li[cc] * Lk[cc] : 0.0;
+                A[IDX(i, k)] -= sacc;
+            }
         }
         __syncthreads();
     }
-    // ---------------- back substitution L^T y = z in wave 0 (rows owned by lanes, shuffles) ----------------
+    PV_STAMP(2, 5);
+    // ---------------- back substitution L^T y = z in wave 0 (rows owned by lanes, one shuffle per column) ----------------
     if (tid == 0) sh_fail = fail;
     __syncthreads();
     if (!fail) {
         double zz = 0;
         for (int a = tid; a < P; a += nthr) {
-            const double dj = sqrt(A[(size_t)a * ld + a]);
-            tmp[a] = dj;                                 // L_aa
-            const double z = A[(size_t)P * ld + a] / dj; // z_a = (L^-1 rhs)_a
+            const double z = A[IDX(P, a)]; // z = L^-1 rhs (row P went through the factorization)
             yv[a] = z;
             zz += act[a] != 0.0 ? z * z : 0.0;
         }
         double s1[1] = {zz};
         block_sum<1>(s1, red_scratch);
         if (tid == 0) c->pose_qyy = s1[0]; // y^T (S + mu D^2) y = |z|^2 ; the mu term is removed below
+        __syncthreads();
         if (tid < 64) {
-            // lane owns rows a = tid + 64 q.  L[j][i] (j > i) = A[j][i] / sqrt(A[i][i]).
+            // lane owns rows a = lane + 64 q (q < 8 -> P <= 512) in REGISTERS; per column: one readlane broadcast,
+            // the row of L is read ahead of the dependency chain
+            double yr[8], ir[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int a = tid + 64 * q;
+                yr[q] = a < P ? yv[a] : 0.0;
+                ir[q] = a < P ? tmp[a] : 0.0;
+            }
             for (int j = P - 1; j >= 0; --j) {
-                const int owner = j & 63;
-                double yj = 0;
-                if (tid == owner) {
-                    yj = yv[j] / tmp[j];
-                    yv[j] = yj;
+                const int owner = j & 63, qj = j >> 6;
+                double cand = 0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) cand = (q == qj) ? yr[q] * ir[q] : cand;
+                const double yj = readlane_f64(cand, owner);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int a = tid + 64 * q;
+                    if (q == qj && tid == owner) yr[q] = yj;
+                    else if (a < j) yr[q] -= A[IDX(j, a)] * yj;
                 }
-                yj = __shfl(yj, owner);
-                for (int a = tid; a < j; a += 64) yv[a] -= (A[(size_t)j * ld + a] / tmp[a]) * yj;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int a = tid + 64 * q;
+                if (a < P) yv[a] = yr[q];
             }
         }
         __syncthreads();
     }
+    PV_STAMP(2, 6);
     // ---------------- outputs ----------------
+    double nbad = 0;
+    if (!sh_fail)
+        for (int a = tid; a < P; a += nthr) nbad += isfinite(yv[a]) ? 0.0 : 1.0;
+    {
+        double sb[1] = {nbad};
+        block_sum<1>(sb, red_scratch);
+        nbad = sb[0];
+    }
     if (tid == 0) {
-        int ok = !sh_fail;
-        if (ok)
-            for (int a = 0; a < P; ++a) ok &= isfinite(yv[a]) ? 1 : 0;
+        const int ok = !sh_fail && nbad == 0.0;
         if (ok) {
             c->solve_ok = 1, c->mode = MODE_CANDIDATE, c->scaling_ready = 1, c->retry_relin = 0;
         } else {
@@ -1006,25 +1151,26 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(View v, int lds_matrix)
     if (!sh.do_solve) return;
     // y solves (S + mu D^2) y = rhs_s ; step direction y' = -y ; gn = D y'
     {
-        double s_g2 = 0, s_gn2 = 0, s_gd = 0, s_qvy = 0, s_qyy = 0, s_gy = 0;
+        double s_g2 = 0, s_gn2 = 0, s_gd = 0, s_qvy = 0, s_gy = 0;
         for (int a = tid; a < P; a += nthr) {
             const double yp = act[a] != 0.0 ? -yv[a] : 0.0;
             const double Da = v.Dp[a], gh = v.ghp[a], gn = Da * yp;
-            v.ystep[a] = v.cp[a] * yp;
-            v.vstep[a] = act[a] != 0.0 ? v.cp[a] * vv[a] : 0.0;
+            v.ystep[a] = cpl[a] * yp;
+            v.vstep[a] = act[a] != 0.0 ? cpl[a] * vv[a] : 0.0;
             s_g2 += gh * gh, s_gn2 += gn * gn, s_gd += gh * gn;
             s_qvy += diagH[a] * yp;                      // (S v) . y'
-            s_gy += act[a] != 0.0 ? v.cp[a] * gtot[a] * yp : 0.0;
+            s_gy += act[a] != 0.0 ? cpl[a] * gtot[a] * yp : 0.0;
         }
         // y'^T S y' = |z|^2 - mu sum D_a^2 y'_a^2 = |z|^2 - mu |gn_p|^2
-        (void)s_qyy;
-        double sc[6] = {s_g2, s_gn2, s_gd, s_qvy, 0.0, s_gy};
-        block_sum<6>(sc, red_scratch);
+        double sc[5] = {s_g2, s_gn2, s_gd, s_qvy, s_gy};
+        block_sum<5>(sc, red_scratch);
         if (tid == 0) {
-            c->pose_g2 = sc[0], c->pose_gn2 = sc[1], c->pose_gdot = sc[2], c->pose_qvy = sc[3], c->pose_gy = sc[5];
+            c->pose_g2 = sc[0], c->pose_gn2 = sc[1], c->pose_gdot = sc[2], c->pose_qvy = sc[3], c->pose_gy = sc[4];
             c->pose_qyy = c->pose_qyy - mu * sc[1];
         }
     }
+    PV_STAMP(2, 7);
+    if (v.dbg && threadIdx.x == 0) v.dbg[2 * 32 + 31] = wall_clock64();
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1147,13 +1293,14 @@ __global__ void k_quality(View v, int buf_from_ctrl, double *err_sum /* [2] opti
 }
 
 // Lambda = S^T S, eta = S^T s of the marginalization prior (once per upload)
-__global__ void k_prior_prep(const double *S, const double *s, int D, double *Lambda, double *eta) {
+__global__ void k_prior_prep(const double *S, const double *s, int D, double *Lambda, double *eta, double *ST) {
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < D * (D + 1); e += gridDim.x * blockDim.x) {
         const int a = e / (D + 1), b = e - a * (D + 1);
         double acc = 0;
         if (b < D) {
             for (int r = 0; r < D; ++r) acc += S[(size_t)r * D + a] * S[(size_t)r * D + b];
             Lambda[(size_t)a * D + b] = acc;
+            ST[(size_t)a * D + b] = S[(size_t)b * D + a];
         } else {
             for (int r = 0; r < D; ++r) acc += S[(size_t)r * D + a] * s[r];
             eta[a] = acc;
@@ -1207,16 +1354,15 @@ hipError_t launch_linearize(const View &v, hipStream_t st) {
 
 hipError_t launch_reduce(const View &v, hipStream_t st) {
     const size_t total = (size_t)v.dm.n_tasks * 9 + (size_t)kNumPoseVec * v.dm.P6 + kNumLinScal;
-    int grid = (int)((total + 255) / 256);
-    if (grid > 1024) grid = 1024;
-    hipLaunchKernelGGL(k_reduce, dim3(grid), dim3(256), 0, st, v);
+    const int grid = (int)((total + kRedElems - 1) / kRedElems);
+    hipLaunchKernelGGL(k_reduce, dim3(grid), dim3(kRedElems * kRedGroups), 0, st, v);
     return hipGetLastError();
 }
 
 size_t dense_lds_bytes(const Dims &dm, int *lds_matrix) {
     const size_t P = dm.P, ld = P + 1;
     const size_t vec = (128 + 8 * ld) * sizeof(double);
-    const size_t mat = (P + 1) * ld * sizeof(double);
+    const size_t mat = ((P + 1) * (P + 2) / 2 + 8) * sizeof(double); // packed lower triangle incl. the rhs row
     *lds_matrix = (mat + vec <= 150 * 1024) ? 1 : 0;
     return *lds_matrix ? mat + vec : vec;
 }
@@ -1251,9 +1397,9 @@ hipError_t launch_quality(const View &v, hipStream_t st, int buf_from_ctrl, doub
     hipLaunchKernelGGL(k_quality, dim3(grid), dim3(256), 0, st, v, buf_from_ctrl, err_sum);
     return hipGetLastError();
 }
-hipError_t launch_prior_prep(const double *S, const double *s, int D, double *Lambda, double *eta, hipStream_t st) {
+hipError_t launch_prior_prep(const double *S, const double *s, int D, double *Lambda, double *eta, double *ST, hipStream_t st) {
     int grid = (D * (D + 1) + 255) / 256;
-    hipLaunchKernelGGL(k_prior_prep, dim3(grid), dim3(256), 0, st, S, s, D, Lambda, eta);
+    hipLaunchKernelGGL(k_prior_prep, dim3(grid), dim3(256), 0, st, S, s, D, Lambda, eta, ST);
     return hipGetLastError();
 }
 

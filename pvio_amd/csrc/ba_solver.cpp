@@ -152,9 +152,16 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st) {
         motion_active[i] = (dm.d == 15) && motion_used[i];
     }
 
-    // ---- landmark chunks: <= lm_slots landmarks and <= 256 factors each (one thread per factor) ----
+    hipDeviceProp_t prop;
+    if (check(hipGetDeviceProperties(&prop, device_), "hipGetDeviceProperties")) return PVIO_ERR_HIP;
+    const int cus = std::max(1, prop.multiProcessorCount);
+    // ---- landmark chunks: <= lm_slots landmarks and <= 256 factors each (one thread per factor).  A small window is
+    // latency-bound per workgroup, so chunks are sized to put one chunk on every CU (256 on MI355X) rather than to fill
+    // the LDS; a large window falls back to LDS-filling chunks that each workgroup walks in a grid-stride loop. ----
     const size_t lds_budget = 112 * 1024;
-    dm.lm_slots = (int)std::max<size_t>(1, std::min<size_t>(lds_budget / 8 / (40 * N + 46), (size_t)kLinThreads));
+    const int slots_lds = (int)std::max<size_t>(1, std::min<size_t>(lds_budget / 8 / (40 * N + 46), (size_t)kLinThreads));
+    const int slots_spread = std::max(1, (M + cus - 1) / cus);
+    dm.lm_slots = std::min(slots_lds, slots_spread);
     std::vector<int32_t> chunk_lm;
     chunk_lm.push_back(0);
     {
@@ -176,9 +183,6 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st) {
     if (plane_chunk.empty() || plane_chunk.back() != dm.n_plane) plane_chunk.push_back(dm.n_plane);
     dm.n_plane_chunks = (int)plane_chunk.size() - 1;
 
-    hipDeviceProp_t prop;
-    if (check(hipGetDeviceProperties(&prop, device_), "hipGetDeviceProperties")) return PVIO_ERR_HIP;
-    const int cus = std::max(1, prop.multiProcessorCount);
     dm.G_lm = std::max(1, std::min(dm.n_chunks, cus));
     dm.G_plane = dm.n_plane > 0 ? std::max(1, std::min(dm.n_plane_chunks, std::max(1, cus / 4))) : 0;
     dm.G_pre = dm.use_inertial ? N - 1 : 0;
@@ -222,10 +226,11 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st) {
     ok &= up(pool_, "prior_S", pb->prior_S, Dp * Dp, &v.prior_S, stream_, &grew);
     ok &= up(pool_, "prior_s", pb->prior_s, Dp, &v.prior_s, stream_, &grew);
     ok &= up(pool_, "prior_lin", pb->prior_lin_state, (size_t)dm.prior_n * 16, &v.prior_lin, stream_, &grew);
-    double *Lambda = nullptr, *eta = nullptr;
+    double *Lambda = nullptr, *eta = nullptr, *ST = nullptr;
     ok &= dev(pool_, "prior_Lambda", Dp * Dp, &Lambda, &grew);
     ok &= dev(pool_, "prior_eta", Dp, &eta, &grew);
-    v.prior_Lambda = Lambda, v.prior_eta = eta;
+    ok &= dev(pool_, "prior_ST", Dp * Dp, &ST, &grew);
+    v.prior_Lambda = Lambda, v.prior_eta = eta, v.prior_ST = ST;
     const size_t npo = dm.n_plane ? (size_t)pb->plane_obs_ptr[dm.n_plane] : 0;
     ok &= up(pool_, "plane_ptr", pb->plane_obs_ptr, (size_t)dm.n_plane + 1, &v.plane_ptr, stream_, &grew);
     ok &= up(pool_, "plane_frame", pb->plane_obs_frame, npo, &v.plane_frame, stream_, &grew);
@@ -286,7 +291,7 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st) {
     if (!ok) return fail(PVIO_ERR_OUT_OF_MEMORY, "device allocation failed");
     if (check(hipMemcpyAsync(fs_init, h_init_fs_.data(), Ns * 16 * sizeof(double), hipMemcpyHostToDevice, stream_), "H2D state")) return PVIO_ERR_HIP;
     if (M && check(hipMemcpyAsync(rho_init, h_init_rho_.data(), (size_t)M * sizeof(double), hipMemcpyHostToDevice, stream_), "H2D state")) return PVIO_ERR_HIP;
-    if (dm.prior_n > 0 && check(launch_prior_prep(v.prior_S, v.prior_s, (int)Dp, Lambda, eta, stream_), "k_prior_prep")) return PVIO_ERR_HIP;
+    if (dm.prior_n > 0 && check(launch_prior_prep(v.prior_S, v.prior_s, (int)Dp, Lambda, eta, ST, stream_), "k_prior_prep")) return PVIO_ERR_HIP;
 
     const bool dims_changed = std::memcmp(&v.dm, &v_.dm, sizeof(Dims)) != 0;
     if (grew || dims_changed || std::memcmp(&v, &v_, sizeof(View)) != 0) invalidate_graph();
@@ -383,9 +388,15 @@ int BASolver::solve(pvio_ba_summary *sum, pvio_ba_kernel_times *prof) {
     const int n_slots = dm.max_iter + 2;
     int rounds = 0;
     hipEvent_t pev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    long long *dbg_saved = v_.dbg;
     if (prof) {
         std::memset(prof, 0, sizeof *prof);
         for (auto &e : pev) (void)hipEventCreate(&e);
+        bool grew = false;
+        long long *dbg = nullptr;
+        if (!dev(pool_, "dbg", 4 * 32, &dbg, &grew)) return fail(PVIO_ERR_OUT_OF_MEMORY, "dbg");
+        (void)hipMemsetAsync(dbg, 0, 4 * 32 * sizeof(long long), stream_);
+        v_.dbg = dbg;
     }
     for (;;) {
         int rc;
@@ -411,8 +422,11 @@ int BASolver::solve(pvio_ba_summary *sum, pvio_ba_kernel_times *prof) {
         if (check(hipStreamSynchronize(stream_), "solve sync")) return PVIO_ERR_HIP;
         if (h_ctrl_->done || ++rounds > 16) break;
     }
-    if (prof)
+    if (prof) {
         for (auto &e : pev) (void)hipEventDestroy(e);
+        (void)hipMemcpy(prof->phase_ticks, v_.dbg, 4 * 32 * sizeof(long long), hipMemcpyDeviceToHost);
+        v_.dbg = dbg_saved;
+    }
     if (!h_ctrl_->done) return fail(PVIO_ERR_HIP, "device state machine did not terminate");
     float ms = 0;
     (void)hipEventElapsedTime(&ms, ev0_, ev1_);

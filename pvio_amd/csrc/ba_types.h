@@ -16,7 +16,7 @@ namespace pvba {
 
 constexpr int kMaxFrames = 32;
 constexpr int kLinThreads = 256;   // workgroup size of k_linearize
-constexpr int kDenseThreads = 1024;
+constexpr int kDenseThreads = 256;
 constexpr int kNumLinScal = 8;     // cost, sum g^_l^2, |step_l|^2, |x_l|^2, max|b_l|, nonfinite, spare, spare
 constexpr int kNumBackScal = 8;    // sum gn_l^2, sum g^_l gn_l, Qvv, Qvy, Qyy, Gy, spare, spare
 constexpr int kNumPoseVec = 3;     // g_dir, rhs_schur, diagH_dir
@@ -99,7 +99,7 @@ struct View { // passed by value to every kernel
     const uint8_t *pre_valid;     // [N]
     const double *pre_delta, *pre_U, *pre_jac;
     const int32_t *prior_frames;
-    const double *prior_S, *prior_s, *prior_lin, *prior_Lambda, *prior_eta;
+    const double *prior_S, *prior_s, *prior_lin, *prior_Lambda, *prior_eta, *prior_ST; // Lambda = S^T S, eta = S^T s, ST = S^T
     const int32_t *plane_ptr, *plane_frame, *plane_chunk; // CSR + chunk ranges
     const double *plane_z, *plane_normal, *plane_dist;
     double plane_sic;
@@ -127,6 +127,7 @@ struct View { // passed by value to every kernel
     double *trace_states;
     double *lm_quality;
     uint8_t *lm_valid;
+    long long *dbg; // optional phase timestamps (profiling builds): [kernel 0..3][32] shader-clock ticks, block 0 / thread 0
 };
 
 inline int lin_set_stride_M() { return 1; }

@@ -66,6 +66,7 @@ class HipContext:
         kt = capi.BAKernelTimesC()
         self._check(self.lib.pvio_hip_ba_profile_resident(self.ctx, C.byref(summary.c), C.byref(kt)), "pvio_hip_ba_profile_resident")
         names = ["k_linearize", "k_reduce", "k_dense", "k_backsub"]
+        self.last_phase_ticks = {n: [int(x) for x in kt.phase_ticks[i]] for i, n in enumerate(names)}
         return {n: (kt.total_ms[i], kt.launches[i]) for i, n in enumerate(names)}
 
     def download(self, state):

@@ -26,6 +26,7 @@ std::vector<Fiber> fibers;
 std::vector<WaveState> waves;
 ucontext_t sched_ctx;
 int n_threads = 0, bar_arrived = 0, bar_generation = 0, n_done = 0;
+long launch_counter = 0;
 std::function<void()> *cur_body = nullptr;
 Fiber *cur_fiber = nullptr;
 
@@ -79,6 +80,7 @@ double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::
 
 void launch(dim3 grid, dim3 block, size_t shmem, Stream *s, std::function<void()> body) {
     auto run = [grid, block, shmem, body]() mutable {
+        ++launch_counter;
         const int nt = (int)(block.x * block.y * block.z);
         if (shmem > sizeof(dyn_smem_pool)) {
             std::fprintf(stderr, "hipemu: dynamic LDS request %zu exceeds 160 KiB\n", shmem);
@@ -130,8 +132,9 @@ void launch(dim3 grid, dim3 block, size_t shmem, Stream *s, std::function<void()
                                 ++progressed;
                             }
                         }
-                        if (!progressed && ++spins > 2000000) {
-                            std::fprintf(stderr, "hipemu: block (%u,%u,%u) deadlocked (divergent barrier / shuffle?)\n", bx, by, bz);
+                        if (!progressed && ++spins > 20000) {
+                            std::fprintf(stderr, "hipemu: launch #%ld (%d threads) block (%u,%u,%u) deadlocked: bar_arrived=%d n_done=%d (divergent barrier / shuffle?)\n", launch_counter, nt, bx, by, bz, bar_arrived, n_done);
+                            for (size_t w = 0; w < waves.size(); ++w) std::fprintf(stderr, "  wave %zu: arrived=%d alive=%d readers=%d\n", w, waves[w].arrived, waves[w].alive, waves[w].readers);
                             std::abort();
                         }
                         if (progressed) spins = 0;

@@ -91,6 +91,10 @@ using std::min;
 
 // ---- device intrinsics ---------------------------------------------------------------------------------
 inline void __syncthreads() { hipemu::syncthreads(); }
+inline double rsqrt(double x) { return 1.0 / std::sqrt(x); }
+inline double __builtin_amdgcn_rsq(double x) { return (double)(float)(1.0 / std::sqrt(x)); } // deliberately low precision, like v_rsq_f64
+inline long long clock64() { return (long long)(hipemu::now_ms() * 1e6); }
+inline long long wall_clock64() { return (long long)(hipemu::now_ms() * 1e5); }
 inline void __threadfence() {}
 inline void __threadfence_block() {}
 template <typename T>
@@ -126,6 +130,11 @@ inline T __shfl_up(T v, unsigned delta, int width = 64) {
     int idx = lane - (int)delta;
     if (idx < (lane & ~(width - 1))) idx = lane;
     return all[idx];
+}
+inline int __builtin_amdgcn_readlane(int v, int src) {
+    int all[64];
+    hipemu::wave_exchange(&v, all, sizeof(int));
+    return all[src & 63];
 }
 inline unsigned long long __ballot(int pred) {
     int all[64];
