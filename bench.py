@@ -48,6 +48,45 @@ def build_window(args, preintegrate):
     return synth.make_window(n_frames=n, n_landmarks=m, use_inertial=vio, preintegrate=preintegrate if vio else None), (n, m, vio)
 
 
+def bench_klt(ctx, args, width=512, height=512, n_points=1500, reps=50):
+    """KLT tracks/ms on a TUM-VI-sized synthetic pair (BASELINE.json configs[3]: 512x512, 1500 tracks)."""
+    from pvio_amd import synth
+    from pvio_amd.solver import HipImage, klt_track
+    img0, img1, p, truth, init = synth.make_image_pair(width, height, n_points)
+    t0 = time.perf_counter()
+    A, B = HipImage(ctx, img0), HipImage(ctx, img1)   # upload + CLAHE + pyramid + Scharr on device
+    prep_ms = 1e3 * (time.perf_counter() - t0) / 2
+    for _ in range(5):
+        klt_track(ctx, A, B, p, init)
+    dev_ms, t0 = 0.0, time.perf_counter()
+    for _ in range(reps):
+        q, st, ms = klt_track(ctx, A, B, p, init)
+        dev_ms += ms
+    wall_ms = 1e3 * (time.perf_counter() - t0) / reps
+    dev_ms /= reps
+    alg_bytes = 11616 * n_points  # SURVEY 8(d): 4 levels x (22^2 u8 template + 22^2 x 2 int16 derivatives + 22^2 u8 target)
+    out = {"metric": "KLT tracks/ms", "value": n_points / dev_ms, "unit": "tracks/ms", "value_incl_h2d_d2h": n_points / wall_ms,
+           "workload": "%dx%d u8 pair, %d tracks, win 21x21, 4 levels, <=30 iterations, initial flow given" % (width, height, n_points),
+           "tracked": int(st.sum()), "preprocess_ms_per_image": prep_ms,
+           "roofline": {"bound": "hbm", "kernel": "k_lk_track", "achieved": alg_bytes / (dev_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": alg_bytes / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
+                        "avg_launch_us": dev_ms * 1e3}}
+    if not args.no_cpu_baseline:
+        from oracle import oracle_py as O
+        P0, P1 = O.build_pyramid(O.clahe(img0)), O.build_pyramid(O.clahe(img1))
+        t1, n = time.perf_counter(), 0
+        while time.perf_counter() - t1 < min(args.cpu_seconds, 5.0):
+            O.klt_track(P0, P1, p, init)
+            n += 1
+        cpu_ms = 1e3 * (time.perf_counter() - t1) / n
+        out["cpu_baseline"] = {"value": n_points / cpu_ms, "unit": "tracks/ms", "cores": 1, "kind": "port",
+                               "sample": "%d calls of the scalar restatement of calcOpticalFlowPyrLK on the same pair (OpenCV itself is "
+                                         "parallel_for_ over points)" % n}
+    A.release()
+    B.release()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -57,6 +96,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline sample budget (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-klt", action="store_true")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -151,6 +191,11 @@ def main():
                "sample": "%d solves of the same window (%.1f s), single thread as the reference's num_threads=1 "
                          "(solver_options.h:31); host has %d cores" % (c_n, c_t, os.cpu_count())}
 
+    # ---- KLT leg (second half of BASELINE.json's metric): tracks/ms, pyramids resident, TUM-VI-sized frames ----
+    klt = None
+    if rank == 0 and args.gpus == 1 and not args.no_klt:
+        klt = bench_klt(ctx, args)
+
     if rank == 0:
         value = iters / elapsed
         out = {
@@ -166,6 +211,7 @@ def main():
             "device_ms_per_step": 1e3 * dev_s / args.steps,
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "klt": klt,
         }
         if cpu:
             out["speedup_vs_cpu_baseline"] = value / cpu["value"]

@@ -226,6 +226,9 @@ int32_t pvio_hip_image_download_level(pvio_hip_ctx *ctx, const pvio_hip_image *i
 int32_t pvio_hip_klt_track(pvio_hip_ctx *ctx, const pvio_hip_image *prev, const pvio_hip_image *next,
                            int32_t n, const float *prev_xy, float *next_xy, uint8_t *status);
 
+/* hipEvent duration [ms] of the LK kernel of the last pvio_hip_klt_track call (bench.py: tracks/ms, pyramids resident) */
+double pvio_hip_klt_last_device_ms(const pvio_hip_ctx *ctx);
+
 #ifdef __cplusplus
 }
 #endif

@@ -131,3 +131,65 @@ def reprojection_error(problem, state):
     out = np.zeros(1)
     lib().oracle_ba_reprojection_error(C.byref(pb), C.byref(st), _d(out))
     return out[0]
+
+
+# ---- KLT front end --------------------------------------------------------------------------------------------
+u8p = C.POINTER(C.c_uint8)
+i16p = C.POINTER(C.c_int16)
+f32p = C.POINTER(C.c_float)
+i32p = C.POINTER(C.c_int32)
+
+
+def clahe(img, clip_limit=6.0, tiles=(8, 8)):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape
+    out = np.zeros_like(img)
+    f = lib().oracle_clahe
+    f.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, u8p, C.c_int]
+    f.restype = None
+    f(img.ctypes.data_as(u8p), w, h, w, float(clip_limit), tiles[0], tiles[1], out.ctypes.data_as(u8p), w)
+    return out
+
+
+def build_pyramid(img):
+    """-> list of (u8 image, int16 [h][w][2] Scharr derivative) per level, like buildOpticalFlowPyramid(.., 3, true)."""
+    L = lib()
+    L.oracle_pyr_down.argtypes = [u8p, C.c_int, C.c_int, u8p]
+    L.oracle_pyr_down.restype = None
+    L.oracle_scharr.argtypes = [u8p, C.c_int, C.c_int, i16p]
+    L.oracle_scharr.restype = None
+    L.oracle_pyramid_sizes.argtypes = [C.c_int, C.c_int, i32p, i32p]
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    h, w = img.shape
+    ws, hs = np.zeros(4, np.int32), np.zeros(4, np.int32)
+    n = L.oracle_pyramid_sizes(w, h, ws.ctypes.data_as(i32p), hs.ctypes.data_as(i32p))
+    levels = []
+    cur = img
+    for l in range(n):
+        if l > 0:
+            nxt = np.zeros((hs[l], ws[l]), np.uint8)
+            L.oracle_pyr_down(cur.ctypes.data_as(u8p), int(ws[l - 1]), int(hs[l - 1]), nxt.ctypes.data_as(u8p))
+            cur = nxt
+        d = np.zeros((hs[l], ws[l], 2), np.int16)
+        L.oracle_scharr(cur.ctypes.data_as(u8p), int(ws[l]), int(hs[l]), d.ctypes.data_as(i16p))
+        levels.append((cur, d))
+    return levels
+
+
+def klt_track(prev_levels, next_levels, prev_xy, next_xy_init):
+    L = lib()
+    n_levels = len(prev_levels)
+    ws = np.array([lv[0].shape[1] for lv in prev_levels], np.int32)
+    hs = np.array([lv[0].shape[0] for lv in prev_levels], np.int32)
+    PI = (u8p * n_levels)(*[lv[0].ctypes.data_as(u8p) for lv in prev_levels])
+    PD = (i16p * n_levels)(*[lv[1].ctypes.data_as(i16p) for lv in prev_levels])
+    NI = (u8p * n_levels)(*[lv[0].ctypes.data_as(u8p) for lv in next_levels])
+    prev_xy = np.ascontiguousarray(prev_xy, dtype=np.float32)
+    nxt = np.array(next_xy_init, dtype=np.float32, order="C", copy=True)
+    n = prev_xy.shape[0]
+    status = np.zeros(n, np.uint8)
+    L.oracle_klt_track.argtypes = [C.c_int, i32p, i32p, C.POINTER(u8p), C.POINTER(i16p), C.POINTER(u8p), C.c_int, f32p, f32p, u8p]
+    L.oracle_klt_track.restype = None
+    L.oracle_klt_track(n_levels, ws.ctypes.data_as(i32p), hs.ctypes.data_as(i32p), PI, PD, NI, n, prev_xy.ctypes.data_as(f32p),
+                       nxt.ctypes.data_as(f32p), status.ctypes.data_as(u8p))
+    return nxt, status

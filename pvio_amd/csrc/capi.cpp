@@ -125,4 +125,6 @@ int32_t pvio_hip_klt_track(pvio_hip_ctx *ctx, const pvio_hip_image *prev, const 
     return ctx->klt->track(reinterpret_cast<const pvklt::Image *>(prev), reinterpret_cast<const pvklt::Image *>(next), n, prev_xy, next_xy, status);
 }
 
+double pvio_hip_klt_last_device_ms(const pvio_hip_ctx *ctx) { return ctx ? ctx->klt->last_track_ms() : 0.0; }
+
 } // extern "C"

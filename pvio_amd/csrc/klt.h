@@ -18,10 +18,13 @@ class Klt {
     int download_level(const Image *img, int level, uint8_t *pixels, int16_t *deriv, int32_t *w, int32_t *h);
     int track(const Image *prev, const Image *next, int n, const float *prev_xy, float *next_xy, uint8_t *status);
     const std::string &error() const { return err_; }
+    double last_track_ms() const { return last_ms_; } // hipEvent time of the last k_lk_track launch
 
   private:
     int device_;
     hipStream_t stream_ = nullptr;
+    hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
+    double last_ms_ = 0;
     std::string err_;
     void *d_pts_ = nullptr;
     size_t pts_cap_ = 0;

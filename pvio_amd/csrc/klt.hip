@@ -1,19 +1,447 @@
-// klt.hip -- placeholder until the KLT kernels land (see DESIGN.md roadmap); every entry point fails loudly.
+// klt.hip -- device-resident image front end: CLAHE, 4-level pyramid, Scharr derivatives, pyramidal Lucas-Kanade.
+//
+// Replaces what the reference gets from OpenCV in
+//   OpenCvImage::preprocess       pvio-extra/src/pvio/extra/opencv_image.cpp:138-145  (CLAHE(6.0, 8x8) + buildOpticalFlowPyramid(21x21, 3, true))
+//   OpenCvImage::track_keypoints  opencv_image.cpp:88-109                             (calcOpticalFlowPyrLK + 20-px border kill)
+// The F-matrix RANSAC of :121-129 stays on the host adapter.
+//
+// HBM layout: every pyramid level is stored PADDED by kPad pixels on each side -- pixels with the BORDER_REFLECT_101
+// values OpenCV's pyramid carries, derivatives (int16 x 2, interleaved) with a zero border -- so that the LK kernel
+// never clamps or branches on image boundaries.  Row pitch is a multiple of 64 bytes.
+// LK kernel: one 64-wide wavefront per track; the 21x21 template patch and its derivative patch are built once per
+// level with 14-bit fixed-point bilinear weights (exactly OpenCV's integer arithmetic) and staged in LDS as int16;
+// every iteration each lane resamples ~7 window pixels of the next image and the 2x1 mismatch vector is a wave
+// reduction.  The float accumulators are reduced in a fixed butterfly order (deterministic, but not the scalar
+// left-to-right order of the CPU restatement: positions agree to ~1e-5 px, see tests/test_gpu_klt.py).
 #include "klt.h"
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
 
 #include "../../include/pvio_hip.h"
 
 namespace pvklt {
-struct Image {
-    int w, h;
+
+constexpr int kLevels = 4;   // maxLevel 3
+constexpr int kWin = 21;
+constexpr int kPad = 32;     // >= kWin + 1
+constexpr int kWinPix = kWin * kWin;
+
+struct LevelDesc {
+    int w, h, pitch;         // pitch in pixels (u8) / in int16 pairs (derivative)
+    uint8_t *img;            // (h + 2 kPad) x pitch
+    int16_t *drv;            // (h + 2 kPad) x pitch x 2
 };
-Klt::Klt(int device) : device_(device) {}
-Klt::~Klt() {}
-int Klt::create_image(const uint8_t *, int, int, int, bool, Image **) {
-    err_ = "KLT not built yet";
-    return PVIO_ERR_UNSUPPORTED;
+struct Image {
+    int w, h, n_levels;
+    LevelDesc lv[kLevels];
+    uint8_t *raw;            // unpadded upload buffer (w x h)
+    uint8_t *lut;            // CLAHE LUTs [64][256]
+    void *slab;              // one allocation for everything above
+    size_t slab_bytes;
+};
+
+struct TrackArgs {
+    int n, n_levels;
+    LevelDesc prev[kLevels], next[kLevels];
+    const float *prev_xy;
+    float *next_xy;
+    uint8_t *status;
+};
+
+__device__ __forceinline__ int reflect101(int p, int len) {
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) p = p < 0 ? -p : 2 * (len - 1) - p;
+    return p;
 }
-void Klt::release_image(Image *) {}
-int Klt::download_level(const Image *, int, uint8_t *, int16_t *, int32_t *, int32_t *) { return PVIO_ERR_UNSUPPORTED; }
-int Klt::track(const Image *, const Image *, int, const float *, float *, uint8_t *) { return PVIO_ERR_UNSUPPORTED; }
+
+// ---- CLAHE ----------------------------------------------------------------------------------------------------------
+// one workgroup per tile: histogram (LDS atomics), clip + redistribute, cumulative LUT
+__global__ void __launch_bounds__(256) k_clahe_lut(const uint8_t *src, int w, int h, int tiles_x, int tiles_y, int tw, int th, int clip, uint8_t *lut) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+    __shared__ int hist[256];
+    __shared__ int scan[256];
+    __shared__ int s_clipped;
+    const int tid = threadIdx.x, tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    hist[tid] = 0;
+    if (tid == 0) s_clipped = 0;
+    __syncthreads();
+    for (int i = tid; i < tw * th; i += 256) {
+        const int y = ty * th + i / tw, x = tx * tw + i % tw;
+        atomicAdd(&hist[src[(size_t)reflect101(y, h) * w + reflect101(x, w)]], 1); // padded region = BORDER_REFLECT_101
+    }
+    __syncthreads();
+    int v = hist[tid];
+    if (clip > 0) {
+        if (v > clip) {
+            atomicAdd(&s_clipped, v - clip);
+            v = clip;
+        }
+        __syncthreads();
+        const int clipped = s_clipped, batch = clipped / 256, residual = clipped - batch * 256;
+        v += batch;
+        if (residual != 0) {
+            int step = 256 / residual;
+            if (step < 1) step = 1;
+            if (tid % step == 0 && tid / step < residual) v += 1; // bins 0, step, 2 step, ... (residual of them)
+        }
+    }
+    scan[tid] = v;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) { // inclusive scan
+        const int add = tid >= off ? scan[tid - off] : 0;
+        __syncthreads();
+        scan[tid] += add;
+        __syncthreads();
+    }
+    const float lut_scale = 255.0f / (float)(tw * th);
+    int r = (int)rintf((float)scan[tid] * lut_scale);
+    lut[(size_t)blockIdx.x * 256 + tid] = (uint8_t)(r < 0 ? 0 : r > 255 ? 255 : r);
+}
+
+__global__ void k_clahe_apply(const uint8_t *src, int w, int h, int tiles_x, int tiles_y, int tw, int th, const uint8_t *lut, LevelDesc out) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w || y >= h) return;
+    const float inv_tw = 1.0f / (float)tw, inv_th = 1.0f / (float)th;
+    const float tyf = (float)y * inv_th - 0.5f, txf = (float)x * inv_tw - 0.5f;
+    int ty1 = (int)floorf(tyf), tx1 = (int)floorf(txf);
+    int ty2 = ty1 + 1, tx2 = tx1 + 1;
+    const float ya = tyf - (float)ty1, ya1 = 1.0f - ya, xa = txf - (float)tx1, xa1 = 1.0f - xa;
+    ty1 = max(ty1, 0), tx1 = max(tx1, 0), ty2 = min(ty2, tiles_y - 1), tx2 = min(tx2, tiles_x - 1);
+    const int v = src[(size_t)y * w + x];
+    const uint8_t *p1 = lut + (size_t)(ty1 * tiles_x) * 256, *p2 = lut + (size_t)(ty2 * tiles_x) * 256;
+    const int i1 = tx1 * 256 + v, i2 = tx2 * 256 + v;
+    const float res = ((float)p1[i1] * xa1 + (float)p1[i2] * xa) * ya1 + ((float)p2[i1] * xa1 + (float)p2[i2] * xa) * ya;
+    const int r = (int)rintf(res);
+    out.img[(size_t)(y + kPad) * out.pitch + x + kPad] = (uint8_t)(r < 0 ? 0 : r > 255 ? 255 : r);
+}
+
+__global__ void k_copy_level0(const uint8_t *src, int w, int h, LevelDesc out) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x < w && y < h) out.img[(size_t)(y + kPad) * out.pitch + x + kPad] = src[(size_t)y * w + x];
+}
+
+// BORDER_REFLECT_101 ring of kPad pixels around the interior
+__global__ void k_border(LevelDesc lv) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x - kPad, y = (int)blockIdx.y - kPad;
+    if (x >= lv.w + kPad || y >= lv.h + kPad) return;
+    if (x >= 0 && x < lv.w && y >= 0 && y < lv.h) return;
+    lv.img[(size_t)(y + kPad) * lv.pitch + x + kPad] = lv.img[(size_t)(reflect101(y, lv.h) + kPad) * lv.pitch + reflect101(x, lv.w) + kPad];
+}
+
+// calcSharrDeriv: dx = [3 10 3]^T (x) [-1 0 1], dy = [-1 0 1]^T (x) [3 10 3]; the reflected border of the image supplies
+// exactly the BORDER_REFLECT_101 neighbours the reference uses
+__global__ void k_scharr(LevelDesc lv) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= lv.w || y >= lv.h) return;
+    const uint8_t *c = lv.img + (size_t)(y + kPad) * lv.pitch + x + kPad;
+    const int p = lv.pitch;
+    const int a00 = c[-p - 1], a01 = c[-p], a02 = c[-p + 1], a10 = c[-1], a12 = c[1], a20 = c[p - 1], a21 = c[p], a22 = c[p + 1];
+    const int dx = ((a02 + a22) * 3 + a12 * 10) - ((a00 + a20) * 3 + a10 * 10);
+    const int dy = ((a20 + a22) * 3 + a21 * 10) - ((a00 + a02) * 3 + a01 * 10);
+    int16_t *d = lv.drv + 2 * ((size_t)(y + kPad) * lv.pitch + x + kPad);
+    d[0] = (int16_t)dx, d[1] = (int16_t)dy;
+}
+
+// cv::pyrDown: [1 4 6 4 1] x [1 4 6 4 1], (sum + 128) >> 8
+__global__ void k_pyr_down(LevelDesc src, LevelDesc dst) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= dst.w || y >= dst.h) return;
+    const uint8_t *c = src.img + (size_t)(2 * y + kPad) * src.pitch + 2 * x + kPad;
+    int sum = 0;
+#pragma unroll
+    for (int j = -2; j <= 2; ++j) {
+        const uint8_t *r = c + (ptrdiff_t)j * src.pitch;
+        const int rs = r[-2] + 4 * r[-1] + 6 * r[0] + 4 * r[1] + r[2];
+        sum += (j == 0 ? 6 : (j == -1 || j == 1) ? 4 : 1) * rs;
+    }
+    dst.img[(size_t)(y + kPad) * dst.pitch + x + kPad] = (uint8_t)((sum + 128) >> 8);
+}
+
+// ---- pyramidal LK: one wavefront per track --------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__global__ void __launch_bounds__(256) k_lk_track(TrackArgs a) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+    __shared__ int16_t s_I[4][kWinPix];
+    __shared__ int16_t s_dI[4][kWinPix * 2];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int p = blockIdx.x * 4 + wv;
+    if (p >= a.n) return; // whole wave exits together
+    int16_t *Iw = s_I[wv], *dIw = s_dI[wv];
+    const float half = (kWin - 1) * 0.5f, FLT_SCALE = 1.f / (1 << 20);
+    const int W_BITS = 14;
+    const float pxf = a.prev_xy[2 * p], pyf = a.prev_xy[2 * p + 1];
+    float outx = a.next_xy[2 * p], outy = a.next_xy[2 * p + 1];
+    int st = 1;
+    for (int level = a.n_levels - 1; level >= 0; --level) {
+        const LevelDesc I = a.prev[level], J = a.next[level];
+        const float sc = (float)(1. / (1 << level));
+        float px = pxf * sc, py = pyf * sc, nx, ny;
+        if (level == a.n_levels - 1) nx = outx * sc, ny = outy * sc; // OPTFLOW_USE_INITIAL_FLOW
+        else nx = outx * 2.f, ny = outy * 2.f;
+        outx = nx, outy = ny;
+        px -= half, py -= half;
+        const int ipx = (int)floorf(px), ipy = (int)floorf(py);
+        if (ipx < -kWin || ipx >= I.w || ipy < -kWin || ipy >= I.h) {
+            if (level == 0) st = 0;
+            continue;
+        }
+        float fa = px - (float)ipx, fb = py - (float)ipy;
+        int iw00 = (int)rintf((1.f - fa) * (1.f - fb) * (float)(1 << W_BITS));
+        int iw01 = (int)rintf(fa * (1.f - fb) * (float)(1 << W_BITS));
+        int iw10 = (int)rintf((1.f - fa) * fb * (float)(1 << W_BITS));
+        int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+        float sA11 = 0, sA12 = 0, sA22 = 0;
+        for (int i = lane; i < kWinPix; i += 64) {
+            const int y = i / kWin, x = i - y * kWin;
+            const size_t o = (size_t)(ipy + y + kPad) * I.pitch + (ipx + x + kPad);
+            const uint8_t *s = I.img + o;
+            const int16_t *d = I.drv + 2 * o;
+            const int ival = (s[0] * iw00 + s[1] * iw01 + s[I.pitch] * iw10 + s[I.pitch + 1] * iw11 + (1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
+            const int ixval = (d[0] * iw00 + d[2] * iw01 + d[2 * I.pitch] * iw10 + d[2 * I.pitch + 2] * iw11 + (1 << (W_BITS - 1))) >> W_BITS;
+            const int iyval = (d[1] * iw00 + d[3] * iw01 + d[2 * I.pitch + 1] * iw10 + d[2 * I.pitch + 3] * iw11 + (1 << (W_BITS - 1))) >> W_BITS;
+            Iw[i] = (int16_t)ival, dIw[2 * i] = (int16_t)ixval, dIw[2 * i + 1] = (int16_t)iyval;
+            sA11 += (float)(ixval * ixval), sA12 += (float)(ixval * iyval), sA22 += (float)(iyval * iyval);
+        }
+        const float A11 = wave_sum_f(sA11) * FLT_SCALE, A12 = wave_sum_f(sA12) * FLT_SCALE, A22 = wave_sum_f(sA22) * FLT_SCALE;
+        float D = A11 * A22 - A12 * A12;
+        const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * kWin * kWin);
+        if (minEig < 1e-4f || D < 1.1920929e-07f) {
+            if (level == 0) st = 0;
+            continue;
+        }
+        D = 1.f / D;
+        nx -= half, ny -= half;
+        float pdx = 0, pdy = 0;
+        for (int j = 0; j < 30; ++j) {
+            const int inx = (int)floorf(nx), iny = (int)floorf(ny);
+            if (inx < -kWin || inx >= J.w || iny < -kWin || iny >= J.h) {
+                if (level == 0) st = 0;
+                break;
+            }
+            fa = nx - (float)inx, fb = ny - (float)iny;
+            iw00 = (int)rintf((1.f - fa) * (1.f - fb) * (float)(1 << W_BITS));
+            iw01 = (int)rintf(fa * (1.f - fb) * (float)(1 << W_BITS));
+            iw10 = (int)rintf((1.f - fa) * fb * (float)(1 << W_BITS));
+            iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+            float sb1 = 0, sb2 = 0;
+            for (int i = lane; i < kWinPix; i += 64) {
+                const int y = i / kWin, x = i - y * kWin;
+                const uint8_t *s = J.img + (size_t)(iny + y + kPad) * J.pitch + (inx + x + kPad);
+                const int diff = ((s[0] * iw00 + s[1] * iw01 + s[J.pitch] * iw10 + s[J.pitch + 1] * iw11 + (1 << (W_BITS - 5 - 1))) >> (W_BITS - 5)) - Iw[i];
+                sb1 += (float)(diff * dIw[2 * i]), sb2 += (float)(diff * dIw[2 * i + 1]);
+            }
+            const float b1 = wave_sum_f(sb1) * FLT_SCALE, b2 = wave_sum_f(sb2) * FLT_SCALE;
+            const float dx = (A12 * b2 - A22 * b1) * D, dy = (A12 * b1 - A11 * b2) * D;
+            nx += dx, ny += dy;
+            outx = nx + half, outy = ny + half;
+            if (dx * dx + dy * dy <= 0.01f * 0.01f) break;
+            if (j > 0 && fabsf(dx + pdx) < 0.01f && fabsf(dy + pdy) < 0.01f) {
+                outx -= dx * 0.5f, outy -= dy * 0.5f;
+                break;
+            }
+            pdx = dx, pdy = dy;
+        }
+        if (st && level == 0) {
+            const int ix = (int)floorf(outx - half), iy = (int)floorf(outy - half);
+            if (ix < -kWin || ix >= J.w || iy < -kWin || iy >= J.h) st = 0;
+        }
+    }
+    // opencv_image.cpp:104-109: 20-px border of the full-resolution image
+    if (outx < 20 || outx >= (float)(a.prev[0].w - 20) || outy < 20 || outy >= (float)(a.prev[0].h - 20)) st = 0;
+    if (lane == 0) {
+        a.next_xy[2 * p] = outx, a.next_xy[2 * p + 1] = outy;
+        a.status[p] = (uint8_t)st;
+    }
+}
+
+// ---- host -----------------------------------------------------------------------------------------------------------
+static int level_sizes(int w, int h, int *ws, int *hs) {
+    int n = 0;
+    for (int l = 0; l < kLevels; ++l) {
+        if (l > 0) {
+            w = (w + 1) / 2, h = (h + 1) / 2;
+            if (w <= kWin || h <= kWin) break; // buildOpticalFlowPyramid stops when a level is not larger than the window
+        }
+        ws[n] = w, hs[n] = h, ++n;
+    }
+    return n;
+}
+
+Klt::Klt(int device) : device_(device) {
+    (void)hipSetDevice(device_);
+    (void)hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking);
+    (void)hipEventCreate(&ev0_);
+    (void)hipEventCreate(&ev1_);
+}
+Klt::~Klt() {
+    if (d_pts_) (void)hipFree(d_pts_);
+    if (ev0_) (void)hipEventDestroy(ev0_);
+    if (ev1_) (void)hipEventDestroy(ev1_);
+    if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+int Klt::create_image(const uint8_t *pixels, int w, int h, int stride, bool clahe, Image **out) {
+    if (w < 2 * kWin || h < 2 * kWin || stride < w) {
+        err_ = "image too small / bad stride";
+        return PVIO_ERR_INVALID_ARGUMENT;
+    }
+    (void)hipSetDevice(device_);
+    Image *im = new Image();
+    std::memset(im, 0, sizeof *im);
+    im->w = w, im->h = h;
+    int ws[kLevels], hs[kLevels];
+    im->n_levels = level_sizes(w, h, ws, hs);
+    size_t off = 0;
+    auto carve = [&](size_t bytes) {
+        size_t o = off;
+        off += (bytes + 255) & ~(size_t)255;
+        return o;
+    };
+    size_t o_raw = carve((size_t)w * h), o_lut = carve(64 * 256), o_img[kLevels], o_drv[kLevels];
+    for (int l = 0; l < im->n_levels; ++l) {
+        im->lv[l].w = ws[l], im->lv[l].h = hs[l];
+        im->lv[l].pitch = (ws[l] + 2 * kPad + 63) & ~63;
+        o_img[l] = carve((size_t)(hs[l] + 2 * kPad) * im->lv[l].pitch);
+        o_drv[l] = carve((size_t)(hs[l] + 2 * kPad) * im->lv[l].pitch * 4);
+    }
+    im->slab_bytes = off;
+    if (hipMalloc(&im->slab, off) != hipSuccess) {
+        delete im;
+        err_ = "hipMalloc failed";
+        return PVIO_ERR_OUT_OF_MEMORY;
+    }
+    char *base = static_cast<char *>(im->slab);
+    im->raw = reinterpret_cast<uint8_t *>(base + o_raw);
+    im->lut = reinterpret_cast<uint8_t *>(base + o_lut);
+    for (int l = 0; l < im->n_levels; ++l) {
+        im->lv[l].img = reinterpret_cast<uint8_t *>(base + o_img[l]);
+        im->lv[l].drv = reinterpret_cast<int16_t *>(base + o_drv[l]);
+    }
+    // derivative borders are BORDER_CONSTANT zeros; image borders are written by k_border
+    (void)hipMemsetAsync(im->slab, 0, off, stream_);
+    std::vector<uint8_t> packed;
+    const uint8_t *src = pixels;
+    if (stride != w) {
+        packed.resize((size_t)w * h);
+        for (int y = 0; y < h; ++y) std::memcpy(&packed[(size_t)y * w], pixels + (size_t)y * stride, w);
+        src = packed.data();
+    }
+    if (hipMemcpyAsync(im->raw, src, (size_t)w * h, hipMemcpyHostToDevice, stream_) != hipSuccess) {
+        release_image(im);
+        err_ = "H2D failed";
+        return PVIO_ERR_HIP;
+    }
+    const dim3 blk(256);
+    if (clahe) {
+        const int tiles = 8;
+        int ew = w, eh = h;
+        if (w % tiles != 0 || h % tiles != 0) ew = w + (tiles - w % tiles), eh = h + (tiles - h % tiles);
+        const int tw = ew / tiles, th = eh / tiles;
+        int clip = (int)(6.0 * (tw * th) / 256);
+        if (clip < 1) clip = 1;
+        hipLaunchKernelGGL(k_clahe_lut, dim3(tiles * tiles), blk, 0, stream_, (const uint8_t *)im->raw, w, h, tiles, tiles, tw, th, clip, im->lut);
+        hipLaunchKernelGGL(k_clahe_apply, dim3((w + 255) / 256, h), blk, 0, stream_, (const uint8_t *)im->raw, w, h, tiles, tiles, tw, th,
+                           (const uint8_t *)im->lut, im->lv[0]);
+    } else {
+        hipLaunchKernelGGL(k_copy_level0, dim3((w + 255) / 256, h), blk, 0, stream_, (const uint8_t *)im->raw, w, h, im->lv[0]);
+    }
+    for (int l = 0; l < im->n_levels; ++l) {
+        const LevelDesc &L = im->lv[l];
+        hipLaunchKernelGGL(k_border, dim3((L.w + 2 * kPad + 255) / 256, L.h + 2 * kPad), blk, 0, stream_, L);
+        hipLaunchKernelGGL(k_scharr, dim3((L.w + 255) / 256, L.h), blk, 0, stream_, L);
+        if (l + 1 < im->n_levels) hipLaunchKernelGGL(k_pyr_down, dim3((im->lv[l + 1].w + 255) / 256, im->lv[l + 1].h), blk, 0, stream_, L, im->lv[l + 1]);
+    }
+    if (hipStreamSynchronize(stream_) != hipSuccess || hipGetLastError() != hipSuccess) {
+        release_image(im);
+        err_ = "pyramid kernels failed";
+        return PVIO_ERR_HIP;
+    }
+    *out = im;
+    return PVIO_OK;
+}
+
+void Klt::release_image(Image *img) {
+    if (!img) return;
+    if (img->slab) (void)hipFree(img->slab);
+    delete img;
+}
+
+int Klt::download_level(const Image *img, int level, uint8_t *pixels, int16_t *deriv, int32_t *w, int32_t *h) {
+    if (level < 0 || level >= img->n_levels) return PVIO_ERR_INVALID_ARGUMENT;
+    const LevelDesc &L = img->lv[level];
+    if (w) *w = L.w;
+    if (h) *h = L.h;
+    std::vector<uint8_t> hp;
+    std::vector<int16_t> hd;
+    const size_t rows = L.h + 2 * kPad;
+    if (pixels) {
+        hp.resize(rows * L.pitch);
+        if (hipMemcpy(hp.data(), L.img, hp.size(), hipMemcpyDeviceToHost) != hipSuccess) return PVIO_ERR_HIP;
+        for (int y = 0; y < L.h; ++y) std::memcpy(pixels + (size_t)y * L.w, &hp[(size_t)(y + kPad) * L.pitch + kPad], L.w);
+    }
+    if (deriv) {
+        hd.resize(rows * L.pitch * 2);
+        if (hipMemcpy(hd.data(), L.drv, hd.size() * 2, hipMemcpyDeviceToHost) != hipSuccess) return PVIO_ERR_HIP;
+        for (int y = 0; y < L.h; ++y) std::memcpy(deriv + (size_t)y * L.w * 2, &hd[2 * ((size_t)(y + kPad) * L.pitch + kPad)], (size_t)L.w * 4);
+    }
+    return PVIO_OK;
+}
+
+int Klt::track(const Image *prev, const Image *next, int n, const float *prev_xy, float *next_xy, uint8_t *status) {
+    if (prev->w != next->w || prev->h != next->h) {
+        err_ = "image sizes differ";
+        return PVIO_ERR_INVALID_ARGUMENT;
+    }
+    last_ms_ = 0;
+    if (n == 0) return PVIO_OK;
+    (void)hipSetDevice(device_);
+    const size_t need = (size_t)n * (2 * sizeof(float) * 2 + 1) + 64;
+    if (need > pts_cap_) {
+        if (d_pts_) (void)hipFree(d_pts_);
+        d_pts_ = nullptr;
+        if (hipMalloc(&d_pts_, need * 2) != hipSuccess) {
+            pts_cap_ = 0;
+            err_ = "hipMalloc failed";
+            return PVIO_ERR_OUT_OF_MEMORY;
+        }
+        pts_cap_ = need * 2;
+    }
+    float *d_prev = static_cast<float *>(d_pts_), *d_next = d_prev + 2 * (size_t)n;
+    uint8_t *d_st = reinterpret_cast<uint8_t *>(d_next + 2 * (size_t)n);
+    TrackArgs a;
+    a.n = n, a.n_levels = std::min(prev->n_levels, next->n_levels);
+    for (int l = 0; l < a.n_levels; ++l) a.prev[l] = prev->lv[l], a.next[l] = next->lv[l];
+    a.prev_xy = d_prev, a.next_xy = d_next, a.status = d_st;
+    bool ok = hipMemcpyAsync(d_prev, prev_xy, (size_t)n * 8, hipMemcpyHostToDevice, stream_) == hipSuccess;
+    ok = ok && hipMemcpyAsync(d_next, next_xy, (size_t)n * 8, hipMemcpyHostToDevice, stream_) == hipSuccess;
+    (void)hipEventRecord(ev0_, stream_);
+    hipLaunchKernelGGL(k_lk_track, dim3((n + 3) / 4), dim3(256), 0, stream_, a);
+    (void)hipEventRecord(ev1_, stream_);
+    ok = ok && hipMemcpyAsync(next_xy, d_next, (size_t)n * 8, hipMemcpyDeviceToHost, stream_) == hipSuccess;
+    ok = ok && hipMemcpyAsync(status, d_st, (size_t)n, hipMemcpyDeviceToHost, stream_) == hipSuccess;
+    ok = ok && hipStreamSynchronize(stream_) == hipSuccess && hipGetLastError() == hipSuccess;
+    if (!ok) {
+        err_ = "klt track failed";
+        return PVIO_ERR_HIP;
+    }
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, ev0_, ev1_);
+    last_ms_ = ms;
+    return PVIO_OK;
+}
+
 } // namespace pvklt

@@ -93,6 +93,42 @@ class HipContext:
         return S, s, IM, iv
 
 
+class HipImage:
+    """Device-resident CLAHE'd pyramid (pvio_hip_image_create); mirrors OpenCvImage::preprocess."""
+
+    def __init__(self, ctx, pixels, clahe=True):
+        self.ctx = ctx
+        px = np.ascontiguousarray(pixels, dtype=np.uint8)
+        self.h, self.w = px.shape
+        self.handle = C.c_void_p()
+        ctx._check(ctx.lib.pvio_hip_image_create(ctx.ctx, px.ctypes.data_as(capi.c_uint8_p), self.w, self.h, self.w, int(clahe), C.byref(self.handle)),
+                   "pvio_hip_image_create")
+
+    def level(self, l):
+        w, h = C.c_int32(0), C.c_int32(0)
+        self.ctx._check(self.ctx.lib.pvio_hip_image_download_level(self.ctx.ctx, self.handle, l, None, None, C.byref(w), C.byref(h)), "download_level")
+        img = np.zeros((h.value, w.value), np.uint8)
+        drv = np.zeros((h.value, w.value, 2), np.int16)
+        self.ctx._check(self.ctx.lib.pvio_hip_image_download_level(self.ctx.ctx, self.handle, l, img.ctypes.data_as(capi.c_uint8_p),
+                                                                 drv.ctypes.data_as(capi.c_int16_p), C.byref(w), C.byref(h)), "download_level")
+        return img, drv
+
+    def release(self):
+        if self.handle:
+            self.ctx.lib.pvio_hip_image_release(self.ctx.ctx, self.handle)
+            self.handle = C.c_void_p()
+
+
+def klt_track(ctx, prev, nxt, prev_xy, next_xy_init):
+    """pvio_hip_klt_track: returns (next_xy, status, device_ms); mirrors OpenCvImage::track_keypoints up to the border kill."""
+    p = np.ascontiguousarray(prev_xy, dtype=np.float32)
+    q = np.array(next_xy_init, dtype=np.float32, order="C", copy=True)
+    st = np.zeros(p.shape[0], np.uint8)
+    ctx._check(ctx.lib.pvio_hip_klt_track(ctx.ctx, prev.handle, nxt.handle, p.shape[0], p.ctypes.data_as(capi.c_float_p), q.ctypes.data_as(capi.c_float_p),
+                                          st.ctypes.data_as(capi.c_uint8_p)), "pvio_hip_klt_track")
+    return q, st, ctx.lib.pvio_hip_klt_last_device_ms(ctx.ctx)
+
+
 def preintegrate(t, w, a, t_end, bg, ba, noise, lib=None):
     """Product host-side pre-integration (pvio_preintegrate); same signature as oracle_py.preintegrate."""
     lib = lib or capi.load()

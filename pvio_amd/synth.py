@@ -287,3 +287,56 @@ def algorithmic_bytes_per_iteration(pb):
     d = 15 if pb.use_inertial else 6
     F, M, N = pb.n_obs, pb.n_landmarks, pb.n_frames
     return 2 * (20 * F + 32 * M) + 8 * M + 8 * (d * N) ** 2
+
+
+# ---- synthetic KLT inputs ---------------------------------------------------------------------------
+def make_image_pair(width=752, height=480, n_points=1500, seed=SEED, max_motion=6.0, gain=1.05, noise_sigma=2.0):
+    """Band-limited random texture (64 random-phase sinusoids + noise), second image = first warped by a known
+    homography (<= max_motion px) with a brightness gain.  Returns img0, img1 (u8), prev_xy, truth_xy, init_xy (float32):
+    points on a jittered grid >= 20 px from the borders; init = truth + U(-2, 2) px (mimics the gyro prediction,
+    frame.cpp:97-103)."""
+    rng = Rng(seed + 17)
+    K = 64
+    fx = (rng.uniform(K) - 0.5) * 0.9
+    fy = (rng.uniform(K) - 0.5) * 0.9
+    ph = rng.uniform(K) * 2 * np.pi
+    amp = 0.5 + rng.uniform(K)
+    ys, xs = np.mgrid[0:height, 0:width].astype(np.float64)
+
+    def tex(x, y):
+        acc = np.zeros_like(x)
+        for k in range(K):
+            acc += amp[k] * np.cos(fx[k] * x + fy[k] * y + ph[k])
+        return 128.0 + acc * (90.0 / np.sqrt(K))
+
+    # homography: small rotation + translation + perspective, pixel motion bounded by max_motion
+    cx, cy = width / 2.0, height / 2.0
+    ang, tx, ty, p1, p2 = 0.006, 2.5, -1.8, 2e-6, -1.5e-6
+    H = np.array([[np.cos(ang), -np.sin(ang), tx], [np.sin(ang), np.cos(ang), ty], [p1, p2, 1.0]])
+    T = np.array([[1, 0, -cx], [0, 1, -cy], [0, 0, 1.0]])
+    H = np.linalg.inv(T) @ H @ T
+    Hi = np.linalg.inv(H)
+
+    def warp(M, x, y):
+        d = M[2, 0] * x + M[2, 1] * y + M[2, 2]
+        return (M[0, 0] * x + M[0, 1] * y + M[0, 2]) / d, (M[1, 0] * x + M[1, 1] * y + M[1, 2]) / d
+
+    n0 = rng.normal(width * height).reshape(height, width) * noise_sigma
+    n1 = rng.normal(width * height).reshape(height, width) * noise_sigma
+    img0 = np.clip(np.rint(tex(xs, ys) + n0), 0, 255).astype(np.uint8)
+    sx, sy = warp(Hi, xs, ys)  # content of image 1 at (x, y) comes from image 0 at H^-1 (x, y)
+    img1 = np.clip(np.rint(gain * tex(sx, sy) + n1), 0, 255).astype(np.uint8)
+    # jittered grid
+    gx = int(np.ceil(np.sqrt(n_points * width / height)))
+    gy = int(np.ceil(n_points / gx))
+    m = 30.0
+    px = m + (np.arange(gx) + 0.5) * (width - 2 * m) / gx
+    py = m + (np.arange(gy) + 0.5) * (height - 2 * m) / gy
+    PX, PY = np.meshgrid(px, py)
+    pts = np.stack([PX.ravel(), PY.ravel()], 1)[:n_points]
+    pts += (rng.uniform(2 * n_points).reshape(n_points, 2) - 0.5) * 4.0
+    tx_, ty_ = warp(H, pts[:, 0], pts[:, 1])
+    truth = np.stack([tx_, ty_], 1)
+    assert np.abs(truth - pts).max() <= max_motion
+    init = truth + (rng.uniform(2 * n_points).reshape(n_points, 2) - 0.5) * 4.0
+    return img0, img1, pts.astype(np.float32), truth.astype(np.float32), init.astype(np.float32)
