@@ -192,7 +192,7 @@ __device__ void lin_prologue(const View &v, double *lds, Pro *&pro_out) {
         if (tid == 0 && blockIdx.x == 0) {
             Ctrl *cw = v.ctrl;
             cw->cand_step2_pose = step2, cw->cand_norm2_pose = norm2;
-            cw->lin_result = !pro->valid ? LIN_INVALID_STEP : (mode == MODE_INIT ? LIN_INIT : (mode == MODE_CANDIDATE ? LIN_CANDIDATE : LIN_RELIN));
+            cw->lin_result = !pro->valid ? LIN_INVALID_STEP : (mode == MODE_INIT || mode == MODE_MARG ? LIN_INIT : (mode == MODE_CANDIDATE ? LIN_CANDIDATE : LIN_RELIN));
         }
     }
     __syncthreads();
@@ -216,7 +216,10 @@ __device__ void role_landmarks(const View &v, double *lds, const Pro *pro, int w
     const int rec = lm_rec_doubles(N), slots = v.dm.lm_slots;
     double *rho_eval = chunk + (size_t)slots * rec; // [slots]
     int *anch = reinterpret_cast<int *>(rho_eval + slots);
+    int *active = anch + slots + (slots & 1);
     const int mode = pro->mode, cur = pro->cur, lin = pro->lin, oset = pro->out_set;
+    const bool marg = mode == MODE_MARG;
+    const int victim = v.ctrl->marg_victim;
     const double mu = pro->mu_schur, ca = pro->ca, cb = pro->cb;
     const size_t Ms = (size_t)M, Fs = (size_t)v.dm.F;
     double *o_Hll = v.Hll + oset * Ms, *o_bl = v.bl + oset * Ms, *o_Dl = v.Dl + oset * Ms, *o_ghl = v.ghl + oset * Ms;
@@ -258,11 +261,17 @@ __device__ void role_landmarks(const View &v, double *lds, const Pro *pro, int w
             if (used) s_norm2 += r * r;
             rho_eval[tid] = r;
             anch[tid] = v.lm_anchor[l];
+            int act = 1;
+            if (marg) { // bundle_adjustor.cpp:455-461: only tracks the victim frame observes
+                act = v.lm_anchor[l] == victim;
+                for (int o = v.lm_ptr[l]; o < v.lm_ptr[l + 1]; ++o) act |= v.obs_frame[o] == victim;
+            }
+            active[tid] = act;
         }
         __syncthreads();
         PV_STAMP(0, 3);
         // ---- phase 1: one thread per reprojection factor ----
-        if (tid < nf) {
+        if (tid < nf && active[v.obs_lm[o0 + tid] - l0]) {
             const int o = o0 + tid, l = v.obs_lm[o], s = l - l0, t = v.obs_frame[o], a = anch[s];
             double r[2], Jt[12], Jr[12], Jd[2];
             reproj_eval<true>(frec + t * kFrameRec, frec + a * kFrameRec, rho_eval[s], v.lm_zref[2 * l], v.lm_zref[2 * l + 1],
@@ -270,8 +279,9 @@ __device__ void role_landmarks(const View &v, double *lds, const Pro *pro, int w
             const double sq = r[0] * r[0] + r[1] * r[1];
             s_cost += 0.5 * log(1.0 + sq);                                  // CauchyLoss(1): rho(s) = log(1 + s)
             double bad = isfinite(sq) ? 0.0 : 1.0;
-            const double sw = sqrt(fmax(DBL_MIN, 1.0 / (1.0 + sq)));         // Corrector, rho'' < 0: sqrt(rho')
-            const bool tfix = v.frame_fixed[t] != 0, afix = v.frame_fixed[a] != 0;
+            // Corrector, rho'' < 0: sqrt(rho'); marginalization uses the un-robustified Jacobians (:487-510) of ALL blocks
+            const double sw = marg ? 1.0 : sqrt(fmax(DBL_MIN, 1.0 / (1.0 + sq)));
+            const bool tfix = !marg && v.frame_fixed[t] != 0, afix = !marg && v.frame_fixed[a] != 0;
             r[0] *= sw, r[1] *= sw, Jd[0] *= sw, Jd[1] *= sw;
 #pragma unroll
             for (int k = 0; k < 12; ++k) {
@@ -340,7 +350,9 @@ __device__ void role_landmarks(const View &v, double *lds, const Pro *pro, int w
             const double Hll = SC[3], b = SC[1];
             const bool used = v.lm_ptr[l + 1] > v.lm_ptr[l];
             double cl;
-            if (mode == MODE_INIT) {
+            if (marg) {
+                cl = 1.0;
+            } else if (mode == MODE_INIT) {
                 cl = used ? 1.0 / (1.0 + sqrt(Hll)) : 1.0; // jacobi_scaling, computed once (iteration 0)
                 v.cl[l] = cl;
             } else {
@@ -351,6 +363,10 @@ __device__ void role_landmarks(const View &v, double *lds, const Pro *pro, int w
             const double gh = cl * b / Dl;
             const double A = d2 + mu * Dl * Dl;                     // e-block: E^T E + mu D^2
             SC[0] = used ? cl * cl / A : 0.0;                       // Schur weight on the UNscaled W rows
+            if (marg) { // scalar inverse of the landmark block, skipped when not finite (:537-538)
+                const double inv = 1.0 / Hll;
+                SC[0] = (active[tid] && isfinite(inv)) ? inv : 0.0;
+            }
             o_Hll[l] = Hll, o_bl[l] = b, o_Dl[l] = Dl, o_ghl[l] = used ? gh : 0.0;
             if (used) {
                 s_g2 += gh * gh;
@@ -520,7 +536,7 @@ __device__ void role_preint(const View &v, double *lds, const Pro *pro, int j) {
         // live bias read: the accepted linearization keeps the biases it was evaluated with (RELIN must reuse them)
         const double *b0 = (pro->mode == MODE_RELIN) ? v.bias0_lin + 6 * i : v.fs_user + 16 * i + 10;
         preint_raw(est + 16 * i, est + 16 * j, b0, v.pre_delta + 11 * j, v.pre_jac + 45 * j, v.imu_ext + 7 * i, v.imu_ext + 7 * j, raw, G);
-        const bool fi = v.frame_fixed[i] != 0, fj = v.frame_fixed[j] != 0;
+        const bool fi = pro->mode != MODE_MARG && v.frame_fixed[i] != 0, fj = pro->mode != MODE_MARG && v.frame_fixed[j] != 0;
         for (int row = 0; row < 15; ++row)
             for (int c = 0; c < 6; ++c) {
                 if (fi) G[row * 30 + c] = 0.0;
@@ -598,7 +614,7 @@ __device__ void role_prior(const View &v, double *lds, const Pro *pro, int b, in
                 g = rr[a];
             }
             const int fr = v.prior_frames[i];
-            if (k < 6 && v.frame_fixed[fr]) g = 0.0;
+            if (k < 6 && v.frame_fixed[fr] && pro->mode != MODE_MARG) g = 0.0;
             v.prior_g[a] = g;
         }
     }
@@ -619,9 +635,17 @@ __device__ void role_prior(const View &v, double *lds, const Pro *pro, int b, in
         } else {
             h = v.prior_Lambda[(size_t)a * D + c];
         }
-        if ((ka < 6 && v.frame_fixed[v.prior_frames[ia]]) || (kc < 6 && v.frame_fixed[v.prior_frames[ic]])) h = 0.0;
+        if (pro->mode != MODE_MARG && ((ka < 6 && v.frame_fixed[v.prior_frames[ia]]) || (kc < 6 && v.frame_fixed[v.prior_frames[ic]]))) h = 0.0;
         v.prior_H[(size_t)a * D + c] = h;
     }
+}
+
+// a plane workgroup that has nothing to do in this mode still owns a partial row k_reduce will sum
+__device__ void zero_partial_row(const View &v, int row) {
+    const size_t nS = (size_t)v.dm.n_tasks * 9, nV = (size_t)kNumPoseVec * v.dm.P6;
+    for (size_t e = threadIdx.x; e < nS; e += kLinThreads) v.part_S[(size_t)row * nS + e] = 0.0;
+    for (size_t e = threadIdx.x; e < nV; e += kLinThreads) v.part_vec[(size_t)row * nV + e] = 0.0;
+    if (threadIdx.x < kNumLinScal) v.part_scal[(size_t)row * kNumLinScal + threadIdx.x] = 0.0;
 }
 
 template <int T>
@@ -636,10 +660,14 @@ __global__ void __launch_bounds__(kLinThreads) k_linearize(View v) {
     if (!pro->valid) return; // invalid trust-region step: k_dense handles it (HandleInvalidStep)
     const int b = blockIdx.x, g0 = v.dm.G_lm, g1 = g0 + v.dm.G_plane, g2 = g1 + v.dm.G_pre;
     if (b < g0) role_landmarks<T>(v, lds, pro, b, g0);
-    else if (b < g1) role_planes<T>(v, lds, pro, b - g0, v.dm.G_plane, b);
+    else if (b < g1) {
+        if (pro->mode != MODE_MARG) role_planes<T>(v, lds, pro, b - g0, v.dm.G_plane, b);
+        else zero_partial_row(v, b);
+    }
     else if (b < g2) {
         const int j = b - g1 + 1;
-        if (v.pre_valid[j]) role_preint(v, lds, pro, j);
+        const int vic = v.ctrl->marg_victim;
+        if (v.pre_valid[j] && (pro->mode != MODE_MARG || j == vic || j == vic + 1)) role_preint(v, lds, pro, j);
     } else role_prior(v, lds, pro, b - g2, v.dm.G_prior);
     PV_STAMP(0, 9);
     if (v.dbg && blockIdx.x == 0 && threadIdx.x == 0) v.dbg[31] = wall_clock64();
@@ -709,7 +737,8 @@ struct DenseShared {
 
 constexpr int kPanel = 8; // Cholesky panel width
 
-__global__ void __launch_bounds__(kDenseThreads) k_dense(View v, int lds_matrix) {
+template <bool LDSMAT> // compile-time storage choice: a runtime LDS-or-global pointer select degrades every access to FLAT
+__global__ void __launch_bounds__(kDenseThreads) k_dense(View v) {
     // 256 threads = one wave per SIMD: the redundant 8 x 8 block factorization then costs each SIMD exactly once
     HIP_DYNAMIC_SHARED(double, lds)
     Ctrl *c = v.ctrl;
@@ -726,7 +755,7 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(View v, int lds_matrix)
     int &sh_fail = *reinterpret_cast<int *>(lds + 120);
     const int ld = P + 1;
     double *vec = lds + 128;
-    double *A = lds_matrix ? vec + 8 * (size_t)ld : v.Smat;
+    double *A = LDSMAT ? vec + 8 * (size_t)ld : v.Smat;
     double *diagH = vec, *gtot = vec + ld, *rhs = vec + 2 * ld, *yv = vec + 3 * ld, *vv = vec + 4 * ld, *act = vec + 5 * ld, *tmp = vec + 6 * ld,
            *cpl = vec + 7 * ld;
     auto IDX = [](int i, int k) -> size_t { return (size_t)i * (i + 1) / 2 + k; }; // k <= i
@@ -1005,6 +1034,7 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(View v, int lds_matrix)
     int fail = 0;
     for (int j0 = 0; j0 < P && !fail; j0 += kPanel) {
         const int nb = min(kPanel, P - j0);
+        if (j0 == 0) PV_STAMP(2, 8);
         double Ld[kPanel][kPanel], inv[kPanel];
 #pragma unroll
         for (int r = 0; r < kPanel; ++r)
@@ -1026,6 +1056,7 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(View v, int lds_matrix)
                 Ld[r][cc] = x * inv[cc];
             }
         }
+        if (j0 == 0) PV_STAMP(2, 9);
         if (fail) break; // uniform: every thread factored the same block
 #pragma unroll
         for (int cc = 0; cc < kPanel; ++cc)
@@ -1052,25 +1083,44 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(View v, int lds_matrix)
             }
         }
         __syncthreads();
+        if (j0 == 0) PV_STAMP(2, 10);
         if (irow < k0) {
 #pragma unroll
             for (int cc = 0; cc < kPanel; ++cc)
                 if (cc < nb && j0 + cc <= irow) A[IDX(irow, j0 + cc)] = x[cc];
         }
+        // rank-nb update of the trailing lower triangle.  Loads are batched ahead of the stores (4 columns per lane and
+        // round) -- an LDS read-modify-write loop would serialize on every store.
         for (int i = k0 + ty; i <= P; i += ny) {
             double li[kPanel];
 #pragma unroll
             for (int cc = 0; cc < kPanel; ++cc) li[cc] = cc < nb ? A[IDX(i, j0 + cc)] : 0.0;
             const int kmax = i < P ? i : P - 1;
-            for (int k = k0 + tx; k <= kmax; k += 32) {
-                const double *Lk = A + IDX(k, j0);
-                double sacc = 0;
+            const size_t rowbase = IDX(i, 0);
+            for (int kb = k0 + tx; kb <= kmax; kb += 128) {
+                double aold[4], lk[4][kPanel];
 #pragma unroll
-                for (int cc = 0; cc < kPanel; ++cc) sacc += cc < nb ? li[cc] * Lk[cc] : 0.0;
-                A[IDX(i, k)] -= sacc;
+                for (int q = 0; q < 4; ++q) {
+                    const int k = kb + 32 * q;
+                    const bool ok = k <= kmax;
+                    aold[q] = ok ? A[rowbase + k] : 0.0;
+                    const double *Lk = A + IDX(ok ? k : kmax, j0);
+#pragma unroll
+                    for (int cc = 0; cc < kPanel; ++cc) lk[q][cc] = Lk[cc < nb ? cc : 0];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int k = kb + 32 * q;
+                    double sacc = 0;
+#pragma unroll
+                    for (int cc = 0; cc < kPanel; ++cc) sacc += cc < nb ? li[cc] * lk[q][cc] : 0.0;
+                    if (k <= kmax) A[rowbase + k] = aold[q] - sacc;
+                }
             }
         }
+        if (j0 == 0) PV_STAMP(2, 11);
         __syncthreads();
+        if (j0 == 0) PV_STAMP(2, 12);
     }
     PV_STAMP(2, 5);
     // ---------------- back substitution L^T y = z in wave 0 (rows owned by lanes, one shuffle per column) ----------------
@@ -1097,8 +1147,25 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(View v, int lds_matrix)
                 yr[q] = a < P ? yv[a] : 0.0;
                 ir[q] = a < P ? tmp[a] : 0.0;
             }
+            // the row of L needed by column j is prefetched one column ahead (it does not depend on y)
+            double Lrow[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int a = tid + 64 * q;
+                Lrow[q] = a < P - 1 ? A[IDX(P - 1, a)] : 0.0;
+            }
             for (int j = P - 1; j >= 0; --j) {
                 const int owner = j & 63, qj = j >> 6;
+                double Lcur[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) Lcur[q] = Lrow[q];
+                if (j > 0) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int a = tid + 64 * q;
+                        Lrow[q] = (q <= ((j - 1) >> 6) && a < j - 1) ? A[IDX(j - 1, a)] : 0.0;
+                    }
+                }
                 double cand = 0;
 #pragma unroll
                 for (int q = 0; q < 8; ++q) cand = (q == qj) ? yr[q] * ir[q] : cand;
@@ -1107,7 +1174,7 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(View v, int lds_matrix)
                 for (int q = 0; q < 8; ++q) {
                     const int a = tid + 64 * q;
                     if (q == qj && tid == owner) yr[q] = yj;
-                    else if (a < j) yr[q] -= A[IDX(j, a)] * yj;
+                    else if (a < j) yr[q] -= Lcur[q] * yj;
                 }
             }
 #pragma unroll
@@ -1314,7 +1381,7 @@ __global__ void k_prior_prep(const double *S, const double *s, int D, double *La
 size_t linearize_lds_bytes(const Dims &dm) {
     const int N = dm.N;
     size_t common = (size_t)(N * 16 + N * kFrameRec + 160 + 16);
-    size_t lm = (size_t)dm.lm_slots * (40 * N + 46) + dm.lm_slots + (dm.lm_slots + 1) / 2 + 2;
+    size_t lm = (size_t)dm.lm_slots * (40 * N + 46) + dm.lm_slots + 2 * ((dm.lm_slots + 1) / 2) + 4;
     size_t pl = (size_t)dm.plane_slots * (dm.P6 + 2);
     size_t pre = 16 + 450 + 450 + 16;
     size_t pri = (size_t)dm.prior_n * (15 + 9 + 15) + 8;
@@ -1372,13 +1439,14 @@ hipError_t launch_dense(const View &v, hipStream_t st) {
     const size_t lds = dense_lds_bytes(v.dm, &lm);
 #ifndef PV_HIPEMU
     static size_t configured = 0;
-    if (lds > configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dense), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lm && lds > configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dense<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         configured = lds;
     }
 #endif
-    hipLaunchKernelGGL(k_dense, dim3(1), dim3(kDenseThreads), lds, st, v, lm);
+    if (lm) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_dense<true>), dim3(1), dim3(kDenseThreads), lds, st, v);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_dense<false>), dim3(1), dim3(kDenseThreads), lds, st, v);
     return hipGetLastError();
 }
 

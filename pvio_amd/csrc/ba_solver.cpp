@@ -11,6 +11,8 @@
 #include <cstring>
 
 #include "ba_kernels.h"
+#include "sym_eig.h"
+#include <cmath>
 
 namespace pvba {
 
@@ -500,7 +502,159 @@ int BASolver::reprojection_error(double *out) {
 } // namespace pvba
 
 namespace pvba {
-int BASolver::marginalize(const pvio_ba_problem *, const pvio_ba_state *, int, pvio_ba_prior *) {
-    return fail(PVIO_ERR_UNSUPPORTED, "marginalize_frame: not implemented yet");
+
+static bool lu_inverse15(const double *Ain, double *inv) { // Eigen's .inverse() for a 15 x 15 block is PartialPivLU based
+    const int n = 15;
+    double A[225];
+    int piv[15];
+    std::memcpy(A, Ain, sizeof A);
+    for (int i = 0; i < n; ++i) piv[i] = i;
+    for (int k = 0; k < n; ++k) {
+        int p = k;
+        double best = std::fabs(A[k * n + k]);
+        for (int i = k + 1; i < n; ++i)
+            if (std::fabs(A[i * n + k]) > best) best = std::fabs(A[i * n + k]), p = i;
+        if (best == 0.0) return false;
+        if (p != k) {
+            for (int j = 0; j < n; ++j) std::swap(A[k * n + j], A[p * n + j]);
+            std::swap(piv[k], piv[p]);
+        }
+        for (int i = k + 1; i < n; ++i) {
+            const double f = A[i * n + k] / A[k * n + k];
+            A[i * n + k] = f;
+            for (int j = k + 1; j < n; ++j) A[i * n + j] -= f * A[k * n + j];
+        }
+    }
+    for (int col = 0; col < n; ++col) {
+        double x[15];
+        for (int i = 0; i < n; ++i) x[i] = piv[i] == col ? 1.0 : 0.0;
+        for (int i = 0; i < n; ++i)
+            for (int k = 0; k < i; ++k) x[i] -= A[i * n + k] * x[k];
+        for (int i = n - 1; i >= 0; --i) {
+            for (int k = i + 1; k < n; ++k) x[i] -= A[i * n + k] * x[k];
+            x[i] /= A[i * n + i];
+        }
+        for (int i = 0; i < n; ++i) inv[i * n + col] = x[i];
+    }
+    return true;
 }
+
+// BundleAdjustor::marginalize_frame (bundle_adjustor.cpp:348-599).  The O(F) part -- un-robustified J^T J / J^T r of
+// every reprojection factor of the victim's landmarks, the scalar landmark elimination, the prior and the two IMU
+// factors -- runs on the GPU through k_linearize (MODE_MARG) + k_reduce; the 15N-dimensional dense tail (victim block
+// elimination, eigen-decomposition) is a few hundred kflop and stays on the host.
+int BASolver::marginalize(const pvio_ba_problem *pb, const pvio_ba_state *st, int victim, pvio_ba_prior *out) {
+    if (!pb || !st || !out || !out->S || !out->s) return fail(PVIO_ERR_INVALID_ARGUMENT, "null argument");
+    const int N = pb->n_frames;
+    if (victim < 0 || victim >= N || N < 2) return fail(PVIO_ERR_INVALID_ARGUMENT, "victim frame out of range");
+    // marginalization always works on the full 15-dim error state and ignores FF_FIX_POSE; IMU factors are used
+    // whenever they exist (:416-450), regardless of how the last solve was configured
+    pvio_ba_problem p2 = *pb;
+    p2.use_inertial = 1;
+    int rc = upload(&p2, st);
+    if (rc != PVIO_OK) return rc;
+    const Dims &dm = v_.dm;
+    const size_t Ns = N;
+    double *fs_init = static_cast<double *>(pool_.get("fs_init", Ns * 16 * sizeof(double)));
+    double *rho_init = static_cast<double *>(pool_.get("rho_init", std::max(dm.M, 1) * sizeof(double)));
+    if (check(hipMemcpyAsync(v_.fs, fs_init, Ns * 16 * sizeof(double), hipMemcpyDeviceToDevice, stream_), "reset fs")) return PVIO_ERR_HIP;
+    if (check(hipMemcpyAsync(v_.fs_user, fs_init, Ns * 16 * sizeof(double), hipMemcpyDeviceToDevice, stream_), "reset user")) return PVIO_ERR_HIP;
+    if (dm.M && check(hipMemcpyAsync(v_.rho, rho_init, (size_t)dm.M * sizeof(double), hipMemcpyDeviceToDevice, stream_), "reset rho")) return PVIO_ERR_HIP;
+    std::memset(h_ctrl_, 0, sizeof(Ctrl));
+    h_ctrl_->mode = MODE_MARG;
+    h_ctrl_->marg_victim = victim;
+    h_ctrl_->mu = 0.0;
+    if (check(hipMemcpyAsync(v_.ctrl, h_ctrl_, sizeof(Ctrl), hipMemcpyHostToDevice, stream_), "ctrl")) return PVIO_ERR_HIP;
+    hipError_t e;
+    if ((e = launch_linearize(v_, stream_)) != hipSuccess) return check(e, "k_linearize");
+    if ((e = launch_reduce(v_, stream_)) != hipSuccess) return check(e, "k_reduce");
+    const size_t nS = (size_t)dm.n_tasks * 9, nV = (size_t)kNumPoseVec * dm.P6;
+    std::vector<double> red(nS + nV + kNumLinScal), preH(Ns * 900), preg(Ns * 30);
+    const size_t Dp = 15 * (size_t)dm.prior_n;
+    std::vector<double> priH(Dp * Dp), prig(Dp);
+    std::vector<int32_t> tasks(dm.n_tasks);
+    if (check(hipMemcpyAsync(red.data(), v_.red, red.size() * sizeof(double), hipMemcpyDeviceToHost, stream_), "D2H")) return PVIO_ERR_HIP;
+    if (check(hipMemcpyAsync(preH.data(), v_.pre_H, preH.size() * sizeof(double), hipMemcpyDeviceToHost, stream_), "D2H")) return PVIO_ERR_HIP;
+    if (check(hipMemcpyAsync(preg.data(), v_.pre_g, preg.size() * sizeof(double), hipMemcpyDeviceToHost, stream_), "D2H")) return PVIO_ERR_HIP;
+    if (Dp) {
+        if (check(hipMemcpyAsync(priH.data(), v_.prior_H, priH.size() * sizeof(double), hipMemcpyDeviceToHost, stream_), "D2H")) return PVIO_ERR_HIP;
+        if (check(hipMemcpyAsync(prig.data(), v_.prior_g, prig.size() * sizeof(double), hipMemcpyDeviceToHost, stream_), "D2H")) return PVIO_ERR_HIP;
+    }
+    if (check(hipMemcpyAsync(tasks.data(), v_.task_desc, tasks.size() * sizeof(int32_t), hipMemcpyDeviceToHost, stream_), "D2H")) return PVIO_ERR_HIP;
+    if (check(hipStreamSynchronize(stream_), "marginalize sync")) return PVIO_ERR_HIP;
+
+    // ---- assemble the 15N information matrix / vector ----
+    const int D = 15 * N;
+    std::vector<double> H((size_t)D * D, 0.0), b(D, 0.0);
+    for (int t = 0; t < dm.n_tasks; ++t) {
+        const int fi = tasks[t] & 255, fj = (tasks[t] >> 8) & 255, si = (tasks[t] >> 16) & 1, sj = (tasks[t] >> 17) & 1;
+        for (int el = 0; el < 9; ++el) {
+            const int r = 15 * fi + 3 * si + el / 3, c = 15 * fj + 3 * sj + el % 3;
+            const double val = red[(size_t)el * dm.n_tasks + t];
+            H[(size_t)r * D + c] = val;
+            if (fi != fj) H[(size_t)c * D + r] = val;
+        }
+    }
+    for (int f = 0; f < N; ++f)
+        for (int k = 0; k < 6; ++k) b[15 * f + k] = red[nS + 6 * f + k] - red[nS + dm.P6 + 6 * f + k]; // J^T r - sum_l W_l^T b_l / H_ll
+    for (int j = victim; j <= victim + 1; ++j) {
+        if (j == 0 || j >= N || !(pb->preint_valid && pb->preint_valid[j])) continue;
+        for (int a = 0; a < 30; ++a) {
+            b[15 * (j - 1) + a] += preg[(size_t)j * 30 + a];
+            for (int c = 0; c < 30; ++c) H[(size_t)(15 * (j - 1) + a) * D + 15 * (j - 1) + c] += preH[(size_t)j * 900 + a * 30 + c];
+        }
+    }
+    for (size_t a = 0; a < Dp; ++a) {
+        const int ga = 15 * pb->prior_frames[a / 15] + (int)(a % 15);
+        b[ga] += prig[a];
+        for (size_t c = 0; c < Dp; ++c) H[(size_t)ga * D + 15 * pb->prior_frames[c / 15] + (int)(c % 15)] += priH[a * Dp + c];
+    }
+    // ---- eliminate the victim's 15 x 15 block (:547-581) ----
+    const int R = D - 15;
+    double Hvv[225], Hinv[225];
+    for (int x = 0; x < 15; ++x)
+        for (int y = 0; y < 15; ++y) Hvv[x * 15 + y] = H[(size_t)(15 * victim + x) * D + 15 * victim + y];
+    if (!lu_inverse15(Hvv, Hinv)) return fail(PVIO_ERR_INVALID_ARGUMENT, "singular victim block");
+    auto gidx = [&](int k) { return k < 15 * victim ? k : k + 15; };
+    std::vector<double> C((size_t)R * R, 0.0), cv(R, 0.0), T((size_t)R * 15);
+    for (int i = 0; i < R; ++i)
+        for (int y = 0; y < 15; ++y) {
+            double s = 0;
+            for (int x = 0; x < 15; ++x) s += H[(size_t)gidx(i) * D + 15 * victim + x] * Hinv[x * 15 + y];
+            T[(size_t)i * 15 + y] = s;
+        }
+    const int split = 15 * victim;
+    for (int i = 0; i < R; ++i) {
+        double s = 0;
+        for (int y = 0; y < 15; ++y) s += T[(size_t)i * 15 + y] * b[15 * victim + y];
+        cv[i] = b[gidx(i)] - s;
+        for (int j = 0; j < R; ++j) {
+            if (i >= split && j < split) continue; // lower-left = transpose of upper-right (:572-576)
+            double s2 = 0;
+            for (int y = 0; y < 15; ++y) s2 += T[(size_t)i * 15 + y] * H[(size_t)(15 * victim + y) * D + gidx(j)];
+            C[(size_t)i * R + j] = H[(size_t)gidx(i) * D + gidx(j)] - s2;
+        }
+    }
+    for (int i = split; i < R; ++i)
+        for (int j = 0; j < split; ++j) C[(size_t)i * R + j] = C[(size_t)j * R + i];
+    if (out->info_matrix) std::memcpy(out->info_matrix, C.data(), sizeof(double) * R * R);
+    if (out->info_vector) std::memcpy(out->info_vector, cv.data(), sizeof(double) * R);
+    // ---- sqrt information: sqrt(L) V^T and L^-1/2 V^T b, eigenvalues <= 1e-8 zeroed (:583-590) ----
+    std::vector<double> w(R), V((size_t)R * R);
+    sym_eig(C.data(), R, w.data(), V.data());
+    out->n = N - 1;
+    for (int k = 0; k < R; ++k) {
+        const double lam = w[k] > 1.0e-8 ? w[k] : 0.0, lam_inv = w[k] > 1.0e-8 ? 1.0 / w[k] : 0.0;
+        const double sl = std::sqrt(lam), sli = std::sqrt(lam_inv);
+        double acc = 0;
+        for (int i = 0; i < R; ++i) {
+            out->S[(size_t)k * R + i] = sl * V[(size_t)i * R + k];
+            acc += V[(size_t)i * R + k] * cv[i];
+        }
+        out->s[k] = sli * acc;
+    }
+    uploaded_ = false; // the device buffers now hold a marginalization pass, not a solvable window
+    return PVIO_OK;
+}
+
 } // namespace pvba

@@ -25,7 +25,8 @@ enum Mode : int32_t {
     MODE_INIT = 0,       // evaluate + linearize the initial point (iteration 0)
     MODE_CANDIDATE = 1,  // form the dogleg step, evaluate + speculatively linearize the candidate
     MODE_RELIN = 2,      // re-linearize the accepted point (mu changed after a failed factorization / invalid step)
-    MODE_DONE = 3
+    MODE_DONE = 3,
+    MODE_MARG = 4        // marginalize_frame: un-robustified J^T J of the victim's landmarks, Schur weight 1 / H_ll
 };
 enum LinResult : int32_t { LIN_NONE = 0, LIN_INIT = 1, LIN_CANDIDATE = 2, LIN_RELIN = 3, LIN_INVALID_STEP = 4 };
 
@@ -51,7 +52,7 @@ struct Ctrl {
     int32_t scaling_ready;   // Jacobi scaling has been computed (iteration 0)
     int32_t trace_len, trace_cap;
     int32_t retry_relin;     // RELIN triggered by a mu escalation inside one iteration (not a new iteration)
-    int32_t pad0;
+    int32_t marg_victim;     // MODE_MARG: frame being marginalized
     double radius, mu;
     double x_cost, x_norm2_pose, x_norm2_lm, grad_max;
     double initial_cost;

@@ -57,3 +57,21 @@ def test_rejects_bad_input(emu_ctx, oracle):
     pb.obs_frame[1] = pb.obs_frame[0]  # same target frame twice for one landmark
     with pytest.raises(HipError):
         emu_ctx.solve(pb)
+
+
+import marg_compare  # noqa: E402
+
+
+@pytest.mark.parametrize("victim", [0, 2])
+def test_emulated_marginalize_matches_oracle(emu_ctx, oracle, victim):
+    marg_compare.check_marginalize(emu_ctx, oracle, victim, n_frames=5, n_landmarks=60, use_inertial=True, visibility=4)
+
+
+def test_emulated_marginalize_last_frame_no_prior(emu_ctx, oracle):
+    import numpy as np
+    pb, st = marg_compare.solved_window(oracle, n_frames=4, n_landmarks=40, use_inertial=True)
+    pb.prior_frames = np.zeros(0, np.int32)  # no previous marginalization factor
+    S0, s0, IM0, iv0 = oracle.marginalize(pb, st, 3)
+    S1, s1, IM1, iv1 = emu_ctx.marginalize(pb, st, 3)
+    np.testing.assert_allclose(IM1, IM0, rtol=1e-7, atol=1e-9 * np.abs(IM0).max())
+    np.testing.assert_allclose(S1.T @ S1, S0.T @ S0, rtol=1e-6, atol=1e-7 * np.abs(IM0).max())

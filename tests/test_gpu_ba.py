@@ -78,3 +78,9 @@ def test_gpu_reprojection_error_matches_oracle(gpu_ctx, oracle):
     pb = ba_compare.make(oracle, **ba_compare.CASES["config1_10x200"])
     st = BAState(pb)
     np.testing.assert_allclose(gpu_ctx.reprojection_error(pb, st), oracle.reprojection_error(pb, st), rtol=1e-10)
+
+
+@pytest.mark.parametrize("victim", [0, 3, 9])
+def test_gpu_marginalize_matches_oracle(gpu_ctx, oracle, victim):
+    import marg_compare
+    print(marg_compare.check_marginalize(gpu_ctx, oracle, victim, n_frames=10, n_landmarks=300, use_inertial=True, visibility=6))
