@@ -33,6 +33,20 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/*_pmc_hbm.json: separate
+    FETCH_SIZE / WRITE_SIZE runs of this same command, FETCH_SIZE doubled per the gfx950 correction).  None if absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm.json")))
+    if not files:
+        return None
+    try:
+        with open(files[-1]) as f:
+            return json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def parse_workload(name):
     # "<frames>x<landmarks>[_vision|_vio]" or the shorthands "vio" / "vision"
     if name in ("vio", "vision"):
@@ -69,7 +83,7 @@ def bench_klt(ctx, args, width=512, height=512, n_points=1500, reps=50):
            "workload": "%dx%d u8 pair, %d tracks, win 21x21, 4 levels, <=30 iterations, initial flow given" % (width, height, n_points),
            "tracked": int(st.sum()), "preprocess_ms_per_image": prep_ms,
            "roofline": {"bound": "hbm", "kernel": "k_lk_track", "achieved": alg_bytes / (dev_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": alg_bytes / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
+                        "frac": alg_bytes / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic("k_lk_track"), "algorithmic_bytes_per_launch": alg_bytes,
                         "avg_launch_us": dev_ms * 1e3}}
     if not args.no_cpu_baseline:
         from oracle import oracle_py as O
@@ -167,7 +181,7 @@ def main():
     achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
     roofline = {
         "bound": "hbm", "kernel": "k_linearize", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+        "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("k_linearize"),
         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": avg_s * 1e6,
         "kernel_us": {k: (v[0] / max(v[1], 1)) * 1e3 for k, v in prof.items()},
         "note": "working set < 1 MB: L2/Infinity-Cache resident, the iteration is launch/dependency-latency bound",
