@@ -1,0 +1,300 @@
+// bundle_adjustor.cpp -- pvio::BundleAdjustor on top of the HIP C-ABI (include/pvio_hip.h).
+//
+// Drop-in for pvio/src/pvio/estimation/bundle_adjustor.cpp: same class, same three methods, same in-place semantics
+// (states are read from and written back into Frame::pose/motion and Track::landmark), same return value
+// (IsSolutionUsable(), :298), no exceptions.  What it does NOT contain any more: ceres::Problem assembly and
+// ceres::Solve -- the Map is flattened, in the reference's residual-block order, into a pvio_ba_problem and handed to
+// the GPU.  Host-side passes that are map bookkeeping stay here (plane re-validation :251-275 needs
+// PlaneExtractor/triangulation, which live outside this seam).
+#ifdef PVIO_HOST_USE_REFERENCE_TYPES
+#include <pvio/estimation/bundle_adjustor.h>
+#include <pvio/map/frame.h>
+#include <pvio/map/map.h>
+#include <pvio/map/plane.h>
+#include <pvio/map/track.h>
+#else
+#include "pvio_min.h"
+#endif
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <unordered_map>
+#include <unordered_set>
+
+#include "../../include/pvio_hip.h"
+
+namespace pvio {
+
+namespace {
+
+// One GPU context per process: the reference constructs a BundleAdjustor temporary per call
+// (sliding_window_tracker.cpp:113), so the context must outlive the object.
+pvio_hip_ctx *process_ctx() {
+    static pvio_hip_ctx *ctx = nullptr;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        pvio_hip_opts o;
+        std::memset(&o, 0, sizeof o);
+        o.world_size = 1, o.use_graph = 1;
+        if (pvio_hip_create(&o, &ctx) != PVIO_OK) {
+            std::fprintf(stderr, "[pvio-hip] no usable GPU context: BundleAdjustor::solve will report failure\n");
+            ctx = nullptr;
+        }
+    });
+    return ctx;
+}
+
+struct Flat { // owns the arrays a pvio_ba_problem points into
+    std::vector<uint8_t> frame_fixed, pre_valid;
+    std::vector<double> cam, imu, sic, intr, fstate, lm_z, obs_z, rho, pre_delta, pre_U, pre_jac, prior_S, prior_s, prior_lin, plane_z, plane_n, plane_d;
+    std::vector<int32_t> lm_anchor, lm_ptr, obs_frame, prior_frames, plane_ptr, plane_frame;
+    std::vector<Track *> lm_track; // landmark index -> track (write-back)
+    pvio_ba_problem pb;
+};
+
+void put_q(std::vector<double> &v, size_t off, quaternion &q) {
+    const double *c = q.coeffs().data();
+    for (int k = 0; k < 4; ++k) v[off + k] = c[k];
+}
+
+// The reference's block order: frames in map index order (:75-88); inverse depths by first encounter scanning frames then
+// keypoint index (:91-103); reprojection blocks per track in ascending frame id with the anchor first (track.h:69).
+// (Ceres sums residual blocks frame-major; the flat CSR is landmark-major -- a different summation order, i.e. a
+// difference at rounding level only.)
+void flatten(Map *map, Config *config, bool use_inertial, bool for_marginalization, Flat &F) {
+    const int N = (int)map->frame_num();
+    std::unordered_map<const Frame *, int> fidx;
+    for (int i = 0; i < N; ++i) fidx[map->get_frame(i)] = i;
+    F.frame_fixed.assign(N, 0), F.pre_valid.assign(N, 0);
+    F.cam.assign(7 * N, 0), F.imu.assign(7 * N, 0), F.sic.assign(4 * N, 0), F.intr.assign(4 * N, 0), F.fstate.assign(16 * N, 0);
+    F.pre_delta.assign(11 * N, 0), F.pre_U.assign(225 * N, 0), F.pre_jac.assign(45 * N, 0);
+    for (int i = 0; i < N; ++i) {
+        Frame *f = map->get_frame(i);
+        F.frame_fixed[i] = f->flag(FrameFlag::FF_FIX_POSE) ? 1 : 0;
+        put_q(F.cam, 7 * i, f->camera.q_cs), put_q(F.imu, 7 * i, f->imu.q_cs);
+        for (int k = 0; k < 3; ++k) F.cam[7 * i + 4 + k] = f->camera.p_cs[k], F.imu[7 * i + 4 + k] = f->imu.p_cs[k];
+        F.sic[4 * i] = f->sqrt_inv_cov(0, 0), F.sic[4 * i + 1] = f->sqrt_inv_cov(0, 1), F.sic[4 * i + 2] = f->sqrt_inv_cov(1, 0), F.sic[4 * i + 3] = f->sqrt_inv_cov(1, 1);
+        F.intr[4 * i] = f->K(0, 0), F.intr[4 * i + 1] = f->K(1, 1), F.intr[4 * i + 2] = f->K(0, 2), F.intr[4 * i + 3] = f->K(1, 2);
+        put_q(F.fstate, 16 * i, f->pose.q);
+        for (int k = 0; k < 3; ++k) {
+            F.fstate[16 * i + 4 + k] = f->pose.p[k], F.fstate[16 * i + 7 + k] = f->motion.v[k];
+            F.fstate[16 * i + 10 + k] = f->motion.bg[k], F.fstate[16 * i + 13 + k] = f->motion.ba[k];
+        }
+    }
+    // planes with >= 20 tracks constrain their best-plane tracks through the plane-distance factor; tracks of smaller
+    // planes fall back to plain reprojection blocks (:165-195)
+    std::unordered_set<Track *> small_plane_tracks;
+    std::vector<std::pair<Track *, Plane *>> plane_factors;
+    if (!for_marginalization)
+        for (size_t i = 0; i < map->plane_num(); ++i) {
+            Plane *pl = map->get_plane(i);
+            if (pl->tracks.size() < 20) {
+                for (Track *t : pl->tracks) small_plane_tracks.insert(t);
+            } else {
+                for (Track *t : pl->tracks)
+                    if (t->landmark.plane_id == pl->id()) plane_factors.emplace_back(t, pl);
+            }
+        }
+    std::unordered_set<Track *> visited;
+    F.lm_track.clear(), F.lm_anchor.clear(), F.lm_ptr.assign(1, 0), F.obs_frame.clear(), F.lm_z.clear(), F.obs_z.clear(), F.rho.clear();
+    auto add_landmark = [&](Track *track) {
+        if (!visited.insert(track).second) return;
+        auto first = track->first_keypoint();
+        if (!fidx.count(first.first)) return;
+        F.lm_track.push_back(track);
+        F.lm_anchor.push_back(fidx[first.first]);
+        const auto &za = first.first->get_keypoint(first.second);
+        F.lm_z.push_back(za(0)), F.lm_z.push_back(za(1));
+        F.rho.push_back(track->landmark.inv_depth);
+        for (const auto &kv : track->keypoint_map()) {
+            if (kv.first == first.first) continue;              // the anchor observation has no factor (:149)
+            auto it = fidx.find(kv.first);
+            if (it == fidx.end()) continue;
+            const auto &z = kv.first->get_keypoint(kv.second);
+            F.obs_frame.push_back(it->second);
+            F.obs_z.push_back(z(0)), F.obs_z.push_back(z(1));
+        }
+        F.lm_ptr.push_back((int32_t)F.obs_frame.size());
+    };
+    for (int i = 0; i < N; ++i) {
+        Frame *f = map->get_frame(i);
+        for (size_t j = 0; j < f->keypoint_num(); ++j) {
+            Track *track = f->get_track(j);
+            if (!track || !track->flag(TrackFlag::TF_VALID) || track->flag(TrackFlag::TF_PLANE)) continue;
+            add_landmark(track);
+        }
+    }
+    for (size_t i = 0; i < map->plane_num() && !for_marginalization; ++i)
+        if (map->get_plane(i)->tracks.size() < 20)
+            for (Track *t : map->get_plane(i)->tracks) add_landmark(t);
+    // plane-distance factors (:180-195)
+    F.plane_ptr.assign(1, 0), F.plane_frame.clear(), F.plane_z.clear(), F.plane_n.clear(), F.plane_d.clear();
+    for (auto &tp : plane_factors) {
+        for (const auto &kv : tp.first->keypoint_map()) {
+            auto it = fidx.find(kv.first);
+            if (it == fidx.end()) continue;
+            const auto &z = kv.first->get_keypoint(kv.second);
+            F.plane_frame.push_back(it->second);
+            F.plane_z.push_back(z(0)), F.plane_z.push_back(z(1));
+        }
+        F.plane_ptr.push_back((int32_t)F.plane_frame.size());
+        for (int k = 0; k < 3; ++k) F.plane_n.push_back(tp.second->parameter.normal[k]);
+        F.plane_d.push_back(tp.second->parameter.distance);
+    }
+    // IMU factors: re-integrate at frame_i's current biases first (:224); marginalization reuses the stored delta (:416-450)
+    if (use_inertial || for_marginalization)
+        for (int j = 1; j < N; ++j) {
+            Frame *fi = map->get_frame(j - 1), *fj = map->get_frame(j);
+            bool ok = for_marginalization ? fj->has_preintegration_factor : fj->preintegration.integrate(fj->image_t, fi->motion.bg, fi->motion.ba, true, true);
+            if (!ok) continue;
+            F.pre_valid[j] = 1;
+            auto &d = fj->preintegration.delta;
+            F.pre_delta[11 * j] = d.t;
+            put_q(F.pre_delta, 11 * j + 1, d.q);
+            for (int k = 0; k < 3; ++k) F.pre_delta[11 * j + 5 + k] = d.p[k], F.pre_delta[11 * j + 8 + k] = d.v[k];
+            std::memcpy(&F.pre_U[225 * j], d.sqrt_inv_cov, sizeof d.sqrt_inv_cov);
+            auto &jc = fj->preintegration.jacobian;
+            std::memcpy(&F.pre_jac[45 * j], jc.dq_dbg, 72), std::memcpy(&F.pre_jac[45 * j + 9], jc.dp_dbg, 72);
+            std::memcpy(&F.pre_jac[45 * j + 18], jc.dp_dba, 72), std::memcpy(&F.pre_jac[45 * j + 27], jc.dv_dbg, 72), std::memcpy(&F.pre_jac[45 * j + 36], jc.dv_dba, 72);
+        }
+    // marginalization prior (:126-139)
+    F.prior_frames.clear(), F.prior_S.clear(), F.prior_s.clear(), F.prior_lin.clear();
+    if (MarginalizationPrior *pr = map->get_marginalization_factor()) {
+        for (size_t i = 0; i < pr->frames.size(); ++i) {
+            F.prior_frames.push_back(fidx.at(pr->frames[i]));
+            const size_t o = F.prior_lin.size();
+            F.prior_lin.resize(o + 16);
+            put_q(F.prior_lin, o, pr->pose_0[i].q);
+            for (int k = 0; k < 3; ++k) {
+                F.prior_lin[o + 4 + k] = pr->pose_0[i].p[k], F.prior_lin[o + 7 + k] = pr->motion_0[i].v[k];
+                F.prior_lin[o + 10 + k] = pr->motion_0[i].bg[k], F.prior_lin[o + 13 + k] = pr->motion_0[i].ba[k];
+            }
+        }
+        F.prior_S = pr->sqrt_infomat, F.prior_s = pr->sqrt_infovec;
+    }
+    pvio_ba_problem &pb = F.pb;
+    std::memset(&pb, 0, sizeof pb);
+    pb.n_frames = N, pb.n_landmarks = (int32_t)F.lm_anchor.size(), pb.n_obs = (int32_t)F.obs_frame.size();
+    pb.use_inertial = use_inertial ? 1 : 0;
+    pb.frame_fixed = F.frame_fixed.data(), pb.cam_extrinsic = F.cam.data(), pb.imu_extrinsic = F.imu.data();
+    pb.sqrt_inv_cov = F.sic.data(), pb.intrinsics = F.intr.data();
+    pb.lm_anchor_frame = F.lm_anchor.data(), pb.lm_anchor_z = F.lm_z.data(), pb.lm_obs_ptr = F.lm_ptr.data();
+    pb.obs_frame = F.obs_frame.data(), pb.obs_z = F.obs_z.data();
+    pb.preint_valid = F.pre_valid.data(), pb.preint_delta = F.pre_delta.data(), pb.preint_sqrt_inv_cov = F.pre_U.data(), pb.preint_jacobian = F.pre_jac.data();
+    pb.prior_n = (int32_t)F.prior_frames.size(), pb.prior_frames = F.prior_frames.data();
+    pb.prior_S = F.prior_S.data(), pb.prior_s = F.prior_s.data(), pb.prior_lin_state = F.prior_lin.data();
+    pb.n_plane_factors = (int32_t)F.plane_d.size();
+    pb.plane_obs_ptr = F.plane_ptr.data(), pb.plane_obs_frame = F.plane_frame.data(), pb.plane_obs_z = F.plane_z.data();
+    pb.plane_normal = F.plane_n.data(), pb.plane_distance = F.plane_d.data();
+    pb.plane_sqrt_inv_cov = std::sqrt(1.0 / config->plane_distance_cov()); // :181
+    pb.max_iterations = (int32_t)config->solver_iteration_limit();
+    pb.max_solver_time = config->solver_time_limit();
+}
+
+struct DefaultConfig : Config {};
+
+} // namespace
+
+#ifndef PVIO_HOST_USE_REFERENCE_TYPES
+bool PreIntegrator::integrate(double t, const vector<3> &bg, const vector<3> &ba, bool, bool) { // preintegrator.cpp:84-96
+    if (data.empty()) return false;
+    std::vector<double> ts(data.size()), w(3 * data.size()), a(3 * data.size());
+    for (size_t i = 0; i < data.size(); ++i) {
+        ts[i] = data[i].t;
+        for (int k = 0; k < 3; ++k) w[3 * i + k] = data[i].w[k], a[3 * i + k] = data[i].a[k];
+    }
+    pvio_imu_noise nz;
+    std::memcpy(nz.cov_w, cov_w, 72), std::memcpy(nz.cov_a, cov_a, 72), std::memcpy(nz.cov_bg, cov_bg, 72), std::memcpy(nz.cov_ba, cov_ba, 72);
+    double d[11], jac[45];
+    if (pvio_preintegrate((int32_t)data.size(), ts.data(), w.data(), a.data(), t, bg.data(), ba.data(), &nz, d, delta.cov, delta.sqrt_inv_cov, jac) != PVIO_OK) return false;
+    delta.t = d[0];
+    std::memcpy(delta.q.c, d + 1, 32);
+    for (int k = 0; k < 3; ++k) delta.p[k] = d[5 + k], delta.v[k] = d[8 + k];
+    std::memcpy(jacobian.dq_dbg, jac, 72), std::memcpy(jacobian.dp_dbg, jac + 9, 72), std::memcpy(jacobian.dp_dba, jac + 18, 72);
+    std::memcpy(jacobian.dv_dbg, jac + 27, 72), std::memcpy(jacobian.dv_dba, jac + 36, 72);
+    return true;
+}
+#endif
+
+BundleAdjustor::BundleAdjustor() = default;
+BundleAdjustor::~BundleAdjustor() = default;
+
+bool BundleAdjustor::solve(Map *map, Config *config, bool use_inertial) {
+    pvio_hip_ctx *ctx = process_ctx();
+    if (!ctx) return false;
+    DefaultConfig dc;
+    Flat F;
+    flatten(map, config ? config : &dc, use_inertial, false, F);
+    std::vector<double> quality(F.lm_track.size(), 0.0);
+    std::vector<uint8_t> valid(F.lm_track.size(), 1);
+    pvio_ba_state st{F.fstate.data(), F.rho.data(), quality.data(), valid.data()};
+    pvio_ba_summary sum;
+    std::memset(&sum, 0, sizeof sum);
+    if (pvio_hip_ba_solve(ctx, &F.pb, &st, &sum) != PVIO_OK) {
+        std::fprintf(stderr, "[pvio-hip] ba_solve failed: %s\n", pvio_hip_last_error(ctx));
+        return false;
+    }
+    // write the states back in place, like Ceres does through the parameter-block pointers
+    for (size_t i = 0; i < map->frame_num(); ++i) {
+        Frame *f = map->get_frame(i);
+        double *q = f->pose.q.coeffs().data();
+        for (int k = 0; k < 4; ++k) q[k] = F.fstate[16 * i + k];
+        for (int k = 0; k < 3; ++k) {
+            f->pose.p[k] = F.fstate[16 * i + 4 + k];
+            if (use_inertial || map->get_marginalization_factor()) {
+                f->motion.v[k] = F.fstate[16 * i + 7 + k], f->motion.bg[k] = F.fstate[16 * i + 10 + k], f->motion.ba[k] = F.fstate[16 * i + 13 + k];
+            }
+        }
+    }
+    for (size_t l = 0; l < F.lm_track.size(); ++l) {
+        Track *t = F.lm_track[l];
+        t->landmark.inv_depth = F.rho[l];
+        if (!valid[l]) { // depth gate (:286-290)
+            t->set_flag(TrackFlag::TF_VALID, false), t->set_flag(TrackFlag::TF_PLANE, false);
+        } else {
+            t->landmark.quality = quality[l];
+        }
+    }
+    return sum.is_usable != 0;
+}
+
+void BundleAdjustor::marginalize_frame(Map *map, size_t index) {
+    pvio_hip_ctx *ctx = process_ctx();
+    if (!ctx || index >= map->frame_num() || map->frame_num() < 2) return;
+    DefaultConfig dc;
+    Flat F;
+    flatten(map, &dc, true, true, F);
+    const size_t n = map->frame_num() - 1, D = 15 * n;
+    auto pr = std::make_unique<MarginalizationPrior>();
+    pr->sqrt_infomat.assign(D * D, 0.0), pr->sqrt_infovec.assign(D, 0.0);
+    pvio_ba_state st{F.fstate.data(), F.rho.data(), nullptr, nullptr};
+    pvio_ba_prior out;
+    std::memset(&out, 0, sizeof out);
+    out.S = pr->sqrt_infomat.data(), out.s = pr->sqrt_infovec.data();
+    if (pvio_hip_ba_marginalize(ctx, &F.pb, &st, (int32_t)index, &out) != PVIO_OK) {
+        std::fprintf(stderr, "[pvio-hip] ba_marginalize failed: %s\n", pvio_hip_last_error(ctx));
+        return;
+    }
+    for (size_t i = 0; i < map->frame_num(); ++i) { // remaining frames, linearized at their current states (:592-598)
+        if (i == index) continue;
+        Frame *f = map->get_frame(i);
+        pr->frames.push_back(f), pr->pose_0.push_back(f->pose), pr->motion_0.push_back(f->motion);
+    }
+    map->set_marginalization_factor(std::move(pr));
+}
+
+double BundleAdjustor::compute_reprojection_error(Map *map) {
+    pvio_hip_ctx *ctx = process_ctx();
+    if (!ctx) return 0.0;
+    DefaultConfig dc;
+    Flat F;
+    flatten(map, &dc, false, true, F);
+    pvio_ba_state st{F.fstate.data(), F.rho.data(), nullptr, nullptr};
+    double err = 0;
+    if (pvio_hip_ba_reprojection_error(ctx, &F.pb, &st, &err) != PVIO_OK) return 0.0;
+    return err;
+}
+
+} // namespace pvio
