@@ -1289,14 +1289,18 @@ __global__ void __launch_bounds__(256) k_backsub(View v) {
     }
 }
 
-// sums the k_backsub rows into row 0 (only used before an all-reduce across landmark shards)
-__global__ void k_back_reduce(View v, int rows) {
+// Landmark-sharded solves only: back_local keeps this rank's latest k_backsub sums (they stay valid across rejected
+// steps, when k_backsub does not run); every slot copies them into back_red, which the host then all-reduces IN PLACE --
+// so the collective can be issued unconditionally without accumulating stale values.
+__global__ void k_back_reduce(View v, int rows, double *back_local) {
     const Ctrl *c = v.ctrl;
-    if (c->done || !c->solve_ok) return;
     if (threadIdx.x < kNumBackScal) {
-        double s = 0;
-        for (int r = 0; r < rows; ++r) s += v.back_part[(size_t)r * kNumBackScal + threadIdx.x];
-        v.back_red[threadIdx.x] = s;
+        if (!c->done && c->solve_ok) {
+            double s = 0;
+            for (int r = 0; r < rows; ++r) s += v.back_part[(size_t)r * kNumBackScal + threadIdx.x];
+            back_local[threadIdx.x] = s;
+        }
+        v.back_red[threadIdx.x] = back_local[threadIdx.x];
     }
 }
 
@@ -1454,8 +1458,8 @@ hipError_t launch_backsub(const View &v, hipStream_t st) {
     hipLaunchKernelGGL(k_backsub, dim3(v.dm.G_back), dim3(256), 0, st, v);
     return hipGetLastError();
 }
-hipError_t launch_back_reduce(const View &v, hipStream_t st) {
-    hipLaunchKernelGGL(k_back_reduce, dim3(1), dim3(64), 0, st, v, v.dm.G_back);
+hipError_t launch_back_reduce(const View &v, double *back_local, hipStream_t st) {
+    hipLaunchKernelGGL(k_back_reduce, dim3(1), dim3(64), 0, st, v, v.dm.G_back, back_local);
     return hipGetLastError();
 }
 hipError_t launch_quality(const View &v, hipStream_t st, int buf_from_ctrl, double *err_sum) {

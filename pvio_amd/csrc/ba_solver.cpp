@@ -324,7 +324,8 @@ int BASolver::enqueue_slot(hipEvent_t *ev) {
     if ((e = launch_backsub(v_, stream_)) != hipSuccess) return check(e, "k_backsub");
     if (ev) (void)hipEventRecord(ev[5], stream_);
     if (world_ > 1) {
-        if ((e = launch_back_reduce(v_, stream_)) != hipSuccess) return check(e, "k_back_reduce");
+        double *back_local = static_cast<double *>(pool_.get("back_local", kNumBackScal * sizeof(double)));
+        if ((e = launch_back_reduce(v_, back_local, stream_)) != hipSuccess) return check(e, "k_back_reduce");
         if (comm_allreduce(comm_, v_.back_red, kNumBackScal, 0, stream_)) return fail(PVIO_ERR_COMM, "all-reduce failed");
     }
     return PVIO_OK;

@@ -1,0 +1,52 @@
+"""One rank of the CPU multi-process test of the landmark-sharded solve (launched by tests/test_multi_rank_cpu.py with
+torch.distributed.run, backend gloo).  Kernels run in the fiber emulator; the RCCL all-reduce is replaced by gloo."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    out_dir = sys.argv[1]
+    case = sys.argv[2]
+    dist.init_process_group(backend="gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    import ba_compare
+    from oracle import oracle_py as O
+    from pvio_amd import BAState, BASummary, capi
+    from pvio_amd.solver import HipContext
+
+    lib = capi.load(os.path.join(ROOT, "tests", "hipemu", "libpvio_hipemu.so"))
+
+    @C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_long, C.c_int)
+    def allreduce(buf, n, op_max):
+        a = np.ctypeslib.as_array(buf, shape=(n,))
+        t = torch.from_numpy(a)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX if op_max else dist.ReduceOp.SUM)
+        return 0
+
+    lib.hipemu_set_allreduce(allreduce)
+    pb = ba_compare.make(O, **ba_compare.CASES[case])
+    shard = pb.shard(rank, world)
+    ctx = HipContext(lib=lib, rank=rank, world_size=world, use_graph=False)
+    uid = (C.c_uint8 * 128)()
+    assert lib.pvio_hip_comm_unique_id(uid) == 0
+    assert lib.pvio_hip_comm_init(ctx.ctx, uid, rank, world) == 0
+    st, sm = ctx.solve(shard)
+    l0, l1 = shard.meta["lm_range"] if world > 1 else (0, pb.n_landmarks)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), frame_state=st.frame_state, rho=st.lm_inv_depth, l0=l0, l1=l1,
+             iters=sm.num_iterations, term=sm.termination, costs=np.array([t["cost"] for t in sm.trace()]),
+             succ=np.array([t["step_is_successful"] for t in sm.trace()]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
