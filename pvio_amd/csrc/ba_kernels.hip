@@ -576,68 +576,59 @@ __device__ void role_preint(const View &v, double *lds, const Pro *pro, int j) {
 }
 
 // ---- marginalization prior: block b of nb -------------------------------------------------------------------
+// One workgroup per prior frame b (its 15 rows of r = S e + s, t = Lambda e + eta, H = B^T Lambda B): 16 threads
+// cooperate on a row, so every row product is one coalesced sweep with all loads in flight.
 __device__ void role_prior(const View &v, double *lds, const Pro *pro, int b, int nb) {
     const int N = v.dm.N, n = v.dm.prior_n, D = 15 * n, tid = threadIdx.x;
     const double *est = lds;
-    double *scratch = lds + N * 16 + N * kFrameRec;
-    double *work = lds + common_lds_doubles(N); // e[D] JRI[9n] rr[D]
-    double *e = work, *JRI = work + D, *rr = JRI + 9 * n;
+    double *work = lds + common_lds_doubles(N); // e[D] JRI[9n] rs[16] rt[16]
+    double *e = work, *JRI = work + D, *rs = JRI + 9 * n, *rt = rs + 16;
     if (tid < n) prior_frame_error(est + 16 * v.prior_frames[tid], v.prior_lin + 16 * tid, e + 15 * tid, JRI + 9 * tid);
     __syncthreads();
-    if (b == 0) {
-        // r = S e + s ; cost = |r|^2 / 2 ; g = B^T (Lambda e + eta)
-        double c2 = 0;
-        // thread per row, but walking COLUMNS of S^T / Lambda (= rows, Lambda is symmetric) so that a wave reads
-        // consecutive addresses; 4-way unrolled independent accumulators
-        for (int row = tid; row < D; row += kLinThreads) {
-            double s0 = v.prior_s[row], s1 = 0, t0 = v.prior_eta[row], t1 = 0;
-            int k = 0;
-            for (; k + 1 < D; k += 2) {
-                s0 += v.prior_ST[(size_t)k * D + row] * e[k], s1 += v.prior_ST[(size_t)(k + 1) * D + row] * e[k + 1];
-                t0 += v.prior_Lambda[(size_t)k * D + row] * e[k], t1 += v.prior_Lambda[(size_t)(k + 1) * D + row] * e[k + 1];
-            }
-            if (k < D) s0 += v.prior_ST[(size_t)k * D + row] * e[k], t0 += v.prior_Lambda[(size_t)k * D + row] * e[k];
-            const double s = s0 + s1;
-            c2 += s * s;
-            rr[row] = t0 + t1;
+    const bool marg = pro->mode == MODE_MARG;
+    {
+        const int r = tid >> 4, part = tid & 15, row = 15 * b + r; // 15 rows x 16 lanes (tid < 240)
+        double ss = 0, tt = 0;
+        if (r < 15) {
+            const double *Sr = v.prior_S + (size_t)row * D, *Lr = v.prior_Lambda + (size_t)row * D;
+            for (int k = part; k < D; k += 16) ss += Sr[k] * e[k], tt += Lr[k] * e[k];
         }
-        double sc[1] = {c2};
-        block_sum<1>(sc, scratch); // also orders the rr writes
-        if (tid == 0) v.prior_cost[0] = 0.5 * sc[0];
-        for (int a = tid; a < D; a += kLinThreads) {
-            const int i = a / 15, k = a - 15 * i;
-            double g;
-            if (k < 3) {
-                const double *Jm = JRI + 9 * i;
-                g = Jm[k] * rr[15 * i] + Jm[3 + k] * rr[15 * i + 1] + Jm[6 + k] * rr[15 * i + 2];
-            } else {
-                g = rr[a];
-            }
-            const int fr = v.prior_frames[i];
-            if (k < 6 && v.frame_fixed[fr] && pro->mode != MODE_MARG) g = 0.0;
-            v.prior_g[a] = g;
-        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o), tt += __shfl_xor(tt, o);
+        if (r < 15 && part == 0) rs[r] = ss + v.prior_s[row], rt[r] = tt + v.prior_eta[row];
     }
-    // H = B^T Lambda B, rows split across the prior blocks
-    const int rows_per = (D + nb - 1) / nb, ra = b * rows_per, rb = min(D, ra + rows_per);
-    for (int idx = tid; idx < (rb - ra) * D; idx += kLinThreads) {
-        const int a = ra + idx / D, c = idx % D;
-        const int ia = a / 15, ka = a - 15 * ia, ic = c / 15, kc = c - 15 * ic;
-        const double *Ja = JRI + 9 * ia, *Jc = JRI + 9 * ic;
+    __syncthreads();
+    if (tid == 0) {
+        double c2 = 0;
+        for (int r = 0; r < 15; ++r) c2 += rs[r] * rs[r];
+        v.prior_cost[b] = 0.5 * c2; // summed over the prior frames by k_dense
+    }
+    if (tid < 15) { // g = B^T t on this frame's block
+        const double *Jm = JRI + 9 * b;
+        double g = tid < 3 ? Jm[tid] * rt[0] + Jm[3 + tid] * rt[1] + Jm[6 + tid] * rt[2] : rt[tid];
+        if (tid < 6 && v.frame_fixed[v.prior_frames[b]] && !marg) g = 0.0;
+        v.prior_g[15 * b + tid] = g;
+    }
+    // H rows of this frame: H = B^T Lambda B
+    for (int idx = tid; idx < 15 * D; idx += kLinThreads) {
+        const int ka = idx / D, c = idx - ka * D, a = 15 * b + ka;
+        const int ic = c / 15, kc = c - 15 * ic;
+        const double *Ja = JRI + 9 * b, *Jc = JRI + 9 * ic;
         double h = 0;
         if (ka < 3 && kc < 3) {
             for (int x = 0; x < 3; ++x)
-                for (int y = 0; y < 3; ++y) h += Ja[3 * x + ka] * v.prior_Lambda[(size_t)(15 * ia + x) * D + 15 * ic + y] * Jc[3 * y + kc];
+                for (int y = 0; y < 3; ++y) h += Ja[3 * x + ka] * v.prior_Lambda[(size_t)(15 * b + x) * D + 15 * ic + y] * Jc[3 * y + kc];
         } else if (ka < 3) {
-            for (int x = 0; x < 3; ++x) h += Ja[3 * x + ka] * v.prior_Lambda[(size_t)(15 * ia + x) * D + c];
+            for (int x = 0; x < 3; ++x) h += Ja[3 * x + ka] * v.prior_Lambda[(size_t)(15 * b + x) * D + c];
         } else if (kc < 3) {
             for (int y = 0; y < 3; ++y) h += v.prior_Lambda[(size_t)a * D + 15 * ic + y] * Jc[3 * y + kc];
         } else {
             h = v.prior_Lambda[(size_t)a * D + c];
         }
-        if (pro->mode != MODE_MARG && ((ka < 6 && v.frame_fixed[v.prior_frames[ia]]) || (kc < 6 && v.frame_fixed[v.prior_frames[ic]]))) h = 0.0;
+        if (!marg && ((ka < 6 && v.frame_fixed[v.prior_frames[b]]) || (kc < 6 && v.frame_fixed[v.prior_frames[ic]]))) h = 0.0;
         v.prior_H[(size_t)a * D + c] = h;
     }
+    (void)nb;
 }
 
 // a plane workgroup that has nothing to do in this mode still owns a partial row k_reduce will sum
@@ -735,7 +726,48 @@ struct DenseShared {
     double x_cost_new;
 };
 
-constexpr int kPanel = 8; // Cholesky panel width
+// per-landmark back-substitution for landmarks l = first, first + stride, ...; vs / ys = C_p v_p, C_p y'_p (any memory)
+__device__ __forceinline__ void backsub_landmarks(const View &v, int lin, double mu, const double *vs, const double *ys, int first, int stride, double *s) {
+    const int M = v.dm.M, d = v.dm.d;
+    const size_t Ms = (size_t)M, Fs = (size_t)v.dm.F;
+    const double *Hll = v.Hll + lin * Ms, *bl = v.bl + lin * Ms, *Dl = v.Dl + lin * Ms, *ghl = v.ghl + lin * Ms;
+    const double *Wa = v.Wa + lin * Ms * 6, *Wt = v.Wt + lin * Fs * 6;
+    double *gnl = v.gnl + lin * Ms;
+    for (int l = first; l < M; l += stride) {
+        const int o0 = v.lm_ptr[l], o1 = v.lm_ptr[l + 1];
+        if (o1 == o0) {
+            gnl[l] = 0.0;
+            continue;
+        }
+        const int a = v.lm_anchor[l];
+        double Wv = 0, Wy = 0; // W_l . (C_p v_p), W_l . (C_p y'_p)
+        for (int k = 0; k < 6; ++k) Wv += Wa[(size_t)l * 6 + k] * vs[d * a + k], Wy += Wa[(size_t)l * 6 + k] * ys[d * a + k];
+        for (int o = o0; o < o1; ++o) {
+            const int t = v.obs_frame[o];
+            for (int k = 0; k < 6; ++k) Wv += Wt[(size_t)o * 6 + k] * vs[d * t + k], Wy += Wt[(size_t)o * 6 + k] * ys[d * t + k];
+        }
+        const double cl = v.cl[l], D = Dl[l], gh = ghl[l];
+        const double Hs = cl * cl * Hll[l], A = Hs + mu * D * D;
+        const double w = cl * cl / A;
+        const double yl = -cl * (bl[l] + Wy) / A; // y'_l
+        const double vl = gh / D;
+        const double gn = D * yl;
+        gnl[l] = gn;
+        s[0] += gn * gn;
+        s[1] += gh * gn;
+        s[2] += w * Wv * Wv + 2 * cl * vl * Wv + Hs * vl * vl;                          // v^T H v (landmark + add-back)
+        s[3] += w * Wv * Wy + cl * vl * Wy + cl * yl * Wv + Hs * vl * yl;               // v^T H y'
+        s[4] += w * Wy * Wy + 2 * cl * yl * Wy + Hs * yl * yl;                          // y'^T H y'
+        s[5] += cl * bl[l] * yl;                                                        // g_s^T y'
+    }
+}
+
+constexpr int kPanel = 8; // Cholesky panel width (= K of two f64 MFMAs)
+#ifdef PV_HIPEMU
+typedef hipemu_double4 mfma_d4;
+#else
+typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+#endif
 
 template <bool LDSMAT> // compile-time storage choice: a runtime LDS-or-global pointer select degrades every access to FLAT
 __global__ void __launch_bounds__(kDenseThreads) k_dense(View v) {
@@ -758,7 +790,8 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(View v) {
     double *A = LDSMAT ? vec + 8 * (size_t)ld : v.Smat;
     double *diagH = vec, *gtot = vec + ld, *rhs = vec + 2 * ld, *yv = vec + 3 * ld, *vv = vec + 4 * ld, *act = vec + 5 * ld, *tmp = vec + 6 * ld,
            *cpl = vec + 7 * ld;
-    auto IDX = [](int i, int k) -> size_t { return (size_t)i * (i + 1) / 2 + k; }; // k <= i
+    auto IDX = [](int i, int k) -> int { return ((i * (i + 1)) >> 1) + k; }; // k <= i; 32-bit: P <= 512 -> < 2^18
+    double *ysol = rhs; // solution of the reduced system (rhs is dead once the augmented row has been written)
     const int tx = tid & 31, ty = tid >> 5, ny = nthr >> 5;
 
     PV_STAMP(2, 0);
@@ -771,7 +804,7 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(View v) {
         if (lr != LIN_INVALID_STEP) {
             for (int j = 1; j < N; ++j)
                 if (v.dm.G_pre && v.pre_valid[j]) aux_cost += v.pre_cost[j];
-            if (v.dm.prior_n > 0) aux_cost += v.prior_cost[0];
+            for (int i = 0; i < v.dm.prior_n; ++i) aux_cost += v.prior_cost[i];
         }
         const double lm_cost = redS[0], lm_bad = redS[5];
         double total_cost = aux_cost + lm_cost;
@@ -857,8 +890,8 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(View v) {
             act[a] = (k < 6 ? v.pose_active[f] : v.motion_active[f]) ? 1.0 : 0.0;
             diagH[a] = dg, gtot[a] = g, rhs[a] = g - rs; // rhs_u = g_total - sum_l w_l W_l^T b_l
         }
-        const size_t npk = IDX(P, P) + 1;
-        for (size_t e = tid; e < npk; e += nthr) A[e] = 0.0;
+        const int npk = IDX(P, P) + 1;
+        for (int e = tid; e < npk; e += nthr) A[e] = 0.0;
         __syncthreads();
         // landmark + plane tiles (upper block triangle, element-major) -> lower triangle of A
         for (size_t e = tid; e < nS; e += nthr) {
@@ -1089,32 +1122,42 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(View v) {
             for (int cc = 0; cc < kPanel; ++cc)
                 if (cc < nb && j0 + cc <= irow) A[IDX(irow, j0 + cc)] = x[cc];
         }
-        // rank-nb update of the trailing lower triangle.  Loads are batched ahead of the stores (4 columns per lane and
-        // round) -- an LDS read-modify-write loop would serialize on every store.
-        for (int i = k0 + ty; i <= P; i += ny) {
-            double li[kPanel];
+        // rank-nb update of the trailing lower triangle on the matrix cores: C(16x16 tile) -= Lp_i (16 x 8) Lp_k^T, two
+        // v_mfma_f64_16x16x4_f64 per tile.  Operand layout (cdna_hip_programming.md section 3, f64): lane l supplies
+        // A[l & 15][l >> 4] and B[l >> 4][l & 15]; it receives D[(l >> 4) + 4 r][l & 15], r = 0..3.  Per tile a lane
+        // does 4 + 4 LDS loads and <= 4 stores for 32 FMAs; the VALU form was LDS-read bound at ~1 load per FMA.
+        {
+            const int wv = tid >> 6, lane = tid & 63, nwave = nthr >> 6;
+            const int TR = (P + 1 - k0 + 15) >> 4, TC = (P - k0 + 15) >> 4; // row blocks (incl. the rhs row), column blocks
+            const int lr = lane & 15, lk = lane >> 4;
+            int t = 0;
+            for (int bi = 0; bi < TR; ++bi) {
+                const int bkmax = bi < TC ? bi : TC - 1;
+                for (int bk = 0; bk <= bkmax; ++bk, ++t) {
+                    if (t % nwave != wv) continue;
+                    const int i0 = k0 + 16 * bi, c0 = k0 + 16 * bk;
+                    const int ra = i0 + lr, rb = c0 + lr;
+                    const int pa = IDX(ra <= P ? ra : P, j0), pb = IDX(rb < P ? rb : P - 1, j0); // clamped: always in bounds
+                    const double a0 = (ra <= P && lk < nb) ? -A[pa + lk] : 0.0;
+                    const double a1 = (ra <= P && 4 + lk < nb) ? -A[pa + 4 + lk] : 0.0;
+                    const double b0 = (rb < P && lk < nb) ? A[pb + lk] : 0.0;
+                    const double b1 = (rb < P && 4 + lk < nb) ? A[pb + 4 + lk] : 0.0;
+                    mfma_d4 cacc;
+                    const int ck = c0 + lr;
+                    bool ok[4];
+                    int pc[4];
 #pragma unroll
-            for (int cc = 0; cc < kPanel; ++cc) li[cc] = cc < nb ? A[IDX(i, j0 + cc)] : 0.0;
-            const int kmax = i < P ? i : P - 1;
-            const size_t rowbase = IDX(i, 0);
-            for (int kb = k0 + tx; kb <= kmax; kb += 128) {
-                double aold[4], lk[4][kPanel];
+                    for (int r = 0; r < 4; ++r) {
+                        const int ci = i0 + lk + 4 * r;
+                        ok[r] = ci <= P && ck < P && ck <= ci;
+                        pc[r] = ok[r] ? IDX(ci, ck) : 0;
+                        cacc[r] = ok[r] ? A[pc[r]] : 0.0;
+                    }
+                    cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, cacc, 0, 0, 0);
+                    cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, cacc, 0, 0, 0);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int k = kb + 32 * q;
-                    const bool ok = k <= kmax;
-                    aold[q] = ok ? A[rowbase + k] : 0.0;
-                    const double *Lk = A + IDX(ok ? k : kmax, j0);
-#pragma unroll
-                    for (int cc = 0; cc < kPanel; ++cc) lk[q][cc] = Lk[cc < nb ? cc : 0];
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int k = kb + 32 * q;
-                    double sacc = 0;
-#pragma unroll
-                    for (int cc = 0; cc < kPanel; ++cc) sacc += cc < nb ? li[cc] * lk[q][cc] : 0.0;
-                    if (k <= kmax) A[rowbase + k] = aold[q] - sacc;
+                    for (int r = 0; r < 4; ++r)
+                        if (ok[r]) A[pc[r]] = cacc[r];
                 }
             }
         }
@@ -1137,59 +1180,43 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(View v) {
         block_sum<1>(s1, red_scratch);
         if (tid == 0) c->pose_qyy = s1[0]; // y^T (S + mu D^2) y = |z|^2 ; the mu term is removed below
         __syncthreads();
-        if (tid < 64) {
-            // lane owns rows a = lane + 64 q (q < 8 -> P <= 512) in REGISTERS; per column: one readlane broadcast,
-            // the row of L is read ahead of the dependency chain
-            double yr[8], ir[8];
+        // blocked backward solve L^T y = z, 8 columns per step, all threads: every thread solves the 8 x 8 triangular
+        // block redundantly in registers (no communication), then the rows above the block are updated in parallel
+        // (column access of packed rows is contiguous).  One barrier per block.
+        for (int jb = ((P - 1) / kPanel) * kPanel; jb >= 0; jb -= kPanel) {
+            const int nb = min(kPanel, P - jb);
+            double Ld[kPanel][kPanel], yb[kPanel];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int a = tid + 64 * q;
-                yr[q] = a < P ? yv[a] : 0.0;
-                ir[q] = a < P ? tmp[a] : 0.0;
-            }
-            // the row of L needed by column j is prefetched one column ahead (it does not depend on y)
-            double Lrow[8];
+            for (int r = 0; r < kPanel; ++r) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int a = tid + 64 * q;
-                Lrow[q] = a < P - 1 ? A[IDX(P - 1, a)] : 0.0;
-            }
-            for (int j = P - 1; j >= 0; --j) {
-                const int owner = j & 63, qj = j >> 6;
-                double Lcur[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) Lcur[q] = Lrow[q];
-                if (j > 0) {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const int a = tid + 64 * q;
-                        Lrow[q] = (q <= ((j - 1) >> 6) && a < j - 1) ? A[IDX(j - 1, a)] : 0.0;
-                    }
-                }
-                double cand = 0;
-#pragma unroll
-                for (int q = 0; q < 8; ++q) cand = (q == qj) ? yr[q] * ir[q] : cand;
-                const double yj = readlane_f64(cand, owner);
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int a = tid + 64 * q;
-                    if (q == qj && tid == owner) yr[q] = yj;
-                    else if (a < j) yr[q] -= Lcur[q] * yj;
-                }
+                for (int cc = 0; cc < r; ++cc) Ld[r][cc] = (r < nb) ? A[IDX(jb + r, jb + cc)] : 0.0;
+                yb[r] = r < nb ? yv[jb + r] : 0.0;
+                Ld[r][r] = r < nb ? tmp[jb + r] : 0.0; // 1 / L_rr
             }
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int a = tid + 64 * q;
-                if (a < P) yv[a] = yr[q];
+            for (int cc = kPanel - 1; cc >= 0; --cc) {
+                double t = yb[cc];
+#pragma unroll
+                for (int r = cc + 1; r < kPanel; ++r) t -= Ld[r][cc] * yb[r];
+                yb[cc] = t * Ld[cc][cc];
             }
+#pragma unroll
+            for (int cc = 0; cc < kPanel; ++cc)
+                if (tid == cc && cc < nb) ysol[jb + cc] = yb[cc];
+            for (int a = tid; a < jb; a += nthr) {
+                double acc2 = 0;
+#pragma unroll
+                for (int cc = 0; cc < kPanel; ++cc) acc2 += cc < nb ? A[IDX(jb + cc, a)] * yb[cc] : 0.0;
+                yv[a] -= acc2;
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
     PV_STAMP(2, 6);
     // ---------------- outputs ----------------
     double nbad = 0;
     if (!sh_fail)
-        for (int a = tid; a < P; a += nthr) nbad += isfinite(yv[a]) ? 0.0 : 1.0;
+        for (int a = tid; a < P; a += nthr) nbad += isfinite(ysol[a]) ? 0.0 : 1.0;
     {
         double sb[1] = {nbad};
         block_sum<1>(sb, red_scratch);
@@ -1220,7 +1247,7 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(View v) {
     {
         double s_g2 = 0, s_gn2 = 0, s_gd = 0, s_qvy = 0, s_gy = 0;
         for (int a = tid; a < P; a += nthr) {
-            const double yp = act[a] != 0.0 ? -yv[a] : 0.0;
+            const double yp = act[a] != 0.0 ? -ysol[a] : 0.0;
             const double Da = v.Dp[a], gh = v.ghp[a], gn = Da * yp;
             v.ystep[a] = cpl[a] * yp;
             v.vstep[a] = act[a] != 0.0 ? cpl[a] * vv[a] : 0.0;
@@ -1236,6 +1263,23 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(View v) {
             c->pose_qyy = c->pose_qyy - mu * sc[1];
         }
     }
+    if (v.dm.fuse_backsub) {
+        // small windows: the landmark back-substitution runs right here (one launch less per iteration); the step
+        // vectors are taken from LDS copies
+        for (int a = tid; a < P; a += nthr) {
+            const double yp = act[a] != 0.0 ? -ysol[a] : 0.0;
+            tmp[a] = act[a] != 0.0 ? cpl[a] * vv[a] : 0.0; // C_p v_p
+            yv[a] = cpl[a] * yp;                           // C_p y'_p
+        }
+        __syncthreads();
+        double sb[6] = {0, 0, 0, 0, 0, 0};
+        backsub_landmarks(v, c->lin, mu, tmp, yv, tid, nthr, sb);
+        block_sum<6>(sb, red_scratch);
+        if (tid == 0) {
+            for (int k = 0; k < 6; ++k) v.back_part[k] = sb[k];
+            v.back_part[6] = v.back_part[7] = 0;
+        }
+    }
     PV_STAMP(2, 7);
     if (v.dbg && threadIdx.x == 0) v.dbg[2 * 32 + 31] = wall_clock64();
 }
@@ -1247,40 +1291,8 @@ __global__ void __launch_bounds__(256) k_backsub(View v) {
     const Ctrl *c = v.ctrl;
     if (c->done || !c->solve_ok) return;
     __shared__ double scratch[6 * 16];
-    const int M = v.dm.M, d = v.dm.d, lin = c->lin;
-    const size_t Ms = (size_t)M, Fs = (size_t)v.dm.F;
-    const double *Hll = v.Hll + lin * Ms, *bl = v.bl + lin * Ms, *Dl = v.Dl + lin * Ms, *ghl = v.ghl + lin * Ms;
-    const double *Wa = v.Wa + lin * Ms * 6, *Wt = v.Wt + lin * Fs * 6;
-    double *gnl = v.gnl + lin * Ms;
-    const double mu = c->mu;
     double s[6] = {0, 0, 0, 0, 0, 0};
-    for (int l = blockIdx.x * blockDim.x + threadIdx.x; l < M; l += gridDim.x * blockDim.x) {
-        const int o0 = v.lm_ptr[l], o1 = v.lm_ptr[l + 1];
-        if (o1 == o0) {
-            gnl[l] = 0.0;
-            continue;
-        }
-        const int a = v.lm_anchor[l];
-        double Wv = 0, Wy = 0; // W_l . (C_p v_p), W_l . (C_p y'_p)   (vstep / ystep already carry C_p)
-        for (int k = 0; k < 6; ++k) Wv += Wa[(size_t)l * 6 + k] * v.vstep[d * a + k], Wy += Wa[(size_t)l * 6 + k] * v.ystep[d * a + k];
-        for (int o = o0; o < o1; ++o) {
-            const int t = v.obs_frame[o];
-            for (int k = 0; k < 6; ++k) Wv += Wt[(size_t)o * 6 + k] * v.vstep[d * t + k], Wy += Wt[(size_t)o * 6 + k] * v.ystep[d * t + k];
-        }
-        const double cl = v.cl[l], D = Dl[l], gh = ghl[l];
-        const double Hs = cl * cl * Hll[l], A = Hs + mu * D * D;
-        const double w = cl * cl / A;
-        const double yl = -cl * (bl[l] + Wy) / A; // y'_l
-        const double vl = gh / D;
-        const double gn = D * yl;
-        gnl[l] = gn;
-        s[0] += gn * gn;
-        s[1] += gh * gn;
-        s[2] += w * Wv * Wv + 2 * cl * vl * Wv + Hs * vl * vl;                          // v^T H v (landmark + add-back)
-        s[3] += w * Wv * Wy + cl * vl * Wy + cl * yl * Wv + Hs * vl * yl;               // v^T H y'
-        s[4] += w * Wy * Wy + 2 * cl * yl * Wy + Hs * yl * yl;                          // y'^T H y'
-        s[5] += cl * bl[l] * yl;                                                        // g_s^T y'
-    }
+    backsub_landmarks(v, c->lin, c->mu, v.vstep, v.ystep, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x, s);
     block_sum<6>(s, scratch);
     if (threadIdx.x == 0) {
         double *row = v.back_part + (size_t)blockIdx.x * kNumBackScal;
@@ -1388,7 +1400,7 @@ size_t linearize_lds_bytes(const Dims &dm) {
     size_t lm = (size_t)dm.lm_slots * (40 * N + 46) + dm.lm_slots + 2 * ((dm.lm_slots + 1) / 2) + 4;
     size_t pl = (size_t)dm.plane_slots * (dm.P6 + 2);
     size_t pre = 16 + 450 + 450 + 16;
-    size_t pri = (size_t)dm.prior_n * (15 + 9 + 15) + 8;
+    size_t pri = (size_t)dm.prior_n * (15 + 9) + 40;
     size_t role = lm;
     if (pl > role) role = pl;
     if (pre > role) role = pre;

@@ -188,9 +188,10 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st) {
     dm.G_lm = std::max(1, std::min(dm.n_chunks, cus));
     dm.G_plane = dm.n_plane > 0 ? std::max(1, std::min(dm.n_plane_chunks, std::max(1, cus / 4))) : 0;
     dm.G_pre = dm.use_inertial ? N - 1 : 0;
-    dm.G_prior = dm.prior_n > 0 ? std::max(1, std::min(16, (15 * dm.prior_n + 31) / 32)) : 0;
+    dm.G_prior = dm.prior_n; // one workgroup per prior frame
     dm.G_back = std::max(1, std::min(64, (M + 255) / 256));
-    dm.n_back_rows = world_ > 1 ? 1 : dm.G_back;
+    dm.fuse_backsub = (world_ == 1 && M <= 4096) ? 1 : 0;
+    dm.n_back_rows = (world_ > 1 || dm.fuse_backsub) ? 1 : dm.G_back;
 
     // 3x3 tile tasks over the upper block triangle
     std::vector<int32_t> task_desc;
@@ -267,7 +268,7 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st) {
     ok &= dev(pool_, "pre_cost", Ns, &v.pre_cost, &grew);
     ok &= dev(pool_, "prior_H", Dp * Dp, &v.prior_H, &grew);
     ok &= dev(pool_, "prior_g", Dp, &v.prior_g, &grew);
-    ok &= dev(pool_, "prior_cost", 1, &v.prior_cost, &grew);
+    ok &= dev(pool_, "prior_cost", (size_t)std::max(dm.prior_n, 1), &v.prior_cost, &grew);
     const size_t P = dm.P;
     ok &= dev(pool_, "Smat", (P + 1) * (P + 1), &v.Smat, &grew);
     ok &= dev(pool_, "cp", P, &v.cp, &grew);
@@ -321,7 +322,7 @@ int BASolver::enqueue_slot(hipEvent_t *ev) {
     if (ev) (void)hipEventRecord(ev[3], stream_);
     if ((e = launch_dense(v_, stream_)) != hipSuccess) return check(e, "k_dense");
     if (ev) (void)hipEventRecord(ev[4], stream_);
-    if ((e = launch_backsub(v_, stream_)) != hipSuccess) return check(e, "k_backsub");
+    if (!v_.dm.fuse_backsub && (e = launch_backsub(v_, stream_)) != hipSuccess) return check(e, "k_backsub");
     if (ev) (void)hipEventRecord(ev[5], stream_);
     if (world_ > 1) {
         double *back_local = static_cast<double *>(pool_.get("back_local", kNumBackScal * sizeof(double)));

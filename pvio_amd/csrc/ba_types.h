@@ -83,6 +83,8 @@ struct Dims {
     int32_t G_back;
     int32_t n_back_rows;  // rows of back partials k_linearize must sum (G_back, or 1 after an all-reduce)
     int32_t world, rank;
+    int32_t fuse_backsub; // landmark back-substitution inside k_dense (small windows, single GPU)
+    int32_t pad_;
 };
 
 struct View { // passed by value to every kernel
