@@ -7,6 +7,7 @@
 namespace pvba {
 size_t linearize_lds_bytes(const Dims &dm);
 size_t dense_lds_bytes(const Dims &dm, int *lds_matrix);
+size_t dense_tile_doubles(const Dims &dm);
 int tiles_per_thread(const Dims &dm);
 hipError_t launch_linearize(const View &v, hipStream_t st);
 hipError_t launch_reduce(const View &v, hipStream_t st);

@@ -23,6 +23,7 @@
 // Reference being replaced: BundleAdjustorSolver::solve -> ceres::Solve (bundle_adjustor.cpp:63-299,
 // solver_options.h:26-33); factor math in pv_factors.h.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 
 #include <float.h>
 
@@ -38,6 +39,16 @@ using namespace pv;
     do {                                                                                         \
         if (v.dbg && blockIdx.x == 0 && threadIdx.x == 0) v.dbg[(kern)*32 + (idx)] = clock64(); \
     } while (0)
+
+#ifdef PV_HIPEMU
+#define PV_STAMPV(kern, idx, var) PV_STAMP(kern, idx)
+#else
+#define PV_STAMPV(kern, idx, var)                 \
+    do {                                          \
+        asm volatile("" : "+v"(var));            \
+        PV_STAMP(kern, idx);                      \
+    } while (0)
+#endif
 
 // ------------------------------------------------------------------------------------------------------
 // small reductions
@@ -765,9 +776,161 @@ __device__ __forceinline__ void backsub_landmarks(const View &v, int lin, double
 constexpr int kPanel = 8; // Cholesky panel width (= K of two f64 MFMAs)
 #ifdef PV_HIPEMU
 typedef hipemu_double4 mfma_d4;
+typedef double lds_d2 __attribute__((vector_size(16)));
 #else
 typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+typedef double lds_d2 __attribute__((ext_vector_type(2)));
 #endif
+
+// The reduced system lives in LDS as 16 x 16 tiles of the lower block triangle (tile (bi, bk), bk <= bi, at
+// (bi (bi + 1) / 2 + bk) * 256 doubles).  Inside a tile the elements are in MFMA accumulator order: lane l of a wave owns
+// D[(l >> 4) + 4 r][l & 15], r = 0..3, as four consecutive doubles, so a trailing update moves a tile with two 16-byte
+// loads and two 16-byte stores per lane.  Entries that are not yet factored are stored NEGATED (the update is then a plain
+// multiply-accumulate, no operand negation); finished L entries are stored as they are.
+__device__ __forceinline__ int tile_base(int bi, int bk) { return (((bi * (bi + 1)) >> 1) + bk) << 8; }
+__device__ __forceinline__ int tile_off(int r, int c) { return ((((r & 3) << 4) + c) << 2) + (r >> 2); }
+__device__ __forceinline__ int mat_at(int i, int k) { return tile_base(i >> 4, k >> 4) + tile_off(i & 15, k & 15); } // k <= i
+
+// Builds the scaled reduced system S_s = C (H_pp - sum_l w_l W_l W_l^T) C in the tile image A (negated, see above): unit
+// rows for inactive coordinates, identity in the panel padding, the scaled rhs in row Pp, zeros above it.  The sources
+// (landmark / plane tiles of `red`, IMU factor blocks, marginalization prior) are swept in THEIR memory order, so every
+// global load is coalesced and all of them are in flight together -- gathering per matrix entry instead costs one L2
+// request per lane and load (measured 26 us for the 150 x 150 system against ~3 us for this form).  Terms are added in a
+// fixed order (tiles, odd IMU factors, even IMU factors, prior); passes that touch the same entries are separated by
+// barriers.  cm[a] = Jacobi scale of coordinate a, 0 if inactive.
+#ifdef PV_HIPEMU
+#define PV_KEEP(x) (void)(x)
+#else
+#define PV_KEEP(x) asm volatile("" : "+v"(x)) // the value is needed HERE: keeps its load unconditional and where it was written
+#endif
+// flags[j] = IMU factor j is present, pframe[q] = frame of prior slot q (both in LDS)
+__device__ __forceinline__ void dense_build(const View &v, double *A, const double *cm, const double *rhs_s, const int *flags, const int *pframe, int P, int Pp, int nbk) {
+    const int tid = threadIdx.x, N = v.dm.N, d = v.dm.d, n_tasks = v.dm.n_tasks;
+    constexpr int nthr = kDenseThreads;
+    // (one wave per SIMD: the VALU instruction count of these passes is what they cost, so index arithmetic is hoisted)
+    { // pass 0: zero fill, 16 bytes per store (the tile image is contiguous)
+        const int nd2 = (nbk * (nbk + 1)) << 6; // tiles * 256 / 2
+        lds_d2 z;
+        z[0] = 0.0, z[1] = 0.0;
+        lds_d2 *A2 = reinterpret_cast<lds_d2 *>(A);
+        for (int e = tid; e < nd2; e += nthr) A2[e] = z;
+    }
+    __syncthreads();
+    PV_STAMP(2, 24);
+    // pass 0b: unit diagonal of inactive / padding coordinates, scaled rhs in row Pp
+    for (int a = tid; a < Pp; a += nthr) {
+        if (a < P) A[mat_at(Pp, a)] = -rhs_s[a];
+        if (a < P ? cm[a] == 0.0 : true) A[mat_at(a, a)] = -1.0;
+    }
+    PV_STAMP(2, 25);
+    // pass 1: landmark + plane tiles (upper block triangle, element-major) -> lower triangle; one plain store per entry
+    for (int t = tid; t < n_tasks; t += nthr) {
+        int fi, fj, si, sj;
+        unpack_task(v.task_desc[t], fi, fj, si, sj);
+        double h[9];
+#pragma unroll
+        for (int el = 0; el < 9; ++el) h[el] = v.red[(size_t)el * n_tasks + t];
+        const int r0 = d * fi + 3 * si, c0 = d * fj + 3 * sj; // fi <= fj => r0 <= c0
+        double cr[3], cc3[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) cr[q] = cm[r0 + q], cc3[q] = cm[c0 + q];
+#pragma unroll
+        for (int el = 0; el < 9; ++el) {
+            const int r_ = r0 + el / 3, c_ = c0 + el % 3;
+            const int row = fi != fj ? c_ : r_, col = fi != fj ? r_ : c_; // diagonal blocks come in full: keep the lower half
+            const double sc = cr[el / 3] * cc3[el % 3];
+            if (row >= col && sc != 0.0) A[mat_at(row, col)] = -(h[el] * sc);
+        }
+    }
+    __syncthreads();
+    PV_STAMP(2, 26);
+    if (d == 15) {
+        if (v.dm.G_pre) {
+            // IMU factor j couples frames j - 1 (local 0..14) and j (local 15..29); consecutive factors overlap on a
+            // diagonal block -> odd factors, then even factors.  A thread keeps the same (a, b) entries for every factor.
+            int ea[4], eb[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int el = tid + m * nthr, a = el / 30, b = el - 30 * a;
+                ea[m] = (el < 900 && a >= b) ? a : -1, eb[m] = b;
+            }
+            // Each step is staged so that no LDS round trip waits on another: all loads (global + scales), then all
+            // reads of the target entries (unconditional, in-range), then the predicated stores.
+            for (int par = 0; par < 2; ++par) {
+                for (int j0 = 1 + par; j0 < N; j0 += 4) { // two factors of this parity per step
+                    const int j1 = j0 + 2 < N ? j0 + 2 : j0;
+                    const bool on0 = flags[j0] != 0, on1 = j0 + 2 < N && flags[j1] != 0;
+                    if (!on0 && !on1) continue;
+                    const double *H0 = v.pre_H + (size_t)j0 * 900 + tid, *H1 = v.pre_H + (size_t)j1 * 900 + tid;
+                    double h[8], sc[8], cur[8];
+                    int at[8];
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        const int o = tid + m * nthr < 900 ? m * nthr : 0;
+                        h[m] = H0[o], h[4 + m] = H1[o];
+                        const int am = ea[m] >= 0 ? ea[m] : 0, bm = ea[m] >= 0 ? eb[m] : 0;
+                        const int r0 = 15 * (j0 - 1) + am, c0 = 15 * (j0 - 1) + bm, r1 = 15 * (j1 - 1) + am, c1 = 15 * (j1 - 1) + bm;
+                        sc[m] = cm[r0] * cm[c0], sc[4 + m] = cm[r1] * cm[c1];
+                        at[m] = mat_at(r0, c0), at[4 + m] = mat_at(r1, c1);
+                    }
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) cur[m] = A[at[m]];
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) {
+                        PV_KEEP(h[m]);
+                        PV_KEEP(cur[m]);
+                    }
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        if (ea[m] >= 0 && on0 && sc[m] != 0.0) A[at[m]] = cur[m] - h[m] * sc[m];
+                        if (ea[m] >= 0 && on1 && sc[4 + m] != 0.0) A[at[4 + m]] = cur[4 + m] - h[4 + m] * sc[4 + m];
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        PV_STAMP(2, 27);
+        if (v.dm.prior_n > 0) {
+            // prior block (slot qa, slot qb): 15 x 15 entries, thread = one (a, b) of every block; only entries on or
+            // below the diagonal of the reduced system contribute; same staging, kFly entries per step
+            constexpr int kFly = 8;
+            const int n = v.dm.prior_n, D = 15 * n;
+            const int a = tid / 15, b = tid - 15 * a;
+            if (tid < 225) {
+                for (int qa = 0; qa < n; ++qa) {
+                    const int fa = pframe[qa], ga = 15 * fa + a;
+                    const double ca = cm[ga];
+                    const double *Hrow = v.prior_H + (size_t)(15 * qa + a) * D + b;
+                    for (int qb0 = 0; qb0 < n; qb0 += kFly) {
+                        double h[kFly], sc[kFly], cur[kFly];
+                        int at[kFly];
+                        bool ok[kFly];
+#pragma unroll
+                        for (int u = 0; u < kFly; ++u) {
+                            const int qb = qb0 + u < n ? qb0 + u : n - 1;
+                            h[u] = Hrow[15 * qb];
+                            const int gb = 15 * pframe[qb] + b;
+                            ok[u] = qb0 + u < n && ga >= gb;
+                            sc[u] = ca * cm[gb];
+                            at[u] = ga >= gb ? mat_at(ga, gb) : mat_at(gb, ga);
+                        }
+#pragma unroll
+                        for (int u = 0; u < kFly; ++u) cur[u] = A[at[u]];
+#pragma unroll
+                        for (int u = 0; u < kFly; ++u) {
+                            PV_KEEP(h[u]);
+                            PV_KEEP(cur[u]);
+                        }
+#pragma unroll
+                        for (int u = 0; u < kFly; ++u)
+                            if (ok[u] && sc[u] != 0.0) A[at[u]] = cur[u] - h[u] * sc[u];
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
 
 template <bool LDSMAT> // compile-time storage choice: a runtime LDS-or-global pointer select degrades every access to FLAT
 __global__ void __launch_bounds__(kDenseThreads) k_dense(View v) {
@@ -775,27 +938,54 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(View v) {
     HIP_DYNAMIC_SHARED(double, lds)
     Ctrl *c = v.ctrl;
     if (c->done) return;
-    const int N = v.dm.N, d = v.dm.d, P = v.dm.P, P6 = v.dm.P6, tid = threadIdx.x, nthr = blockDim.x;
-    const int n_tasks = v.dm.n_tasks;
-    const size_t nS = (size_t)n_tasks * 9;
+    const int N = v.dm.N, d = v.dm.d, P = v.dm.P, P6 = v.dm.P6, tid = threadIdx.x;
+    constexpr int nthr = kDenseThreads;
+    const size_t nS = (size_t)v.dm.n_tasks * 9;
     const double *redV = v.red + nS, *redS = v.red + nS + (size_t)kNumPoseVec * P6;
-    // dynamic LDS: [header 128][8 vectors of P+1][A: packed lower triangle of the (P+1) x (P+1) augmented matrix]
-    // (no static LDS: keeps the dynamic base 16-byte aligned, cdna_hip_programming.md Guideline 17).  Row P of A is
-    // the right-hand side, so the factorization performs the forward substitution on the fly.
+    // dynamic LDS: [header 224][8 vectors of LDV][Lp: panel, LDV x 8][A: tiles]   (no static LDS: keeps the dynamic base
+    // 16-byte aligned, cdna_hip_programming.md Guideline 17).  Row Pp of A is the right-hand side, so the factorization
+    // performs the forward substitution on the fly; rows above it are zero padding.
     DenseShared &sh = *reinterpret_cast<DenseShared *>(lds);
     double *red_scratch = lds + 16; // 6 * 16 doubles
     int &sh_fail = *reinterpret_cast<int *>(lds + 120);
-    const int ld = P + 1;
-    double *vec = lds + 128;
-    double *A = LDSMAT ? vec + 8 * (size_t)ld : v.Smat;
-    double *diagH = vec, *gtot = vec + ld, *rhs = vec + 2 * ld, *yv = vec + 3 * ld, *vv = vec + 4 * ld, *act = vec + 5 * ld, *tmp = vec + 6 * ld,
-           *cpl = vec + 7 * ld;
-    auto IDX = [](int i, int k) -> int { return ((i * (i + 1)) >> 1) + k; }; // k <= i; 32-bit: P <= 512 -> < 2^18
+    int *pslot = reinterpret_cast<int *>(lds + 121); // [N <= 32] frame -> prior slot (or -1), 16 doubles... see static_assert
+    static_assert(kMaxFrames <= 32, "pslot overlaps the LDS header");
+    const int Pp = (P + kPanel - 1) & ~(kPanel - 1); // system padded with identity rows to whole panels; the rhs is row Pp
+    const int nbk = (Pp + 16) >> 4, LDV = nbk << 4;   // tile rows incl. the rhs row
+    double *Dg = lds + 144; // packed lower triangle of the next 8 x 8 diagonal block (36 doubles)
+    int *pvalid = reinterpret_cast<int *>(lds + 184); // [N <= 32] IMU factor j present
+    int *pframe = reinterpret_cast<int *>(lds + 200); // [prior_n <= 32] frame of prior slot q
+    double *vec = lds + 224;
+    double *Lp = vec + 8 * (size_t)LDV;
+    double *A = LDSMAT ? Lp + 8 * (size_t)LDV : v.Smat;
+    double *diagH = vec, *gtot = vec + LDV, *rhs = vec + 2 * LDV, *yv = vec + 3 * LDV, *vv = vec + 4 * LDV, *act = vec + 5 * LDV,
+           *tmp = vec + 6 * LDV, *cpl = vec + 7 * LDV;
     double *ysol = rhs; // solution of the reduced system (rhs is dead once the augmented row has been written)
-    const int tx = tid & 31, ty = tid >> 5, ny = nthr >> 5;
 
     PV_STAMP(2, 0);
     if (v.dbg && threadIdx.x == 0) v.dbg[2 * 32 + 30] = wall_clock64();
+    // Touch everything the assembly reads, one load per 128-byte line: the sources were produced on other XCDs and a first
+    // touch costs a trip through the fabric -- paid once here, all lines in flight, overlapped with the control section.
+    double pf = 0;
+    {
+        const size_t nR = nS + (size_t)kNumPoseVec * P6 + kNumLinScal;
+#pragma unroll 4
+        for (size_t e = (size_t)tid * 16; e < nR; e += (size_t)nthr * 16) pf += v.red[e];
+        if (d == 15) {
+            if (v.dm.G_pre) {
+                const size_t nH = (size_t)N * 900, nG = (size_t)N * 30;
+#pragma unroll 4
+                for (size_t e = (size_t)tid * 16; e < nH; e += (size_t)nthr * 16) pf += v.pre_H[e];
+                for (size_t e = (size_t)tid * 16; e < nG; e += (size_t)nthr * 16) pf += v.pre_g[e];
+            }
+            if (v.dm.prior_n > 0) {
+                const size_t D15 = 15 * (size_t)v.dm.prior_n, nH = D15 * D15;
+#pragma unroll 4
+                for (size_t e = (size_t)tid * 16; e < nH; e += (size_t)nthr * 16) pf += v.prior_H[e];
+                if ((size_t)tid * 16 < D15) pf += v.prior_g[(size_t)tid * 16];
+            }
+        }
+    }
     // ---------------- control (thread 0): Finalize the iteration in flight, decide what comes next ----------------
     if (tid == 0) {
         const int lr = c->lin_result;
@@ -880,64 +1070,44 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(View v) {
         return;
     }
     PV_STAMP(2, 1);
+    if (pf == 1.2345678901234567e301) v.vstep[0] = pf; // keeps the prefetch loads alive (never true for finite data)
     const bool need_build = sh.accepted || sh.do_solve; // a new accepted linearization (or RELIN) is in `red`
-    // ---------------- assemble the unscaled totals: diag(H), gradient, Schur rhs, lower triangle ----------------
+    // ---------------- assemble the unscaled vectors: diag(J^T J), gradient, Schur rhs ----------------
     if (need_build) {
+        if (tid < N) {
+            int slot = -1;
+            for (int q = 0; q < v.dm.prior_n; ++q)
+                if (v.prior_frames[q] == tid) slot = q;
+            pslot[tid] = slot;
+            pvalid[tid] = (v.dm.G_pre && v.pre_valid[tid]) ? 1 : 0;
+            if (tid < v.dm.prior_n) pframe[tid] = v.prior_frames[tid];
+        }
+        __syncthreads();
         for (int a = tid; a < P; a += nthr) {
-            const int f = a / d, k = a - d * f;
+            const int f = d == 15 ? a / 15 : a / 6, k = a - d * f;
             double dg = 0, g = 0, rs = 0;
             if (k < 6) dg = redV[2 * P6 + 6 * f + k], g = redV[6 * f + k], rs = redV[P6 + 6 * f + k];
+            double r = g - rs; // rhs_u = g_total - sum_l w_l W_l^T b_l
+            if (d == 15) {
+                if (v.dm.G_pre) {
+                    const int jA = f, jB = f + 1;
+                    const bool vA = jA >= 1 && v.pre_valid[jA], vB = jB < N && v.pre_valid[jB];
+                    const double hA = vA ? v.pre_H[(size_t)jA * 900 + (15 + k) * 31] : 0.0, gA = vA ? v.pre_g[(size_t)jA * 30 + 15 + k] : 0.0;
+                    const double hB = vB ? v.pre_H[(size_t)jB * 900 + k * 31] : 0.0, gB = vB ? v.pre_g[(size_t)jB * 30 + k] : 0.0;
+                    if (jA & 1) dg = (dg + hA) + hB, g = (g + gA) + gB, r = (r + gA) + gB;
+                    else dg = (dg + hB) + hA, g = (g + gB) + gA, r = (r + gB) + gA;
+                }
+                const int ps = pslot[f];
+                if (ps >= 0) {
+                    const int D = 15 * v.dm.prior_n, pa = 15 * ps + k;
+                    const double pg = v.prior_g[pa];
+                    dg += v.prior_H[(size_t)pa * D + pa], g += pg, r += pg;
+                }
+            }
             act[a] = (k < 6 ? v.pose_active[f] : v.motion_active[f]) ? 1.0 : 0.0;
-            diagH[a] = dg, gtot[a] = g, rhs[a] = g - rs; // rhs_u = g_total - sum_l w_l W_l^T b_l
-        }
-        const int npk = IDX(P, P) + 1;
-        for (int e = tid; e < npk; e += nthr) A[e] = 0.0;
-        __syncthreads();
-        // landmark + plane tiles (upper block triangle, element-major) -> lower triangle of A
-        for (size_t e = tid; e < nS; e += nthr) {
-            const int el = (int)(e / n_tasks), t = (int)(e - (size_t)el * n_tasks);
-            int fi, fj, si, sj;
-            unpack_task(v.task_desc[t], fi, fj, si, sj);
-            const int r = d * fi + 3 * si + el / 3, cc = d * fj + 3 * sj + el % 3;
-            if (fi != fj) A[IDX(cc, r)] = v.red[e];       // fi < fj  =>  r < cc
-            else if (r >= cc) A[IDX(r, cc)] = v.red[e];   // diagonal blocks come in full; keep the lower half
+            diagH[a] = dg, gtot[a] = g, rhs[a] = r;
         }
         __syncthreads();
-        if (d == 15) {
-            // IMU pre-integration blocks (30 x 30 on frames j-1, j); consecutive factors overlap -> one at a time
-            for (int par = 0; par < 2; ++par) { // factors of equal parity touch disjoint blocks
-                for (int e = tid; e < 900 * (N / 2 + 1); e += nthr) {
-                    const int j = 1 + par + 2 * (e / 900), el = e % 900;
-                    if (j >= N || !(v.dm.G_pre && v.pre_valid[j])) continue;
-                    const int a = el / 30, b = el - 30 * a;
-                    const double h = v.pre_H[(size_t)j * 900 + el];
-                    if (a >= b) A[IDX(15 * (j - 1) + a, 15 * (j - 1) + b)] += h;
-                    if (a == b) diagH[15 * (j - 1) + a] += h;
-                    if (b == 0) {
-                        const double g = v.pre_g[(size_t)j * 30 + a];
-                        gtot[15 * (j - 1) + a] += g, rhs[15 * (j - 1) + a] += g;
-                    }
-                }
-                __syncthreads();
-            }
-            if (v.dm.prior_n > 0) {
-                const int n = v.dm.prior_n, D = 15 * n;
-                for (int a = ty; a < D; a += ny) {
-                    const int ga = 15 * v.prior_frames[a / 15] + a % 15;
-                    for (int b = tx; b < D; b += 32) {
-                        const int gb = 15 * v.prior_frames[b / 15] + b % 15;
-                        if (ga >= gb) A[IDX(ga, gb)] += v.prior_H[(size_t)a * D + b];
-                    }
-                }
-                for (int a = tid; a < D; a += nthr) {
-                    const int ga = 15 * v.prior_frames[a / 15] + a % 15;
-                    diagH[ga] += v.prior_H[(size_t)a * D + a];
-                    gtot[ga] += v.prior_g[a];
-                    rhs[ga] += v.prior_g[a];
-                }
-                __syncthreads();
-            }
-        }
         // gradient_max_norm = max | x - (x (+) -g) | over the free blocks (ambient coordinates)
         double gm = 0;
         if (tid < N) {
@@ -1007,7 +1177,11 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(View v) {
     // ---------------- Jacobi scaling (once), dogleg diagonal, scaled system ----------------
     const bool first_scaling = !c->scaling_ready;
     const double mu = c->mu;
-    for (int a = tid; a < P; a += nthr) {
+    for (int a = tid; a < LDV; a += nthr) {
+        if (a >= P) {
+            vv[a] = 0.0, cpl[a] = 0.0, tmp[a] = 0.0, yv[a] = 0.0; // padding (act[] is only read below P)
+            continue;
+        }
         double cpa;
         if (first_scaling) {
             cpa = act[a] != 0.0 ? 1.0 / (1.0 + sqrt(diagH[a])) : 1.0; // jacobi_scaling = 1 / (1 + sqrt(col norm^2)), once
@@ -1015,201 +1189,556 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(View v) {
         } else {
             cpa = v.cp[a];
         }
-        cpl[a] = cpa;
+        cpl[a] = act[a] != 0.0 ? cpa : 0.0; // LDS copy: 0 marks an inactive coordinate
         const double d2 = cpa * cpa * diagH[a];
         const double Da = sqrt(fmin(fmax(d2, 1e-6), 1e32));
         v.Dp[a] = Da;
         const double gh = act[a] != 0.0 ? cpa * gtot[a] / Da : 0.0;
         v.ghp[a] = gh;
-        vv[a] = gh / Da;                                                // v = g^ / D
+        vv[a] = gh / Da;                                  // v = g^ / D
         tmp[a] = Da;
-        A[IDX(P, a)] = act[a] != 0.0 ? cpa * rhs[a] : 0.0;              // augmented row: scaled reduced rhs
+        yv[a] = act[a] != 0.0 ? cpa * rhs[a] : 0.0;       // scaled reduced rhs -> augmented row P
     }
+    for (int e = tid; e < 8 * LDV; e += nthr) Lp[e] = 0.0;
     __syncthreads();
-    for (int a = ty; a < P; a += ny) {
-        const double ca_ = cpl[a], aa = act[a];
-        for (int b = tx; b <= a; b += 32) {
-            double val = A[IDX(a, b)];
-            if (aa == 0.0 || act[b] == 0.0) val = (a == b) ? 1.0 : 0.0;
-            else val *= ca_ * cpl[b];
-            A[IDX(a, b)] = val;
-        }
-    }
-    __syncthreads();
-    // pose quadratic form with the Schur-reduced scaled matrix (mu D^2 not yet added): S v, 4 lanes per row
+    PV_STAMP(2, 21);
+    dense_build(v, A, cpl, yv, pvalid, pframe, P, Pp, nbk);
+    PV_STAMP(2, 22);
+    // pose quadratic form with the Schur-reduced scaled matrix (mu D^2 not yet added): v^T S v = sum S_ik v_i v_k
+    // (thread = one (row, column) of every tile; the vector S v itself is not needed: v^T S y' follows from the solve)
     {
+        const int r = tid >> 4, cc = tid & 15, off = tile_off(r, cc);
         double q = 0;
-        const int seg = tid & 3;
-        for (int a0 = 0; a0 < P; a0 += (nthr >> 2)) {
-            const int a = a0 + (tid >> 2);
-            double row = 0;
-            if (a < P)
-                for (int b = seg; b < P; b += 4) row += (b <= a ? A[IDX(a, b)] : A[IDX(b, a)]) * vv[b];
-            row += __shfl_xor(row, 1);
-            row += __shfl_xor(row, 2);
-            if (a < P && seg == 0) {
-                diagH[a] = row; // S v  (diagH is free from here on)
-                q += act[a] != 0.0 ? vv[a] * row : 0.0;
+        for (int bi = 0; bi < nbk; ++bi) {
+            const int i = 16 * bi + r;
+            const double vi = vv[i];
+            double qr = 0;
+            for (int bk = 0; bk <= bi; ++bk) {
+                const int k = 16 * bk + cc;
+                const double m = A[tile_base(bi, bk) + off]; // stored negated; strictly upper entries of diagonal tiles are 0
+                qr -= (i == k ? m : 2.0 * m) * vv[k];
             }
+            q += qr * vi;
         }
         double s1[1] = {q};
         block_sum<1>(s1, red_scratch);
         if (tid == 0) c->pose_qvv = s1[0];
     }
+    for (int a = tid; a < P; a += nthr) diagH[a] = yv[a]; // keep the scaled rhs (yv is reused by the back substitution)
+    PV_STAMP(2, 23);
     for (int a = tid; a < P; a += nthr)
-        if (act[a] != 0.0) A[IDX(a, a)] += mu * tmp[a] * tmp[a];
+        if (act[a] != 0.0) A[mat_at(a, a)] -= mu * tmp[a] * tmp[a];
+    __syncthreads();
+    if (tid < 36) { // first diagonal block, packed
+        int r = 0;
+        while (((r + 1) * (r + 2)) >> 1 <= tid) ++r;
+        Dg[tid] = -A[mat_at(r, tid - ((r * (r + 1)) >> 1))];
+    }
     __syncthreads();
     PV_STAMP(2, 4);
-    // ---------------- panel Cholesky (width 8), two barriers per panel ----------------
-    // Every thread factors the 8 x 8 diagonal block redundantly in registers (no communication), then the thread that
-    // owns row i turns its panel entries into L (row P = right-hand side -> forward substitution for free), then all
-    // threads apply the rank-8 update to the trailing lower triangle.
     int fail = 0;
-    for (int j0 = 0; j0 < P && !fail; j0 += kPanel) {
-        const int nb = min(kPanel, P - j0);
-        if (j0 == 0) PV_STAMP(2, 8);
-        double Ld[kPanel][kPanel], inv[kPanel];
-#pragma unroll
-        for (int r = 0; r < kPanel; ++r)
-#pragma unroll
-            for (int cc = 0; cc <= r; ++cc) Ld[r][cc] = (r < nb) ? A[IDX(j0 + r, j0 + cc)] : (r == cc ? 1.0 : 0.0);
-#pragma unroll
-        for (int cc = 0; cc < kPanel; ++cc) {
-            double dd = Ld[cc][cc];
-#pragma unroll
-            for (int k = 0; k < cc; ++k) dd -= Ld[cc][k] * Ld[cc][k];
-            if (!(dd > 0.0) || !isfinite(dd)) fail = 1;
-            inv[cc] = fast_rsqrt(dd);
-            Ld[cc][cc] = dd * inv[cc];
-#pragma unroll
-            for (int r = cc + 1; r < kPanel; ++r) {
-                double x = Ld[r][cc];
-#pragma unroll
-                for (int k = 0; k < cc; ++k) x -= Ld[r][k] * Ld[cc][k];
-                Ld[r][cc] = x * inv[cc];
-            }
-        }
-        if (j0 == 0) PV_STAMP(2, 9);
-        if (fail) break; // uniform: every thread factored the same block
-#pragma unroll
-        for (int cc = 0; cc < kPanel; ++cc)
-            if (tid == cc && cc < nb) tmp[j0 + cc] = inv[cc]; // 1 / L_jj for the back substitution
-        const int k0 = j0 + nb;
-        double x[kPanel];
-        const int irow = j0 + tid; // row owner
-        if (irow <= P) {
-#pragma unroll
-            for (int cc = 0; cc < kPanel; ++cc) x[cc] = (cc < nb && j0 + cc <= irow) ? A[IDX(irow, j0 + cc)] : 0.0;
-#pragma unroll
-            for (int cc = 0; cc < kPanel; ++cc) {
-                double t = x[cc];
-#pragma unroll
-                for (int k = 0; k < cc; ++k) t -= x[k] * Ld[cc][k];
-                x[cc] = t * inv[cc];
-            }
-            // rows below the panel can be written now; the panel's own rows ARE the diagonal block other threads may
-            // still be reading, so they go back only after the barrier (nothing in the update reads them)
-            if (irow >= k0) {
-#pragma unroll
-                for (int cc = 0; cc < kPanel; ++cc)
-                    if (cc < nb) A[IDX(irow, j0 + cc)] = x[cc];
-            }
-        }
-        __syncthreads();
-        if (j0 == 0) PV_STAMP(2, 10);
-        if (irow < k0) {
-#pragma unroll
-            for (int cc = 0; cc < kPanel; ++cc)
-                if (cc < nb && j0 + cc <= irow) A[IDX(irow, j0 + cc)] = x[cc];
-        }
-        // rank-nb update of the trailing lower triangle on the matrix cores: C(16x16 tile) -= Lp_i (16 x 8) Lp_k^T, two
-        // v_mfma_f64_16x16x4_f64 per tile.  Operand layout (cdna_hip_programming.md section 3, f64): lane l supplies
-        // A[l & 15][l >> 4] and B[l >> 4][l & 15]; it receives D[(l >> 4) + 4 r][l & 15], r = 0..3.  Per tile a lane
-        // does 4 + 4 LDS loads and <= 4 stores for 32 FMAs; the VALU form was LDS-read bound at ~1 load per FMA.
+    const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 15, lk = lane >> 4;
+    if constexpr (LDSMAT) {
+        // ---------------- register-resident panel Cholesky (width 8), two barriers per panel ----------------
+        // The trailing matrix never returns to LDS: wave w owns tiles w, w + 4, ... of the block triangle (enumerated by
+        // DEscending tile column, so that the tiles still alive at any panel are a prefix of every wave's list) and keeps
+        // them in accumulator registers for the whole factorization.  Per panel the LDS carries only (1) the 8 columns that
+        // are factored next (Xs, published by the owners of that tile column), (2) the finished panel of L (Lf, written
+        // once by the row owners as the (k, k + 4) operand pairs the MFMAs read, and kept: it is also the L the back
+        // substitution uses).  Lf overlays the tile image the gather produced, which is dead once the tiles are loaded.
+        // Every thread factors the 8 x 8 diagonal block redundantly in registers; the owner of row i turns its 8 panel
+        // entries into L (row Pp = right-hand side -> forward substitution for free).  The system is padded with identity
+        // rows to whole panels, so nothing in the loop depends on a partial panel.
+        constexpr int kSlots = 17; // ceil(66 / 4): LDV <= 176
+        double *Xs = Lp, *Lf = A;
+        const int ntile = (nbk * (nbk + 1)) >> 1;
+        int sbi[kSlots], sbk[kSlots];
         {
-            const int wv = tid >> 6, lane = tid & 63, nwave = nthr >> 6;
-            const int TR = (P + 1 - k0 + 15) >> 4, TC = (P - k0 + 15) >> 4; // row blocks (incl. the rhs row), column blocks
-            const int lr = lane & 15, lk = lane >> 4;
-            int t = 0;
-            for (int bi = 0; bi < TR; ++bi) {
-                const int bkmax = bi < TC ? bi : TC - 1;
-                for (int bk = 0; bk <= bkmax; ++bk, ++t) {
-                    if (t % nwave != wv) continue;
-                    const int i0 = k0 + 16 * bi, c0 = k0 + 16 * bk;
-                    const int ra = i0 + lr, rb = c0 + lr;
-                    const int pa = IDX(ra <= P ? ra : P, j0), pb = IDX(rb < P ? rb : P - 1, j0); // clamped: always in bounds
-                    const double a0 = (ra <= P && lk < nb) ? -A[pa + lk] : 0.0;
-                    const double a1 = (ra <= P && 4 + lk < nb) ? -A[pa + 4 + lk] : 0.0;
-                    const double b0 = (rb < P && lk < nb) ? A[pb + lk] : 0.0;
-                    const double b1 = (rb < P && 4 + lk < nb) ? A[pb + 4 + lk] : 0.0;
-                    mfma_d4 cacc;
-                    const int ck = c0 + lr;
-                    bool ok[4];
-                    int pc[4];
+            int e = wv, g = 0;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int ci = i0 + lk + 4 * r;
-                        ok[r] = ci <= P && ck < P && ck <= ci;
-                        pc[r] = ok[r] ? IDX(ci, ck) : 0;
-                        cacc[r] = ok[r] ? A[pc[r]] : 0.0;
-                    }
-                    cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, cacc, 0, 0, 0);
-                    cacc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, cacc, 0, 0, 0);
+            for (int i = 0; i < kSlots; ++i) {
+                while ((((g + 1) * (g + 2)) >> 1) <= e) ++g;
+                const int h = e - ((g * (g + 1)) >> 1);
+                const bool valid = e < ntile;
+                sbk[i] = valid ? nbk - 1 - g : -1;
+                sbi[i] = valid ? nbk - 1 - h : 0;
+                e += 4;
+            }
+        }
+        mfma_d4 acc[kSlots];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (ok[r]) A[pc[r]] = cacc[r];
+        for (int i = 0; i < kSlots; ++i) {
+            acc[i][0] = 0, acc[i][1] = 0, acc[i][2] = 0, acc[i][3] = 0;
+            if (sbk[i] >= 0) {
+                const double *T = A + tile_base(sbi[i], sbk[i]) + 4 * lane;
+                const lds_d2 c01 = *reinterpret_cast<const lds_d2 *>(T), c23 = *reinterpret_cast<const lds_d2 *>(T + 2);
+                acc[i][0] = c01[0], acc[i][1] = c01[1], acc[i][2] = c23[0], acc[i][3] = c23[1];
+            }
+        }
+        // columns [o2, o2 + 8) of slot i's tile -> Xs (row-major, 8 per row; still negated)
+#define PV_PUBLISH(i, o2)                                                                               \
+    do {                                                                                                \
+        const int cX = lr - (o2);                                                                       \
+        if (cX >= 0 && cX < kPanel) {                                                                   \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r) Xs[(16 * sbi[i] + lk + 4 * r) * 8 + cX] = acc[i][r]; \
+        }                                                                                               \
+    } while (0)
+#pragma unroll
+        for (int i = 0; i < kSlots; ++i)
+            if (sbk[i] == 0) PV_PUBLISH(i, 0);
+        __syncthreads(); // every wave holds its tiles: the tile image may be overwritten from here on
+        int lfo = 0;     // offset of the current panel in Lf (panel p keeps rows j0 .. LDV - 1, 8 doubles each)
+        for (int j0 = 0; j0 < Pp; j0 += kPanel) {
+            const int k0 = j0 + kPanel, b0 = k0 >> 4, o2 = k0 & 15;
+            if (j0 == 0) PV_STAMP(2, 8);
+            if (j0 == 80) PV_STAMP(2, 13);
+            double Ld[kPanel][kPanel], inv[kPanel];
+#pragma unroll
+            for (int r = 0; r < kPanel; ++r)
+#pragma unroll
+                for (int h = 0; h <= (r >> 1); ++h) {
+                    const lds_d2 g2 = *reinterpret_cast<const lds_d2 *>(Xs + (j0 + r) * 8 + 2 * h);
+                    Ld[r][2 * h] = -g2[0];
+                    if (2 * h + 1 <= r) Ld[r][2 * h + 1] = -g2[1];
+                }
+            const int irow = j0 + tid; // row owner (LDV <= 176 < 256 threads)
+            double x[kPanel];
+            if (irow < LDV) {
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    const lds_d2 g2 = *reinterpret_cast<const lds_d2 *>(Xs + irow * 8 + 2 * h);
+                    x[2 * h] = -g2[0], x[2 * h + 1] = -g2[1];
                 }
             }
-        }
-        if (j0 == 0) PV_STAMP(2, 11);
-        __syncthreads();
-        if (j0 == 0) PV_STAMP(2, 12);
-    }
-    PV_STAMP(2, 5);
-    // ---------------- back substitution L^T y = z in wave 0 (rows owned by lanes, one shuffle per column) ----------------
-    if (tid == 0) sh_fail = fail;
-    __syncthreads();
-    if (!fail) {
-        double zz = 0;
-        for (int a = tid; a < P; a += nthr) {
-            const double z = A[IDX(P, a)]; // z = L^-1 rhs (row P went through the factorization)
-            yv[a] = z;
-            zz += act[a] != 0.0 ? z * z : 0.0;
-        }
-        double s1[1] = {zz};
-        block_sum<1>(s1, red_scratch);
-        if (tid == 0) c->pose_qyy = s1[0]; // y^T (S + mu D^2) y = |z|^2 ; the mu term is removed below
-        __syncthreads();
-        // blocked backward solve L^T y = z, 8 columns per step, all threads: every thread solves the 8 x 8 triangular
-        // block redundantly in registers (no communication), then the rows above the block are updated in parallel
-        // (column access of packed rows is contiguous).  One barrier per block.
-        for (int jb = ((P - 1) / kPanel) * kPanel; jb >= 0; jb -= kPanel) {
-            const int nb = min(kPanel, P - jb);
-            double Ld[kPanel][kPanel], yb[kPanel];
+            // right-looking: after pivot cc the remaining block entries are updated at once (short dependent chain)
 #pragma unroll
-            for (int r = 0; r < kPanel; ++r) {
+            for (int cc = 0; cc < kPanel; ++cc) {
+                const double dd = Ld[cc][cc];
+                fail |= (!(dd > 0.0) || !isfinite(dd)) ? 1 : 0;
+                inv[cc] = fast_rsqrt(dd);
 #pragma unroll
-                for (int cc = 0; cc < r; ++cc) Ld[r][cc] = (r < nb) ? A[IDX(jb + r, jb + cc)] : 0.0;
-                yb[r] = r < nb ? yv[jb + r] : 0.0;
-                Ld[r][r] = r < nb ? tmp[jb + r] : 0.0; // 1 / L_rr
+                for (int r = cc + 1; r < kPanel; ++r) Ld[r][cc] *= inv[cc];
+#pragma unroll
+                for (int r = cc + 1; r < kPanel; ++r)
+#pragma unroll
+                    for (int c2 = cc + 1; c2 <= r; ++c2) Ld[r][c2] -= Ld[r][cc] * Ld[c2][cc];
             }
-#pragma unroll
-            for (int cc = kPanel - 1; cc >= 0; --cc) {
-                double t = yb[cc];
-#pragma unroll
-                for (int r = cc + 1; r < kPanel; ++r) t -= Ld[r][cc] * yb[r];
-                yb[cc] = t * Ld[cc][cc];
-            }
+            double Ls[kPanel][kPanel]; // L_dd[c2][cc] / L_dd[cc][cc]
 #pragma unroll
             for (int cc = 0; cc < kPanel; ++cc)
-                if (tid == cc && cc < nb) ysol[jb + cc] = yb[cc];
-            for (int a = tid; a < jb; a += nthr) {
-                double acc2 = 0;
 #pragma unroll
-                for (int cc = 0; cc < kPanel; ++cc) acc2 += cc < nb ? A[IDX(jb + cc, a)] * yb[cc] : 0.0;
-                yv[a] -= acc2;
+                for (int c2 = cc + 1; c2 < kPanel; ++c2) Ls[c2][cc] = Ld[c2][cc] * inv[cc];
+            if (j0 == 0) PV_STAMP(2, 9);
+            if (j0 == 80) PV_STAMP(2, 14);
+            if (fail) break; // uniform: every thread factored the same block
+            if (j0 == 80) PV_STAMPV(2, 18, Ls[7][6]);
+            if (tid < kPanel) {
+                double iv = inv[0];
+#pragma unroll
+                for (int cc = 1; cc < kPanel; ++cc) iv = (tid == cc) ? inv[cc] : iv;
+                tmp[j0 + tid] = iv; // 1 / L_jj for the back substitution
+            }
+            if (irow < LDV) {
+                // forward substitution of the owner's row; the chain carries the UNscaled entries (one dependent FMA per
+                // step, Ld's columns were pre-multiplied by 1 / L_cc above), scaling and the mask of the panel's own rows
+                // (their strictly upper entries are not L) come after it
+#pragma unroll
+                for (int cc = 0; cc < kPanel; ++cc) {
+#pragma unroll
+                    for (int c2 = cc + 1; c2 < kPanel; ++c2) x[c2] -= x[cc] * Ls[c2][cc];
+                }
+                if (j0 == 80) PV_STAMPV(2, 19, x[7]);
+#pragma unroll
+                for (int cc = 0; cc < kPanel; ++cc) x[cc] = (j0 + cc <= irow) ? x[cc] * inv[cc] : 0.0;
+                if (j0 == 80) PV_STAMPV(2, 20, x[7]);
+                lds_d2 *Lrow = reinterpret_cast<lds_d2 *>(Lf + lfo + 8 * tid);
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    lds_d2 pr;
+                    pr[0] = x[h], pr[1] = x[h + 4]; // operand pair (k, k + 4) of the two MFMAs
+                    Lrow[h] = pr;
+                }
             }
             __syncthreads();
+            if (j0 == 0) PV_STAMP(2, 10);
+            if (j0 == 80) PV_STAMP(2, 15);
+            // rank-8 update of the live tiles: (-C)(16x16) += L_i (16 x 8) L_k^T, two v_mfma_f64_16x16x4_f64 per tile.
+            // Operand layout (cdna_hip_programming.md section 3, f64): lane l supplies A[l & 15][l >> 4] and
+            // B[l >> 4][l & 15]; it receives D[(l >> 4) + 4 r][l & 15], r = 0..3.  The live tiles are the first `na` slots;
+            // they are walked from the back in groups of four (the tile column that is factored next comes first and is
+            // published while the remaining groups still compute).
+            {
+                const int R = nbk - b0, nact = (R * (R + 1)) >> 1;
+                const int na = nact > wv ? (nact - wv + 3) >> 2 : 0;
+                const double *Lpan = Lf + lfo - 8 * j0 + 2 * lk + 8 * lr; // + 128 * tile row -> this lane's operand pair
+#pragma unroll
+                for (int cg = (kSlots + 3) / 4 - 1; cg >= 0; --cg) {
+                    if (4 * cg < na) {
+                        lds_d2 av[4], pv[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int i = 4 * cg + u;
+                            if (i < kSlots) {
+                                const bool on = i < na;
+                                av[u] = *reinterpret_cast<const lds_d2 *>(Lpan + 128 * (on ? sbi[i] : b0));
+                                pv[u] = *reinterpret_cast<const lds_d2 *>(Lpan + 128 * (on ? sbk[i] : b0));
+                            }
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int i = 4 * cg + u;
+                            if (i < kSlots && i >= na) av[u][0] = 0.0, av[u][1] = 0.0; // tail of the last group: a = 0 leaves the tile as it is
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (4 * cg + u < kSlots) acc[4 * cg + u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][0], pv[u][0], acc[4 * cg + u], 0, 0, 0);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (4 * cg + u < kSlots) acc[4 * cg + u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][1], pv[u][1], acc[4 * cg + u], 0, 0, 0);
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (4 * cg + u < kSlots && sbk[4 * cg + u] == b0) {
+                                asm volatile("" ::: "memory"); // keep this a real (uniform) branch: nothing of the publish is hoisted
+                                PV_PUBLISH(4 * cg + u, o2);
+                            }
+                    }
+                }
+            }
+            if (j0 == 0) PV_STAMP(2, 11);
+            if (j0 == 80) PV_STAMP(2, 16);
+            __syncthreads();
+            if (j0 == 0) PV_STAMP(2, 12);
+            if (j0 == 80) PV_STAMP(2, 17);
+            lfo += 8 * (LDV - j0);
+        }
+#undef PV_PUBLISH
+        PV_STAMP(2, 5);
+        // ---------------- back substitution L^T y = z, 8 columns per step ----------------
+        // L(i, k) = Lf[off(k >> 3) + (i - 8 (k >> 3)) * 8 + perm(k & 7)], off(p) = 8 p LDV - 32 p (p - 1), perm(c) = 2 (c & 3) + (c >> 2)
+        if (tid == 0) sh_fail = fail;
+        __syncthreads();
+        if (!fail) {
+            auto lf_at = [&](int i, int k) -> int {
+                const int p = k >> 3, cI = k & 7;
+                return 8 * p * LDV - 32 * p * (p - 1) + (i - 8 * p) * 8 + 2 * (cI & 3) + (cI >> 2);
+            };
+            // inverses of the 8 x 8 diagonal blocks, all at once (thread = one column of one block: L X = e_c), so that a
+            // block step below is a short dot product instead of a dependent triangular solve.  Li overlays Xs.
+            double *Li = Xs;
+            const int npan = Pp / kPanel;
+            for (int t = tid; t < npan * kPanel; t += nthr) {
+                const int p = t >> 3, cI = t & 7, j0 = p * kPanel;
+                double X[kPanel];
+#pragma unroll
+                for (int r = 0; r < kPanel; ++r) {
+                    double s = (r == cI) ? 1.0 : 0.0;
+#pragma unroll
+                    for (int k = 0; k < r; ++k) s -= Lf[lf_at(j0 + r, j0 + k)] * X[k];
+                    X[r] = s * tmp[j0 + r];
+                }
+#pragma unroll
+                for (int r = 0; r < kPanel; ++r) Li[p * 64 + cI * 8 + r] = X[r]; // Li[p][c][r] = (L_pp^-1)[r][c]
+            }
+            double zz = 0;
+            for (int a = tid; a < Pp; a += nthr) {
+                const double z = Lf[lf_at(Pp, a)]; // z = L^-1 rhs (row Pp went through the factorization); 0 in the padding
+                yv[a] = z;
+                zz += (a < P && act[a] != 0.0) ? z * z : 0.0;
+            }
+            double s1[1] = {zz};
+            block_sum<1>(s1, red_scratch);
+            if (tid == 0) c->pose_qyy = s1[0]; // y^T (S + mu D^2) y = |z|^2 ; the mu term is removed below
+            __syncthreads();
+            // every thread forms y_b = L_bb^-T z_b redundantly (broadcast loads), then the rows above the block are
+            // updated in parallel.  One barrier per block.
+            for (int p = npan - 1; p >= 0; --p) {
+                const int jb0 = p * kPanel;
+                double lrow[kPanel]; // L(jb0 + cc, a) for this thread's row a (independent of y: issued first)
+                const int a = tid;
+                if (a < jb0) {
+                    const double *T = Lf + lf_at(jb0, a);
+#pragma unroll
+                    for (int cc = 0; cc < kPanel; ++cc) lrow[cc] = T[8 * cc];
+                }
+                double zb[kPanel], yb[kPanel];
+                {
+                    const lds_d2 *Z = reinterpret_cast<const lds_d2 *>(yv + jb0);
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) {
+                        const lds_d2 z2 = Z[h];
+                        zb[2 * h] = z2[0], zb[2 * h + 1] = z2[1];
+                    }
+                }
+                const lds_d2 *L2 = reinterpret_cast<const lds_d2 *>(Li + p * 64);
+#pragma unroll
+                for (int cc = 0; cc < kPanel; ++cc) {
+                    double s = 0;
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) {
+                        const lds_d2 l2 = L2[cc * 4 + h];
+                        s += l2[0] * zb[2 * h] + l2[1] * zb[2 * h + 1];
+                    }
+                    yb[cc] = s;
+                }
+                if (tid < kPanel) {
+                    double yo = yb[0];
+#pragma unroll
+                    for (int cc = 1; cc < kPanel; ++cc) yo = (tid == cc) ? yb[cc] : yo;
+                    ysol[jb0 + tid] = yo;
+                }
+                if (a < jb0) {
+                    double acc2 = 0;
+#pragma unroll
+                    for (int cc = 0; cc < kPanel; ++cc) acc2 += lrow[cc] * yb[cc];
+                    yv[a] -= acc2;
+                }
+                __syncthreads();
+            }
+        }
+    } else {
+        // generic path (systems too large for LDS): tiles in HBM, read-modify-written per panel
+        for (int j0 = 0; j0 < Pp; j0 += kPanel) {
+            const int jb = j0 >> 4, o = j0 & 15, k0 = j0 + kPanel;
+            if (j0 == 0) PV_STAMP(2, 8);
+            double Ld[kPanel][kPanel], inv[kPanel];
+            {
+                const lds_d2 *G = reinterpret_cast<const lds_d2 *>(Dg);
+                double flat[36];
+    #pragma unroll
+                for (int e = 0; e < 18; ++e) {
+                    const lds_d2 g = G[e];
+                    flat[2 * e] = g[0], flat[2 * e + 1] = g[1];
+                }
+    #pragma unroll
+                for (int r = 0; r < kPanel; ++r)
+    #pragma unroll
+                    for (int cc = 0; cc <= r; ++cc) Ld[r][cc] = flat[((r * (r + 1)) >> 1) + cc];
+            }
+            // the owner's row: issue the loads before the factorization chain (LDV <= 256 whenever the matrix is in LDS;
+            // larger systems loop over the remaining rows below).  Unfactored entries are stored negated.
+            const int irow = j0 + tid;
+            double x[kPanel];
+            double *Trow = A + tile_base(irow >> 4, jb) + tile_off(irow & 15, o);
+            if (irow < LDV) {
+    #pragma unroll
+                for (int cc = 0; cc < kPanel; ++cc) x[cc] = -Trow[4 * cc];
+            }
+            // right-looking: after pivot cc the remaining block entries are updated at once (short dependent chain)
+    #pragma unroll
+            for (int cc = 0; cc < kPanel; ++cc) {
+                const double dd = Ld[cc][cc];
+                fail |= (!(dd > 0.0) || !isfinite(dd)) ? 1 : 0;
+                inv[cc] = fast_rsqrt(dd);
+    #pragma unroll
+                for (int r = cc + 1; r < kPanel; ++r) Ld[r][cc] *= inv[cc];
+    #pragma unroll
+                for (int r = cc + 1; r < kPanel; ++r)
+    #pragma unroll
+                    for (int c2 = cc + 1; c2 <= r; ++c2) Ld[r][c2] -= Ld[r][cc] * Ld[c2][cc];
+            }
+            if (j0 == 0) PV_STAMP(2, 9);
+            if (fail) break; // uniform: every thread factored the same block
+            if (tid < kPanel) {
+                double iv = inv[0];
+    #pragma unroll
+                for (int cc = 1; cc < kPanel; ++cc) iv = (tid == cc) ? inv[cc] : iv;
+                tmp[j0 + tid] = iv; // 1 / L_jj for the back substitution
+            }
+            if (irow < LDV) {
+    #pragma unroll
+                for (int cc = 0; cc < kPanel; ++cc) {
+                    x[cc] = (j0 + cc <= irow) ? x[cc] * inv[cc] : 0.0; // the panel's own rows: strictly upper entries are not L
+    #pragma unroll
+                    for (int c2 = cc + 1; c2 < kPanel; ++c2) x[c2] -= x[cc] * Ld[c2][cc];
+                }
+                lds_d2 *Lrow = reinterpret_cast<lds_d2 *>(Lp + 8 * irow);
+    #pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    lds_d2 pr;
+                    pr[0] = x[h], pr[1] = x[h + 4]; // operand pair (k, k + 4) of the two MFMAs
+                    Lrow[h] = pr;
+                }
+                // rows below the panel can be written now; the panel's own rows are still being read by their owners'
+                // neighbours (the diagonal tile), so they go back only after the barrier
+                if (irow >= k0) {
+    #pragma unroll
+                    for (int cc = 0; cc < kPanel; ++cc) Trow[4 * cc] = x[cc];
+                }
+            }
+            if (!LDSMAT) {
+                // systems too large for LDS (more rows than threads): the remaining row owners
+                for (int ir = irow + nthr; ir < LDV; ir += nthr) {
+                    double *T = A + tile_base(ir >> 4, jb) + tile_off(ir & 15, o);
+                    double xx[kPanel];
+    #pragma unroll
+                    for (int cc = 0; cc < kPanel; ++cc) xx[cc] = -T[4 * cc];
+    #pragma unroll
+                    for (int cc = 0; cc < kPanel; ++cc) {
+                        xx[cc] *= inv[cc];
+    #pragma unroll
+                        for (int c2 = cc + 1; c2 < kPanel; ++c2) xx[c2] -= xx[cc] * Ld[c2][cc];
+                    }
+    #pragma unroll
+                    for (int cc = 0; cc < kPanel; ++cc) Lp[8 * ir + 2 * (cc & 3) + (cc >> 2)] = xx[cc], T[4 * cc] = xx[cc];
+                }
+            }
+            __syncthreads();
+            if (j0 == 0) PV_STAMP(2, 10);
+            if (irow < k0) {
+    #pragma unroll
+                for (int cc = 0; cc < kPanel; ++cc)
+                    if (j0 + cc <= irow) Trow[4 * cc] = x[cc];
+            }
+            // rank-8 update of the trailing tiles: (-C)(16x16) += Lp_i (16 x 8) Lp_k^T, two v_mfma_f64_16x16x4_f64 per tile.
+            // Operand layout (cdna_hip_programming.md section 3, f64): lane l supplies A[l & 15][l >> 4] and B[l >> 4][l & 15];
+            // it receives D[(l >> 4) + 4 r][l & 15], r = 0..3 = the four consecutive doubles it owns in the tile.  Everything
+            // is loaded unconditionally (padding rows are zero, columns left of k0 hold finished L entries and are simply not
+            // stored back).  Tiles of the trailing block triangle are dealt round-robin to the four waves in batches of
+            // kBatch: all loads of a batch are in flight before its first MFMA.
+            {
+                constexpr int kBatch = 4;
+                const int b0 = k0 >> 4;
+                const int o2 = k0 & 15; // the next diagonal block sits at (o2, o2) of tile (b0, b0) = the first tile of wave 0
+                int bi = b0, q = wv;
+                bool first = wv == 0;
+                while (bi < nbk && q > bi - b0) q -= bi - b0 + 1, ++bi;
+                while (bi < nbk) {
+                    double *C[kBatch];
+                    lds_d2 av[kBatch], pv[kBatch], c01[kBatch], c23[kBatch];
+                    bool st[kBatch];
+    #pragma unroll
+                    for (int u = 0; u < kBatch; ++u) {
+                        const bool valid = bi < nbk;
+                        const int bic = valid ? bi : nbk - 1, bkc = valid ? b0 + q : nbk - 1;
+                        C[u] = A + tile_base(bic, bkc) + 4 * lane;
+                        av[u] = *reinterpret_cast<const lds_d2 *>(Lp + 8 * (16 * bic + lr) + 2 * lk);
+                        pv[u] = *reinterpret_cast<const lds_d2 *>(Lp + 8 * (16 * bkc + lr) + 2 * lk);
+                        c01[u] = *reinterpret_cast<const lds_d2 *>(C[u]);
+                        c23[u] = *reinterpret_cast<const lds_d2 *>(C[u] + 2);
+                        st[u] = valid && (16 * bkc + lr >= k0);
+                        q += 4;
+                        while (bi < nbk && q > bi - b0) q -= bi - b0 + 1, ++bi;
+                    }
+                    mfma_d4 acc[kBatch];
+    #pragma unroll
+                    for (int u = 0; u < kBatch; ++u) {
+                        acc[u][0] = c01[u][0], acc[u][1] = c01[u][1], acc[u][2] = c23[u][0], acc[u][3] = c23[u][1];
+                        acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][0], pv[u][0], acc[u], 0, 0, 0);
+                    }
+    #pragma unroll
+                    for (int u = 0; u < kBatch; ++u) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][1], pv[u][1], acc[u], 0, 0, 0);
+    #pragma unroll
+                    for (int u = 0; u < kBatch; ++u)
+                        if (st[u]) {
+                            lds_d2 w0, w1;
+                            w0[0] = acc[u][0], w0[1] = acc[u][1], w1[0] = acc[u][2], w1[1] = acc[u][3];
+                            *reinterpret_cast<lds_d2 *>(C[u]) = w0;
+                            *reinterpret_cast<lds_d2 *>(C[u] + 2) = w1;
+                        }
+                    if (first) { // hand the next diagonal block over, packed and un-negated
+                        first = false;
+                        const int cD = lr - o2;
+    #pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int rD = lk + 4 * r - o2;
+                            if (rD >= 0 && rD < kPanel && cD >= 0 && cD <= rD) Dg[((rD * (rD + 1)) >> 1) + cD] = -acc[0][r];
+                        }
+                    }
+                }
+            }
+            if (j0 == 0) PV_STAMP(2, 11);
+            __syncthreads();
+            if (j0 == 0) PV_STAMP(2, 12);
+        }
+        PV_STAMP(2, 5);
+        // ---------------- back substitution L^T y = z, 8 columns per step ----------------
+        if (tid == 0) sh_fail = fail;
+        __syncthreads();
+        if (!fail) {
+            // inverses of the 8 x 8 diagonal blocks, all at once (thread = one column of one block: L X = e_c), so that a
+            // block step below is a short dot product instead of a dependent triangular solve.  Li aliases the panel buffer.
+            double *Li = Lp;
+            const int npan = Pp / kPanel;
+            for (int t = tid; t < npan * kPanel; t += nthr) {
+                const int p = t >> 3, cI = t & 7, j0 = p * kPanel;
+                const double *T = A + tile_base(j0 >> 4, j0 >> 4);
+                const int o = j0 & 15;
+                double X[kPanel];
+    #pragma unroll
+                for (int r = 0; r < kPanel; ++r) {
+                    double s = (r == cI) ? 1.0 : 0.0;
+    #pragma unroll
+                    for (int k = 0; k < r; ++k) s -= T[tile_off(o + r, o + k)] * X[k];
+                    X[r] = s * tmp[j0 + r];
+                }
+    #pragma unroll
+                for (int r = 0; r < kPanel; ++r) Li[p * 64 + cI * 8 + r] = X[r]; // Li[p][c][r] = (L_pp^-1)[r][c]
+            }
+            double zz = 0;
+            for (int a = tid; a < Pp; a += nthr) {
+                const double z = A[mat_at(Pp, a)]; // z = L^-1 rhs (row Pp went through the factorization); 0 in the padding
+                yv[a] = z;
+                zz += (a < P && act[a] != 0.0) ? z * z : 0.0;
+            }
+            double s1[1] = {zz};
+            block_sum<1>(s1, red_scratch);
+            if (tid == 0) c->pose_qyy = s1[0]; // y^T (S + mu D^2) y = |z|^2 ; the mu term is removed below
+            __syncthreads();
+            // every thread forms y_b = L_bb^-T z_b redundantly (broadcast loads), then the rows above the block are updated
+            // in parallel.  One barrier per block.
+            for (int p = npan - 1; p >= 0; --p) {
+                const int jb0 = p * kPanel, o = jb0 & 15;
+                double lrow[kPanel]; // L(jb0 + cc, a) for this thread's row a (independent of y: issued first)
+                const int a = tid;
+                if (LDSMAT && a < jb0) {
+                    const double *T = A + tile_base(jb0 >> 4, a >> 4);
+    #pragma unroll
+                    for (int cc = 0; cc < kPanel; ++cc) lrow[cc] = T[tile_off(o + cc, a & 15)];
+                }
+                double zb[kPanel], yb[kPanel];
+                {
+                    const lds_d2 *Z = reinterpret_cast<const lds_d2 *>(yv + jb0);
+    #pragma unroll
+                    for (int h = 0; h < 4; ++h) {
+                        const lds_d2 z2 = Z[h];
+                        zb[2 * h] = z2[0], zb[2 * h + 1] = z2[1];
+                    }
+                }
+                const lds_d2 *L2 = reinterpret_cast<const lds_d2 *>(Li + p * 64);
+    #pragma unroll
+                for (int cc = 0; cc < kPanel; ++cc) {
+                    double s = 0;
+    #pragma unroll
+                    for (int h = 0; h < 4; ++h) {
+                        const lds_d2 l2 = L2[cc * 4 + h];
+                        s += l2[0] * zb[2 * h] + l2[1] * zb[2 * h + 1];
+                    }
+                    yb[cc] = s;
+                }
+                if (tid < kPanel) {
+                    double yo = yb[0];
+    #pragma unroll
+                    for (int cc = 1; cc < kPanel; ++cc) yo = (tid == cc) ? yb[cc] : yo;
+                    ysol[jb0 + tid] = yo;
+                }
+                if (LDSMAT) {
+                    if (a < jb0) {
+                        double acc2 = 0;
+    #pragma unroll
+                        for (int cc = 0; cc < kPanel; ++cc) acc2 += lrow[cc] * yb[cc];
+                        yv[a] -= acc2;
+                    }
+                } else {
+                    for (int aa = tid; aa < jb0; aa += nthr) {
+                        const double *T = A + tile_base(jb0 >> 4, aa >> 4);
+                        double acc2 = 0;
+    #pragma unroll
+                        for (int cc = 0; cc < kPanel; ++cc) acc2 += T[tile_off(o + cc, aa & 15)] * yb[cc];
+                        yv[aa] -= acc2;
+                    }
+                }
+                __syncthreads();
+            }
         }
     }
     PV_STAMP(2, 6);
@@ -1252,7 +1781,7 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(View v) {
             v.ystep[a] = cpl[a] * yp;
             v.vstep[a] = act[a] != 0.0 ? cpl[a] * vv[a] : 0.0;
             s_g2 += gh * gh, s_gn2 += gn * gn, s_gd += gh * gn;
-            s_qvy += diagH[a] * yp;                      // (S v) . y'
+            s_qvy += act[a] != 0.0 ? vv[a] * (mu * Da * Da * ysol[a] - diagH[a]) : 0.0; // v^T S y' = -v^T (rhs_s - mu D^2 y), S y = rhs_s - mu D^2 y
             s_gy += act[a] != 0.0 ? cpl[a] * gtot[a] * yp : 0.0;
         }
         // y'^T S y' = |z|^2 - mu sum D_a^2 y'_a^2 = |z|^2 - mu |gn_p|^2
@@ -1442,11 +1971,17 @@ hipError_t launch_reduce(const View &v, hipStream_t st) {
     return hipGetLastError();
 }
 
+size_t dense_tile_doubles(const Dims &dm) {
+    const size_t nbk = ((((size_t)dm.P + 7) & ~(size_t)7) + 16) >> 4;
+    return nbk * (nbk + 1) / 2 * 256; // 16 x 16 tiles of the lower block triangle incl. the rhs row
+}
 size_t dense_lds_bytes(const Dims &dm, int *lds_matrix) {
-    const size_t P = dm.P, ld = P + 1;
-    const size_t vec = (128 + 8 * ld) * sizeof(double);
-    const size_t mat = ((P + 1) * (P + 2) / 2 + 8) * sizeof(double); // packed lower triangle incl. the rhs row
-    *lds_matrix = (mat + vec <= 150 * 1024) ? 1 : 0;
+    const size_t nbk = ((((size_t)dm.P + 7) & ~(size_t)7) + 16) >> 4, LDV = nbk << 4;
+    const size_t vec = (224 + 16 * LDV) * sizeof(double); // header, 8 vectors, panel buffer
+    const size_t npan = (((size_t)dm.P + 7) & ~(size_t)7) / 8;
+    const size_t lfull = 8 * (npan * LDV - 4 * npan * (npan - 1)); // finished panels of L (overlays the tile image)
+    const size_t mat = std::max(dense_tile_doubles(dm), lfull) * sizeof(double);
+    *lds_matrix = (mat + vec <= 160 * 1024 && LDV <= 176) ? 1 : 0;
     return *lds_matrix ? mat + vec : vec;
 }
 

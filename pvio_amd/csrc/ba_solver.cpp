@@ -190,7 +190,7 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st) {
     dm.G_pre = dm.use_inertial ? N - 1 : 0;
     dm.G_prior = dm.prior_n; // one workgroup per prior frame
     dm.G_back = std::max(1, std::min(64, (M + 255) / 256));
-    dm.fuse_backsub = (world_ == 1 && M <= 4096) ? 1 : 0;
+    dm.fuse_backsub = (world_ == 1 && M <= 256) ? 1 : 0; // beyond one landmark per thread the separate launch is faster
     dm.n_back_rows = (world_ > 1 || dm.fuse_backsub) ? 1 : dm.G_back;
 
     // 3x3 tile tasks over the upper block triangle
@@ -270,7 +270,7 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st) {
     ok &= dev(pool_, "prior_g", Dp, &v.prior_g, &grew);
     ok &= dev(pool_, "prior_cost", (size_t)std::max(dm.prior_n, 1), &v.prior_cost, &grew);
     const size_t P = dm.P;
-    ok &= dev(pool_, "Smat", (P + 1) * (P + 1), &v.Smat, &grew);
+    ok &= dev(pool_, "Smat", dense_tile_doubles(dm), &v.Smat, &grew);
     ok &= dev(pool_, "cp", P, &v.cp, &grew);
     ok &= dev(pool_, "Dp", P, &v.Dp, &grew);
     ok &= dev(pool_, "gtot", P, &v.gtot, &grew);

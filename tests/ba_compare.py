@@ -16,6 +16,8 @@ CASES = {
     "vio_zero_bias_quirk": dict(n_frames=4, n_landmarks=30, use_inertial=True, bias_init="zero", perturb_scale=1.0),
     # BASELINE.json configs[1]: 10 KF x 200 landmarks, reprojection factors only
     "config1_10x200": dict(n_frames=10, n_landmarks=200),
+    "vio_11_frames_lds_limit": dict(n_frames=11, n_landmarks=80, use_inertial=True, visibility=6),   # reduced system 165: largest that stays in LDS
+    "vio_13_frames_global_matrix": dict(n_frames=13, n_landmarks=80, use_inertial=True, visibility=6),  # 195: matrix in HBM
 }
 BIG_CASES = {
     # the configuration the metric is quoted on (10 KF x 1000 landmarks), vision-only and full VIO

@@ -136,6 +136,11 @@ inline int __builtin_amdgcn_readlane(int v, int src) {
     hipemu::wave_exchange(&v, all, sizeof(int));
     return all[src & 63];
 }
+inline int __builtin_amdgcn_readfirstlane(int v) {
+    int all[64];
+    hipemu::wave_exchange(&v, all, sizeof(int));
+    return all[0];
+}
 inline unsigned long long __ballot(int pred) {
     int all[64];
     hipemu::wave_exchange(&pred, all, sizeof(int));

@@ -10,6 +10,6 @@ for vio in (True, False):
     for k in ('k_linearize','k_dense'):
         t = ctx.last_phase_ticks[k]; base=t[0]
         wall = (t[31]-t[30])*10.0  # ns at 100 MHz
-        st = [x-base for x in t[:13]]
+        st = [x-base for x in t[:28]]
         print(' ', k, 'stamps(ticks)', st, 'wall_ns', wall, 'ticks/us', (max(st)/ (wall/1e3)) if wall>0 else None)
     ctx.close()
