@@ -98,6 +98,24 @@ __device__ __forceinline__ void block_sum(double *vals, double *scratch) {
     __syncthreads();
 }
 
+constexpr int kPanel = 8; // Cholesky panel width (= K of two f64 MFMAs)
+#ifdef PV_HIPEMU
+typedef hipemu_double4 mfma_d4;
+typedef double lds_d2 __attribute__((vector_size(16)));
+#else
+typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+typedef double lds_d2 __attribute__((ext_vector_type(2)));
+#endif
+
+// The reduced system lives in LDS as 16 x 16 tiles of the lower block triangle (tile (bi, bk), bk <= bi, at
+// (bi (bi + 1) / 2 + bk) * 256 doubles).  Inside a tile the elements are in MFMA accumulator order: lane l of a wave owns
+// D[(l >> 4) + 4 r][l & 15], r = 0..3, as four consecutive doubles, so a trailing update moves a tile with two 16-byte
+// loads and two 16-byte stores per lane.  Entries that are not yet factored are stored NEGATED (the update is then a plain
+// multiply-accumulate, no operand negation); finished L entries are stored as they are.
+__device__ __forceinline__ int tile_base(int bi, int bk) { return (((bi * (bi + 1)) >> 1) + bk) << 8; }
+__device__ __forceinline__ int tile_off(int r, int c) { return ((((r & 3) << 4) + c) << 2) + (r >> 2); }
+__device__ __forceinline__ int mat_at(int i, int k) { return tile_base(i >> 4, k >> 4) + tile_off(i & 15, k & 15); } // k <= i
+
 // ------------------------------------------------------------------------------------------------------
 // k_linearize
 // ------------------------------------------------------------------------------------------------------
@@ -660,7 +678,12 @@ __global__ void __launch_bounds__(kLinThreads) k_linearize(View v) {
     lin_prologue(v, lds, pro);
     PV_STAMP(0, 1);
     if (!pro->valid) return; // invalid trust-region step: k_dense handles it (HandleInvalidStep)
-    const int b = blockIdx.x, g0 = v.dm.G_lm, g1 = g0 + v.dm.G_plane, g2 = g1 + v.dm.G_pre;
+    // launch order = [IMU | prior | planes | landmarks]: the longest workgroups are dispatched first; b keeps the role
+    // numbering [landmarks | planes | IMU | prior] the partial rows use
+    const int g0 = v.dm.G_lm, g1 = g0 + v.dm.G_plane, g2 = g1 + v.dm.G_pre, naux = v.dm.G_pre + v.dm.G_prior;
+    const int bx = blockIdx.x;
+    const int b = bx < naux ? g1 + bx : (bx < naux + v.dm.G_plane ? g0 + (bx - naux) : bx - naux - v.dm.G_plane);
+    if (v.dbg && threadIdx.x == 0 && (b == g1 || b == g2)) v.dbg[b == g1 ? 10 : 12] = clock64(); // first IMU / prior workgroup
     if (b < g0) role_landmarks<T>(v, lds, pro, b, g0);
     else if (b < g1) {
         if (pro->mode != MODE_MARG) role_planes<T>(v, lds, pro, b - g0, v.dm.G_plane, b);
@@ -671,6 +694,7 @@ __global__ void __launch_bounds__(kLinThreads) k_linearize(View v) {
         const int vic = v.ctrl->marg_victim;
         if (v.pre_valid[j] && (pro->mode != MODE_MARG || j == vic || j == vic + 1)) role_preint(v, lds, pro, j);
     } else role_prior(v, lds, pro, b - g2, v.dm.G_prior);
+    if (v.dbg && threadIdx.x == 0 && (b == g1 || b == g2)) v.dbg[b == g1 ? 11 : 13] = clock64();
     PV_STAMP(0, 9);
     if (v.dbg && blockIdx.x == 0 && threadIdx.x == 0) v.dbg[31] = wall_clock64();
 }
@@ -679,14 +703,47 @@ __global__ void __launch_bounds__(kLinThreads) k_linearize(View v) {
 // k_reduce: fixed-order sums of the WG partials -> red = [S tiles (element-major) | 3 pose vectors | 8 scalars]
 // ------------------------------------------------------------------------------------------------------
 constexpr int kRedElems = 64, kRedGroups = 16; // one block = 64 output elements x 16 partial groups
-__global__ void __launch_bounds__(kRedElems *kRedGroups) k_reduce(View v) {
+// Blocks [0, nb_red) produce `red` (tiles element-major, pose vectors, scalars).  With tile images on (single GPU, reduced
+// system resident in the dense kernel's registers) further blocks produce the UNSCALED reduced system itself, entry by
+// entry in the order the dense kernel's tile owners load it (lower block triangle, 16 x 16 tiles, MFMA accumulator order):
+// the same fixed-order sum of the landmark / plane partials as red[e], plus the IMU factor blocks (odd factor first) and
+// the marginalization prior.  Entries outside the real lower triangle are never written (the image is zeroed at upload).
+__global__ void __launch_bounds__(kRedElems *kRedGroups) k_reduce(View v, int nb_red) {
     if (v.ctrl->done || v.ctrl->lin_result == LIN_INVALID_STEP) return;
     __shared__ double part[kRedGroups][kRedElems];
     const int G = v.dm.G_lm + v.dm.G_plane;
     const size_t nS = (size_t)v.dm.n_tasks * 9, nV = (size_t)kNumPoseVec * v.dm.P6;
     const size_t total = nS + nV + kNumLinScal;
     const int el = threadIdx.x & (kRedElems - 1), gg = threadIdx.x / kRedElems;
-    const size_t e = (size_t)blockIdx.x * kRedElems + el;
+    const bool img_block = (int)blockIdx.x >= nb_red;
+    size_t e = (size_t)blockIdx.x * kRedElems + el;
+    // image entry -> (row i, column k) of the reduced system and the tile element it sums (or none)
+    int i = 0, k = 0, fa = 0, ka = 0, fb = 0, kb = 0;
+    bool entry = false;
+    size_t pos = 0;
+    if (img_block) {
+        const int d = v.dm.d, P = v.dm.P, N = v.dm.N;
+        pos = (size_t)(blockIdx.x - nb_red) * kRedElems + el;
+        const int ti = (int)(pos >> 8), w = (int)(pos & 255), ln = w >> 2, r = w & 3;
+        int bi = (int)((sqrtf(8.0f * ti + 1.0f) - 1.0f) * 0.5f);
+        while (((bi + 1) * (bi + 2)) >> 1 <= ti) ++bi;
+        while (((bi * (bi + 1)) >> 1) > ti) --bi;
+        const int bk = ti - ((bi * (bi + 1)) >> 1);
+        i = 16 * bi + (ln >> 4) + 4 * r, k = 16 * bk + (ln & 15);
+        entry = pos < (size_t)v.dm.img_sz && k <= i && i < P;
+        e = total; // no tile element unless set below
+        if (entry) {
+            fa = i / d, ka = i - d * fa, fb = k / d, kb = k - d * fb;
+            if (ka < 6 && kb < 6) {
+                const int p = fb * N - ((fb * (fb - 1)) >> 1) + (fa - fb); // tile tasks enumerate the upper block triangle (fb <= fa)
+                const int sa = ka >= 3, sb = kb >= 3, ra = ka - 3 * sa, rb = kb - 3 * sb;
+                const bool same = fa == fb;
+                const int t = 4 * p + (same ? 2 * sa + sb : 2 * sb + sa); // rows of an off-diagonal task = the earlier frame
+                const int q = same ? 3 * ra + rb : 3 * rb + ra;            // diagonal blocks come in full
+                e = (size_t)q * v.dm.n_tasks + t;
+            }
+        }
+    }
     // stage 1: group gg sums partials g = gg, gg + 16, ... (coalesced across el), four independent accumulators
     double s = 0;
     if (e < nS + nV) {
@@ -696,25 +753,46 @@ __global__ void __launch_bounds__(kRedElems *kRedGroups) k_reduce(View v) {
         for (int g0 = gg; g0 < G; g0 += 16 * kRedGroups) {
             double vals[16];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int g = g0 + k * kRedGroups;
-                vals[k] = g < G ? src[(size_t)g * stride] : 0.0;
+            for (int q = 0; q < 16; ++q) {
+                const int g = g0 + q * kRedGroups;
+                vals[q] = g < G ? src[(size_t)g * stride] : 0.0;
             }
 #pragma unroll
-            for (int k = 0; k < 16; ++k) s += vals[k];
+            for (int q = 0; q < 16; ++q) s += vals[q];
         }
     } else if (e < total) {
-        const int k = (int)(e - nS - nV);
-        for (int g = gg; g < G; g += kRedGroups) s = (k == 4) ? fmax(s, v.part_scal[(size_t)g * kNumLinScal + k]) : s + v.part_scal[(size_t)g * kNumLinScal + k];
+        const int q = (int)(e - nS - nV);
+        for (int g = gg; g < G; g += kRedGroups) s = (q == 4) ? fmax(s, v.part_scal[(size_t)g * kNumLinScal + q]) : s + v.part_scal[(size_t)g * kNumLinScal + q];
     }
     part[gg][el] = s;
     __syncthreads();
     // stage 2: fixed-order combination of the 16 group sums
-    if (gg == 0 && e < total) {
+    if (gg == 0 && (img_block ? entry : e < total)) {
         const bool is_max = e >= nS + nV && (int)(e - nS - nV) == 4;
         double r = part[0][el];
-        for (int k = 1; k < kRedGroups; ++k) r = is_max ? fmax(r, part[k][el]) : r + part[k][el];
-        v.red[e] = r;
+        for (int q = 1; q < kRedGroups; ++q) r = is_max ? fmax(r, part[q][el]) : r + part[q][el];
+        if (!img_block) {
+            v.red[e] = r;
+        } else {
+            double val = r; // 0 unless both coordinates are pose coordinates
+            if (v.dm.d == 15) {
+                const int N = v.dm.N;
+                if (v.dm.G_pre) {
+                    // factor j couples frames j - 1 (local 0..14) and j (local 15..29); odd factors first
+                    const bool same = fa == fb, adj = fa == fb + 1;
+                    const double hA = (fa >= 1 && (same || adj) && v.pre_valid[fa]) ? v.pre_H[(size_t)fa * 900 + (15 + ka) * 30 + (same ? 15 : 0) + kb] : 0.0;
+                    const double hB = (same && fa + 1 < N && v.pre_valid[fa + 1]) ? v.pre_H[(size_t)(fa + 1) * 900 + ka * 30 + kb] : 0.0;
+                    val = (fa & 1) ? (val + hA) + hB : (val + hB) + hA;
+                }
+                int pa = -1, pb = -1;
+                for (int q = 0; q < v.dm.prior_n; ++q) {
+                    const int f = v.prior_frames[q];
+                    pa = f == fa ? q : pa, pb = f == fb ? q : pb;
+                }
+                if (pa >= 0 && pb >= 0) val += v.prior_H[(size_t)(15 * pa + ka) * (15 * v.dm.prior_n) + 15 * pb + kb];
+            }
+            v.img[pos] = val;
+        }
     }
 }
 
@@ -773,23 +851,6 @@ __device__ __forceinline__ void backsub_landmarks(const View &v, int lin, double
     }
 }
 
-constexpr int kPanel = 8; // Cholesky panel width (= K of two f64 MFMAs)
-#ifdef PV_HIPEMU
-typedef hipemu_double4 mfma_d4;
-typedef double lds_d2 __attribute__((vector_size(16)));
-#else
-typedef double mfma_d4 __attribute__((ext_vector_type(4)));
-typedef double lds_d2 __attribute__((ext_vector_type(2)));
-#endif
-
-// The reduced system lives in LDS as 16 x 16 tiles of the lower block triangle (tile (bi, bk), bk <= bi, at
-// (bi (bi + 1) / 2 + bk) * 256 doubles).  Inside a tile the elements are in MFMA accumulator order: lane l of a wave owns
-// D[(l >> 4) + 4 r][l & 15], r = 0..3, as four consecutive doubles, so a trailing update moves a tile with two 16-byte
-// loads and two 16-byte stores per lane.  Entries that are not yet factored are stored NEGATED (the update is then a plain
-// multiply-accumulate, no operand negation); finished L entries are stored as they are.
-__device__ __forceinline__ int tile_base(int bi, int bk) { return (((bi * (bi + 1)) >> 1) + bk) << 8; }
-__device__ __forceinline__ int tile_off(int r, int c) { return ((((r & 3) << 4) + c) << 2) + (r >> 2); }
-__device__ __forceinline__ int mat_at(int i, int k) { return tile_base(i >> 4, k >> 4) + tile_off(i & 15, k & 15); } // k <= i
 
 // Builds the scaled reduced system S_s = C (H_pp - sum_l w_l W_l W_l^T) C in the tile image A (negated, see above): unit
 // rows for inactive coordinates, identity in the panel padding, the scaled rhs in row Pp, zeros above it.  The sources
@@ -961,6 +1022,37 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(View v) {
     double *diagH = vec, *gtot = vec + LDV, *rhs = vec + 2 * LDV, *yv = vec + 3 * LDV, *vv = vec + 4 * LDV, *act = vec + 5 * LDV,
            *tmp = vec + 6 * LDV, *cpl = vec + 7 * LDV;
     double *ysol = rhs; // solution of the reduced system (rhs is dead once the augmented row has been written)
+    // Tile ownership of the register-resident factorization (LDSMAT): wave w owns tiles w, w + 4, ... of the block triangle
+    // enumerated by DEscending tile column, so that the tiles still alive at any panel are a prefix of every wave's list.
+    constexpr int kSlots = LDSMAT ? 17 : 1; // ceil(66 / 4): LDV <= 176
+    const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 15, lk = lane >> 4;
+    const bool from_images = LDSMAT && v.dm.use_img; // the reduced system arrives as a tile image: loaded straight into registers
+    int sbi[kSlots], sbk[kSlots];
+    lds_d2 raw[kSlots][2];
+    if constexpr (LDSMAT) {
+        const int ntile = (nbk * (nbk + 1)) >> 1;
+        int e = wv, g = 0;
+#pragma unroll
+        for (int i = 0; i < kSlots; ++i) {
+            while ((((g + 1) * (g + 2)) >> 1) <= e) ++g;
+            const int h = e - ((g * (g + 1)) >> 1);
+            const bool valid = e < ntile;
+            sbk[i] = valid ? nbk - 1 - g : -1;
+            sbi[i] = valid ? nbk - 1 - h : 0;
+            e += 4;
+        }
+        // issue the loads of this wave's tiles now: their latency (a trip through the fabric, k_reduce ran on other XCDs)
+        // is covered by the control section and the vector assembly
+#pragma unroll
+        for (int i = 0; i < kSlots; ++i) {
+            raw[i][0][0] = 0.0, raw[i][0][1] = 0.0, raw[i][1][0] = 0.0, raw[i][1][1] = 0.0;
+            if (from_images && sbk[i] >= 0) {
+                const double *T = v.img + ((size_t)(((sbi[i] * (sbi[i] + 1)) >> 1) + sbk[i]) << 8) + 4 * lane;
+                raw[i][0] = *reinterpret_cast<const lds_d2 *>(T);
+                raw[i][1] = *reinterpret_cast<const lds_d2 *>(T + 2);
+            }
+        }
+    }
 
     PV_STAMP(2, 0);
     if (v.dbg && threadIdx.x == 0) v.dbg[2 * 32 + 30] = wall_clock64();
@@ -1199,45 +1291,57 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(View v) {
         tmp[a] = Da;
         yv[a] = act[a] != 0.0 ? cpa * rhs[a] : 0.0;       // scaled reduced rhs -> augmented row P
     }
-    for (int e = tid; e < 8 * LDV; e += nthr) Lp[e] = 0.0;
-    __syncthreads();
-    PV_STAMP(2, 21);
-    dense_build(v, A, cpl, yv, pvalid, pframe, P, Pp, nbk);
-    PV_STAMP(2, 22);
-    // pose quadratic form with the Schur-reduced scaled matrix (mu D^2 not yet added): v^T S v = sum S_ik v_i v_k
-    // (thread = one (row, column) of every tile; the vector S v itself is not needed: v^T S y' follows from the solve)
-    {
-        const int r = tid >> 4, cc = tid & 15, off = tile_off(r, cc);
-        double q = 0;
-        for (int bi = 0; bi < nbk; ++bi) {
-            const int i = 16 * bi + r;
-            const double vi = vv[i];
-            double qr = 0;
-            for (int bk = 0; bk <= bi; ++bk) {
-                const int k = 16 * bk + cc;
-                const double m = A[tile_base(bi, bk) + off]; // stored negated; strictly upper entries of diagonal tiles are 0
-                qr -= (i == k ? m : 2.0 * m) * vv[k];
-            }
-            q += qr * vi;
+    if (from_images) {
+        for (int a = tid; a < LDV; a += nthr) {
+            lds_d2 pr;
+            pr[0] = cpl[a], pr[1] = vv[a]; // {scale, v} pairs of the coordinates: one 16-byte read per row / column at load
+            *reinterpret_cast<lds_d2 *>(A + 2 * a) = pr;
+            diagH[a] = yv[a];               // keep the scaled rhs (yv is reused by the back substitution)
+            // diagonal patch of the assembled system: 1 on inactive coordinates and on the panel padding, mu D^2 elsewhere
+            yv[a] = a < P ? (cpl[a] == 0.0 ? 1.0 : mu * tmp[a] * tmp[a]) : (a < Pp ? 1.0 : 0.0);
         }
-        double s1[1] = {q};
-        block_sum<1>(s1, red_scratch);
-        if (tid == 0) c->pose_qvv = s1[0];
+        __syncthreads();
+        PV_STAMP(2, 21);
+    } else {
+        for (int e = tid; e < 8 * LDV; e += nthr) Lp[e] = 0.0;
+        __syncthreads();
+        PV_STAMP(2, 21);
+        dense_build(v, A, cpl, yv, pvalid, pframe, P, Pp, nbk);
+        PV_STAMP(2, 22);
+        // pose quadratic form with the Schur-reduced scaled matrix (mu D^2 not yet added): v^T S v = sum S_ik v_i v_k
+        // (thread = one (row, column) of every tile; the vector S v itself is not needed: v^T S y' follows from the solve)
+        {
+            const int r = tid >> 4, cc = tid & 15, off = tile_off(r, cc);
+            double q = 0;
+            for (int bi = 0; bi < nbk; ++bi) {
+                const int i = 16 * bi + r;
+                const double vi = vv[i];
+                double qr = 0;
+                for (int bk = 0; bk <= bi; ++bk) {
+                    const int k = 16 * bk + cc;
+                    const double m = A[tile_base(bi, bk) + off]; // stored negated; strictly upper entries of diagonal tiles are 0
+                    qr -= (i == k ? m : 2.0 * m) * vv[k];
+                }
+                q += qr * vi;
+            }
+            double s1[1] = {q};
+            block_sum<1>(s1, red_scratch);
+            if (tid == 0) c->pose_qvv = s1[0];
+        }
+        for (int a = tid; a < P; a += nthr) diagH[a] = yv[a]; // keep the scaled rhs (yv is reused by the back substitution)
+        PV_STAMP(2, 23);
+        for (int a = tid; a < P; a += nthr)
+            if (act[a] != 0.0) A[mat_at(a, a)] -= mu * tmp[a] * tmp[a];
+        __syncthreads();
+        if (tid < 36) { // first diagonal block, packed
+            int r = 0;
+            while (((r + 1) * (r + 2)) >> 1 <= tid) ++r;
+            Dg[tid] = -A[mat_at(r, tid - ((r * (r + 1)) >> 1))];
+        }
+        __syncthreads();
     }
-    for (int a = tid; a < P; a += nthr) diagH[a] = yv[a]; // keep the scaled rhs (yv is reused by the back substitution)
-    PV_STAMP(2, 23);
-    for (int a = tid; a < P; a += nthr)
-        if (act[a] != 0.0) A[mat_at(a, a)] -= mu * tmp[a] * tmp[a];
-    __syncthreads();
-    if (tid < 36) { // first diagonal block, packed
-        int r = 0;
-        while (((r + 1) * (r + 2)) >> 1 <= tid) ++r;
-        Dg[tid] = -A[mat_at(r, tid - ((r * (r + 1)) >> 1))];
-    }
-    __syncthreads();
     PV_STAMP(2, 4);
     int fail = 0;
-    const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 15, lk = lane >> 4;
     if constexpr (LDSMAT) {
         // ---------------- register-resident panel Cholesky (width 8), two barriers per panel ----------------
         // The trailing matrix never returns to LDS: wave w owns tiles w, w + 4, ... of the block triangle (enumerated by
@@ -1249,31 +1353,77 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(View v) {
         // Every thread factors the 8 x 8 diagonal block redundantly in registers; the owner of row i turns its 8 panel
         // entries into L (row Pp = right-hand side -> forward substitution for free).  The system is padded with identity
         // rows to whole panels, so nothing in the loop depends on a partial panel.
-        constexpr int kSlots = 17; // ceil(66 / 4): LDV <= 176
         double *Xs = Lp, *Lf = A;
-        const int ntile = (nbk * (nbk + 1)) >> 1;
-        int sbi[kSlots], sbk[kSlots];
-        {
-            int e = wv, g = 0;
+        mfma_d4 acc[kSlots];
+        if (!from_images) {
 #pragma unroll
             for (int i = 0; i < kSlots; ++i) {
-                while ((((g + 1) * (g + 2)) >> 1) <= e) ++g;
-                const int h = e - ((g * (g + 1)) >> 1);
-                const bool valid = e < ntile;
-                sbk[i] = valid ? nbk - 1 - g : -1;
-                sbi[i] = valid ? nbk - 1 - h : 0;
-                e += 4;
+                acc[i][0] = 0, acc[i][1] = 0, acc[i][2] = 0, acc[i][3] = 0;
+                if (sbk[i] >= 0) {
+                    const double *T = A + tile_base(sbi[i], sbk[i]) + 4 * lane;
+                    const lds_d2 c01 = *reinterpret_cast<const lds_d2 *>(T), c23 = *reinterpret_cast<const lds_d2 *>(T + 2);
+                    acc[i][0] = c01[0], acc[i][1] = c01[1], acc[i][2] = c23[0], acc[i][3] = c23[1];
+                }
             }
-        }
-        mfma_d4 acc[kSlots];
+        } else {
+            // S_s = C H C from the tile image k_reduce assembled (H = H_pp - sum_l w_l W_l W_l^T + IMU + prior), with unit
+            // rows for inactive coordinates, identity in the panel padding and the scaled rhs in row Pp; v^T S v and the
+            // mu D^2 diagonal on the way.  Off-diagonal tiles of real rows take the short path (C is 0 on inactive rows).
+            const double *cv = A, *dgv = yv;
+            const int brow = Pp >> 4; // tile row of the rhs row
+            double q = 0;
 #pragma unroll
-        for (int i = 0; i < kSlots; ++i) {
-            acc[i][0] = 0, acc[i][1] = 0, acc[i][2] = 0, acc[i][3] = 0;
-            if (sbk[i] >= 0) {
-                const double *T = A + tile_base(sbi[i], sbk[i]) + 4 * lane;
-                const lds_d2 c01 = *reinterpret_cast<const lds_d2 *>(T), c23 = *reinterpret_cast<const lds_d2 *>(T + 2);
-                acc[i][0] = c01[0], acc[i][1] = c01[1], acc[i][2] = c23[0], acc[i][3] = c23[1];
+            for (int g = 0; g < (kSlots + 3) / 4; ++g) {
+                // the {scale, v} pairs of four tiles first (in-range for unused slots), then the arithmetic: one LDS round
+                // trip per group instead of one per tile
+                lds_d2 ck2[4], ci2[4][4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = 4 * g + u < kSlots ? 4 * g + u : kSlots - 1;
+                    const int bi = sbi[i], bk = sbk[i] >= 0 ? sbk[i] : 0;
+                    ck2[u] = *reinterpret_cast<const lds_d2 *>(cv + 2 * (16 * bk + lr));
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ci2[u][r] = *reinterpret_cast<const lds_d2 *>(cv + 2 * (16 * bi + lk + 4 * r));
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = 4 * g + u;
+                    if (i < kSlots) {
+                        acc[i][0] = 0, acc[i][1] = 0, acc[i][2] = 0, acc[i][3] = 0;
+                        if (sbk[i] >= 0) {
+                            const int bi = sbi[i], bk = sbk[i];
+                            // C is 0 on inactive and padding coordinates, the image is 0 above the diagonal and outside
+                            // the real rows: one formula for every entry, the structural entries are patched below
+                            double val[4] = {raw[i][0][0], raw[i][0][1], raw[i][1][0], raw[i][1][1]};
+                            const double vk2 = 2.0 * ck2[u][1];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                val[r] *= ci2[u][r][0] * ck2[u][0];
+                                q += val[r] * (ci2[u][r][1] * vk2);
+                            }
+                            if (bi == bk) { // diagonal tile: its diagonal counts once in v^T S v; unit / mu D^2 diagonal
+                                const double dgk = dgv[16 * bk + lr];
+#pragma unroll
+                                for (int r = 0; r < 4; ++r)
+                                    if (lk + 4 * r == lr) q -= val[r] * (ci2[u][r][1] * ck2[u][1]), val[r] += dgk;
+                            }
+                            if (bi == brow) { // the scaled rhs in row Pp
+                                const double rk = diagH[16 * bk + lr];
+#pragma unroll
+                                for (int r = 0; r < 4; ++r)
+                                    if (16 * bi + lk + 4 * r == Pp) val[r] = rk;
+                            }
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) acc[i][r] = -val[r];
+                        }
+                    }
+                }
             }
+            PV_STAMPV(2, 22, q);
+            double s1[1] = {q};
+            block_sum<1>(s1, red_scratch);
+            if (tid == 0) c->pose_qvv = s1[0];
+            PV_STAMP(2, 23);
         }
         // columns [o2, o2 + 8) of slot i's tile -> Xs (row-major, 8 per row; still negated)
 #define PV_PUBLISH(i, o2)                                                                               \
@@ -1966,8 +2116,9 @@ hipError_t launch_linearize(const View &v, hipStream_t st) {
 
 hipError_t launch_reduce(const View &v, hipStream_t st) {
     const size_t total = (size_t)v.dm.n_tasks * 9 + (size_t)kNumPoseVec * v.dm.P6 + kNumLinScal;
-    const int grid = (int)((total + kRedElems - 1) / kRedElems);
-    hipLaunchKernelGGL(k_reduce, dim3(grid), dim3(kRedElems * kRedGroups), 0, st, v);
+    const int nb_red = (int)((total + kRedElems - 1) / kRedElems);
+    const int nb_img = v.dm.use_img ? (v.dm.img_sz + kRedElems - 1) / kRedElems : 0;
+    hipLaunchKernelGGL(k_reduce, dim3(nb_red + nb_img), dim3(kRedElems * kRedGroups), 0, st, v, nb_red);
     return hipGetLastError();
 }
 

@@ -161,8 +161,19 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st) {
     // latency-bound per workgroup, so chunks are sized to put one chunk on every CU (256 on MI355X) rather than to fill
     // the LDS; a large window falls back to LDS-filling chunks that each workgroup walks in a grid-stride loop. ----
     const size_t lds_budget = 112 * 1024;
+    dm.plane_slots = (int)std::max<size_t>(1, std::min<size_t>(lds_budget / 8 / (dm.P6 + 2), (size_t)kLinThreads));
+    std::vector<int32_t> plane_chunk;
+    for (int f = 0; f <= dm.n_plane; f += dm.plane_slots) plane_chunk.push_back(f);
+    if (plane_chunk.empty() || plane_chunk.back() != dm.n_plane) plane_chunk.push_back(dm.n_plane);
+    dm.n_plane_chunks = (int)plane_chunk.size() - 1;
+    dm.G_plane = dm.n_plane > 0 ? std::max(1, std::min(dm.n_plane_chunks, std::max(1, cus / 4))) : 0;
+    dm.G_pre = dm.use_inertial ? N - 1 : 0;
+    dm.G_prior = dm.prior_n; // one workgroup per prior frame
+    // One workgroup fits on a CU (registers, LDS) and the IMU / prior workgroups are the longest: the landmark chunks get
+    // the CUs that are left, so that the whole grid is resident at once instead of queueing a second round behind it.
+    const int lm_cus = std::max(1, cus - dm.G_plane - dm.G_pre - dm.G_prior);
     const int slots_lds = (int)std::max<size_t>(1, std::min<size_t>(lds_budget / 8 / (40 * N + 46), (size_t)kLinThreads));
-    const int slots_spread = std::max(1, (M + cus - 1) / cus);
+    const int slots_spread = std::max(1, (M + lm_cus - 1) / lm_cus);
     dm.lm_slots = std::min(slots_lds, slots_spread);
     std::vector<int32_t> chunk_lm;
     chunk_lm.push_back(0);
@@ -179,16 +190,7 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st) {
         if (M > 0) chunk_lm.push_back(M);
     }
     dm.n_chunks = (int)chunk_lm.size() - 1;
-    dm.plane_slots = (int)std::max<size_t>(1, std::min<size_t>(lds_budget / 8 / (dm.P6 + 2), (size_t)kLinThreads));
-    std::vector<int32_t> plane_chunk;
-    for (int f = 0; f <= dm.n_plane; f += dm.plane_slots) plane_chunk.push_back(f);
-    if (plane_chunk.empty() || plane_chunk.back() != dm.n_plane) plane_chunk.push_back(dm.n_plane);
-    dm.n_plane_chunks = (int)plane_chunk.size() - 1;
-
-    dm.G_lm = std::max(1, std::min(dm.n_chunks, cus));
-    dm.G_plane = dm.n_plane > 0 ? std::max(1, std::min(dm.n_plane_chunks, std::max(1, cus / 4))) : 0;
-    dm.G_pre = dm.use_inertial ? N - 1 : 0;
-    dm.G_prior = dm.prior_n; // one workgroup per prior frame
+    dm.G_lm = std::max(1, std::min(dm.n_chunks, lm_cus));
     dm.G_back = std::max(1, std::min(64, (M + 255) / 256));
     dm.fuse_backsub = (world_ == 1 && M <= 256) ? 1 : 0; // beyond one landmark per thread the separate launch is faster
     dm.n_back_rows = (world_ > 1 || dm.fuse_backsub) ? 1 : dm.G_back;
@@ -271,6 +273,18 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st) {
     ok &= dev(pool_, "prior_cost", (size_t)std::max(dm.prior_n, 1), &v.prior_cost, &grew);
     const size_t P = dm.P;
     ok &= dev(pool_, "Smat", dense_tile_doubles(dm), &v.Smat, &grew);
+    // tile image: k_reduce also assembles the reduced system entry by entry where the dense kernel's tile owners load it
+    // from (single GPU, system resident in LDS/registers); zero wherever nothing is ever written
+    {
+        int lds_matrix = 0;
+        dense_lds_bytes(dm, &lds_matrix);
+        const size_t img_sz = dense_tile_doubles(dm);
+        v.dm.use_img = (world_ == 1 && lds_matrix) ? 1 : 0;
+        v.dm.img_sz = (int)img_sz;
+        dm.use_img = v.dm.use_img, dm.img_sz = v.dm.img_sz;
+        ok &= dev(pool_, "img", img_sz, &v.img, &grew);
+        if (ok && v.dm.use_img && check(hipMemsetAsync(v.img, 0, img_sz * sizeof(double), stream_), "memset img")) return PVIO_ERR_HIP;
+    }
     ok &= dev(pool_, "cp", P, &v.cp, &grew);
     ok &= dev(pool_, "Dp", P, &v.Dp, &grew);
     ok &= dev(pool_, "gtot", P, &v.gtot, &grew);

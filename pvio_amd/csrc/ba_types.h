@@ -84,6 +84,8 @@ struct Dims {
     int32_t n_back_rows;  // rows of back partials k_linearize must sum (G_back, or 1 after an all-reduce)
     int32_t world, rank;
     int32_t fuse_backsub; // landmark back-substitution inside k_dense (small windows, single GPU)
+    int32_t use_img;      // k_reduce also assembles the reduced system as a tile image the dense kernel loads straight into registers
+    int32_t img_sz;       // doubles in the image (tiles * 256)
     int32_t pad_;
 };
 
@@ -123,7 +125,9 @@ struct View { // passed by value to every kernel
     double *pre_H, *pre_g, *pre_cost;       // [N][900], [N][30], [N]
     double *prior_H, *prior_g, *prior_cost; // [(15n)^2], [15n], [1]
     // dense system
-    double *Smat;      // [P*P]
+    double *Smat;      // tile image of the reduced system (systems too large for LDS)
+    double *img;       // the unscaled reduced system as a tile image (lower block triangle, MFMA accumulator order), written by
+                       // k_reduce; zero wherever nothing is ever written
     double *cp, *Dp, *gtot, *ghp, *vstep, *ystep; // [P] each
     // trace
     TraceRec *trace;
