@@ -74,6 +74,26 @@ __device__ __forceinline__ double readlane_f64(double x, int src) {
     u.i[1] = __builtin_amdgcn_readlane(u.i[1], src);
     return u.d;
 }
+// sum over aligned groups of 8 lanes, result in every lane of the group: quad_perm [1,0,3,2], quad_perm [2,3,0,1], then
+// row_half_mirror (lane i <-> 7 - i inside the group; the quads are uniform by then).  DPP moves, no LDS crossbar.
+__device__ __forceinline__ double group8_sum(double x) {
+#ifdef PV_HIPEMU
+    x += __shfl_xor(x, 1);
+    x += __shfl_xor(x, 2);
+    x += __shfl_xor(x, 4);
+    return x;
+#else
+    union { double d; int i[2]; } u, t;
+    u.d = x;
+    t.i[0] = __builtin_amdgcn_update_dpp(0, u.i[0], 0xB1, 0xF, 0xF, true), t.i[1] = __builtin_amdgcn_update_dpp(0, u.i[1], 0xB1, 0xF, 0xF, true);
+    u.d += t.d;
+    t.i[0] = __builtin_amdgcn_update_dpp(0, u.i[0], 0x4E, 0xF, 0xF, true), t.i[1] = __builtin_amdgcn_update_dpp(0, u.i[1], 0x4E, 0xF, 0xF, true);
+    u.d += t.d;
+    t.i[0] = __builtin_amdgcn_update_dpp(0, u.i[0], 0x141, 0xF, 0xF, true), t.i[1] = __builtin_amdgcn_update_dpp(0, u.i[1], 0x141, 0xF, 0xF, true);
+    u.d += t.d;
+    return u.d;
+#endif
+}
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
@@ -997,13 +1017,13 @@ template <bool LDSMAT> // compile-time storage choice: a runtime LDS-or-global p
 __global__ void __launch_bounds__(kDenseThreads) k_dense(View v) {
     // 256 threads = one wave per SIMD: the redundant 8 x 8 block factorization then costs each SIMD exactly once
     HIP_DYNAMIC_SHARED(double, lds)
-    Ctrl *c = v.ctrl;
-    if (c->done) return;
+    Ctrl *const cg = v.ctrl;
+    if (cg->done) return;
     const int N = v.dm.N, d = v.dm.d, P = v.dm.P, P6 = v.dm.P6, tid = threadIdx.x;
     constexpr int nthr = kDenseThreads;
     const size_t nS = (size_t)v.dm.n_tasks * 9;
-    const double *redV = v.red + nS, *redS = v.red + nS + (size_t)kNumPoseVec * P6;
-    // dynamic LDS: [header 224][8 vectors of LDV][Lp: panel, LDV x 8][A: tiles]   (no static LDS: keeps the dynamic base
+    const double *redV = v.red + nS;
+    // dynamic LDS: [header 352][8 vectors of LDV][Lp: panel, LDV x 8][A: tiles]   (no static LDS: keeps the dynamic base
     // 16-byte aligned, cdna_hip_programming.md Guideline 17).  Row Pp of A is the right-hand side, so the factorization
     // performs the forward substitution on the fly; rows above it are zero padding.
     DenseShared &sh = *reinterpret_cast<DenseShared *>(lds);
@@ -1016,12 +1036,26 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(View v) {
     double *Dg = lds + 144; // packed lower triangle of the next 8 x 8 diagonal block (36 doubles)
     int *pvalid = reinterpret_cast<int *>(lds + 184); // [N <= 32] IMU factor j present
     int *pframe = reinterpret_cast<int *>(lds + 200); // [prior_n <= 32] frame of prior slot q
-    double *vec = lds + 224;
+    Ctrl *const c = reinterpret_cast<Ctrl *>(lds + 224); // the control block is worked on in LDS and written back on exit
+    static_assert(sizeof(Ctrl) <= 48 * sizeof(double) && sizeof(Ctrl) % sizeof(double) == 0, "LDS header layout");
+    double *redS = lds + 272;     // [8] reduced scalars of the linearization
+    double *aux_costs = lds + 280; // [N + prior_n <= 64] IMU factor costs (0 where absent) and prior costs
+    double *vec = lds + 352;
     double *Lp = vec + 8 * (size_t)LDV;
     double *A = LDSMAT ? Lp + 8 * (size_t)LDV : v.Smat;
     double *diagH = vec, *gtot = vec + LDV, *rhs = vec + 2 * LDV, *yv = vec + 3 * LDV, *vv = vec + 4 * LDV, *act = vec + 5 * LDV,
            *tmp = vec + 6 * LDV, *cpl = vec + 7 * LDV;
     double *ysol = rhs; // solution of the reduced system (rhs is dead once the augmented row has been written)
+    // Everything the control section reads comes in with one round of parallel loads (a dependent chain of single-thread
+    // global loads costs a trip through the fabric each: the producers ran on other XCDs).
+    {
+        constexpr int nw = (int)(sizeof(Ctrl) / sizeof(double));
+        const double *src = reinterpret_cast<const double *>(cg);
+        if (tid < nw) reinterpret_cast<double *>(c)[tid] = src[tid];
+        else if (tid < 64 + kNumLinScal && tid >= 64) redS[tid - 64] = v.red[nS + (size_t)kNumPoseVec * P6 + (tid - 64)];
+        else if (tid >= 128 && tid < 128 + N) aux_costs[tid - 128] = (tid - 128 >= 1 && v.dm.G_pre && v.pre_valid[tid - 128]) ? v.pre_cost[tid - 128] : 0.0;
+        else if (tid >= 192 && tid < 192 + v.dm.prior_n) aux_costs[N + tid - 192] = v.prior_cost[tid - 192];
+    }
     // Tile ownership of the register-resident factorization (LDSMAT): wave w owns tiles w, w + 4, ... of the block triangle
     // enumerated by DEscending tile column, so that the tiles still alive at any panel are a prefix of every wave's list.
     constexpr int kSlots = LDSMAT ? 17 : 1; // ceil(66 / 4): LDV <= 176
@@ -1078,15 +1112,15 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(View v) {
             }
         }
     }
+    __syncthreads(); // the staged control inputs are in LDS (global loads stay in flight across the barrier)
     // ---------------- control (thread 0): Finalize the iteration in flight, decide what comes next ----------------
     if (tid == 0) {
         const int lr = c->lin_result;
         sh.do_solve = 0, sh.do_trace = 0, sh.accepted = 0, sh.first = 0;
         double aux_cost = 0;
         if (lr != LIN_INVALID_STEP) {
-            for (int j = 1; j < N; ++j)
-                if (v.dm.G_pre && v.pre_valid[j]) aux_cost += v.pre_cost[j];
-            for (int i = 0; i < v.dm.prior_n; ++i) aux_cost += v.prior_cost[i];
+            for (int j = 1; j < N; ++j) aux_cost += aux_costs[j]; // 0 where there is no factor (x + 0 is exact)
+            for (int i = 0; i < v.dm.prior_n; ++i) aux_cost += aux_costs[N + i];
         }
         const double lm_cost = redS[0], lm_bad = redS[5];
         double total_cost = aux_cost + lm_cost;
@@ -1158,7 +1192,7 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(View v) {
     }
     __syncthreads();
     if (c->done && !sh.do_trace) {
-        if (tid == 0) c->mode = MODE_DONE;
+        if (tid == 0) c->mode = MODE_DONE, *cg = *c;
         return;
     }
     PV_STAMP(2, 1);
@@ -1260,10 +1294,13 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(View v) {
     }
     __syncthreads();
     if (c->done) {
-        if (tid == 0) c->mode = MODE_DONE;
+        if (tid == 0) c->mode = MODE_DONE, *cg = *c;
         return;
     }
-    if (!sh.do_solve) return;
+    if (!sh.do_solve) {
+        if (tid == 0) *cg = *c;
+        return;
+    }
 
     PV_STAMP(2, 3);
     // ---------------- Jacobi scaling (once), dogleg diagonal, scaled system ----------------
@@ -1460,24 +1497,23 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(View v) {
                     x[2 * h] = -g2[0], x[2 * h + 1] = -g2[1];
                 }
             }
-            // right-looking: after pivot cc the remaining block entries are updated at once (short dependent chain)
+            // right-looking, without ever forming the block's own L: the update of pivot cc is
+            // A'[r][c2] -= A'[r][cc] * Ls[c2][cc] with Ls[c2][cc] = A'[c2][cc] / d_cc (= L[c2][cc] / L[cc][cc], which is
+            // also what the forward substitution of the rows below needs); 1 / L_cc is only used for the final scaling
+            double Ls[kPanel][kPanel];
 #pragma unroll
             for (int cc = 0; cc < kPanel; ++cc) {
                 const double dd = Ld[cc][cc];
                 fail |= (!(dd > 0.0) || !isfinite(dd)) ? 1 : 0;
                 inv[cc] = fast_rsqrt(dd);
+                const double inv2 = inv[cc] * inv[cc];
 #pragma unroll
-                for (int r = cc + 1; r < kPanel; ++r) Ld[r][cc] *= inv[cc];
+                for (int r = cc + 1; r < kPanel; ++r) Ls[r][cc] = Ld[r][cc] * inv2;
 #pragma unroll
                 for (int r = cc + 1; r < kPanel; ++r)
 #pragma unroll
-                    for (int c2 = cc + 1; c2 <= r; ++c2) Ld[r][c2] -= Ld[r][cc] * Ld[c2][cc];
+                    for (int c2 = cc + 1; c2 <= r; ++c2) Ld[r][c2] -= Ld[r][cc] * Ls[c2][cc];
             }
-            double Ls[kPanel][kPanel]; // L_dd[c2][cc] / L_dd[cc][cc]
-#pragma unroll
-            for (int cc = 0; cc < kPanel; ++cc)
-#pragma unroll
-                for (int c2 = cc + 1; c2 < kPanel; ++c2) Ls[c2][cc] = Ld[c2][cc] * inv[cc];
             if (j0 == 0) PV_STAMP(2, 9);
             if (j0 == 80) PV_STAMP(2, 14);
             if (fail) break; // uniform: every thread factored the same block
@@ -1599,48 +1635,32 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(View v) {
             block_sum<1>(s1, red_scratch);
             if (tid == 0) c->pose_qyy = s1[0]; // y^T (S + mu D^2) y = |z|^2 ; the mu term is removed below
             __syncthreads();
-            // every thread forms y_b = L_bb^-T z_b redundantly (broadcast loads), then the rows above the block are
-            // updated in parallel.  One barrier per block.
+            // Every wave forms y_b = L_bb^-T z_b on its own (no extra barrier): lane (c, r) multiplies (L_bb^-1)[r][c] z_r,
+            // three butterfly steps sum over r, eight lane reads broadcast y_b to the wave; then the rows above the block
+            // are updated in parallel.  One barrier per block.
+            const int lc = lane >> 3, lrr = lane & 7;
             for (int p = npan - 1; p >= 0; --p) {
                 const int jb0 = p * kPanel;
                 double lrow[kPanel]; // L(jb0 + cc, a) for this thread's row a (independent of y: issued first)
                 const int a = tid;
+                double ya = 0;
                 if (a < jb0) {
                     const double *T = Lf + lf_at(jb0, a);
 #pragma unroll
                     for (int cc = 0; cc < kPanel; ++cc) lrow[cc] = T[8 * cc];
+                    ya = yv[a];
                 }
-                double zb[kPanel], yb[kPanel];
-                {
-                    const lds_d2 *Z = reinterpret_cast<const lds_d2 *>(yv + jb0);
+                double part = Li[p * 64 + lane] * yv[jb0 + lrr]; // Li[p][c][r] = (L_pp^-1)[r][c]
+                part = group8_sum(part);
+                double yb[kPanel];
 #pragma unroll
-                    for (int h = 0; h < 4; ++h) {
-                        const lds_d2 z2 = Z[h];
-                        zb[2 * h] = z2[0], zb[2 * h + 1] = z2[1];
-                    }
-                }
-                const lds_d2 *L2 = reinterpret_cast<const lds_d2 *>(Li + p * 64);
-#pragma unroll
-                for (int cc = 0; cc < kPanel; ++cc) {
-                    double s = 0;
-#pragma unroll
-                    for (int h = 0; h < 4; ++h) {
-                        const lds_d2 l2 = L2[cc * 4 + h];
-                        s += l2[0] * zb[2 * h] + l2[1] * zb[2 * h + 1];
-                    }
-                    yb[cc] = s;
-                }
-                if (tid < kPanel) {
-                    double yo = yb[0];
-#pragma unroll
-                    for (int cc = 1; cc < kPanel; ++cc) yo = (tid == cc) ? yb[cc] : yo;
-                    ysol[jb0 + tid] = yo;
-                }
+                for (int cc = 0; cc < kPanel; ++cc) yb[cc] = readlane_f64(part, 8 * cc);
+                if (wv == 0 && lrr == 0) ysol[jb0 + lc] = part;
                 if (a < jb0) {
                     double acc2 = 0;
 #pragma unroll
                     for (int cc = 0; cc < kPanel; ++cc) acc2 += lrow[cc] * yb[cc];
-                    yv[a] -= acc2;
+                    yv[a] = ya - acc2;
                 }
                 __syncthreads();
             }
@@ -1921,7 +1941,10 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(View v) {
         sh.do_solve = ok;
     }
     __syncthreads();
-    if (!sh.do_solve) return;
+    if (!sh.do_solve) {
+        if (tid == 0) *cg = *c;
+        return;
+    }
     // y solves (S + mu D^2) y = rhs_s ; step direction y' = -y ; gn = D y'
     {
         double s_g2 = 0, s_gn2 = 0, s_gd = 0, s_qvy = 0, s_gy = 0;
@@ -1959,6 +1982,8 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(View v) {
             v.back_part[6] = v.back_part[7] = 0;
         }
     }
+    __syncthreads();
+    if (tid == 0) *cg = *c;
     PV_STAMP(2, 7);
     if (v.dbg && threadIdx.x == 0) v.dbg[2 * 32 + 31] = wall_clock64();
 }
@@ -2128,7 +2153,7 @@ size_t dense_tile_doubles(const Dims &dm) {
 }
 size_t dense_lds_bytes(const Dims &dm, int *lds_matrix) {
     const size_t nbk = ((((size_t)dm.P + 7) & ~(size_t)7) + 16) >> 4, LDV = nbk << 4;
-    const size_t vec = (224 + 16 * LDV) * sizeof(double); // header, 8 vectors, panel buffer
+    const size_t vec = (352 + 16 * LDV) * sizeof(double); // header, 8 vectors, panel buffer
     const size_t npan = (((size_t)dm.P + 7) & ~(size_t)7) / 8;
     const size_t lfull = 8 * (npan * LDV - 4 * npan * (npan - 1)); // finished panels of L (overlays the tile image)
     const size_t mat = std::max(dense_tile_doubles(dm), lfull) * sizeof(double);
