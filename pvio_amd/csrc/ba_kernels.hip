@@ -723,47 +723,59 @@ __global__ void __launch_bounds__(kLinThreads) k_linearize(View v) {
 // k_reduce: fixed-order sums of the WG partials -> red = [S tiles (element-major) | 3 pose vectors | 8 scalars]
 // ------------------------------------------------------------------------------------------------------
 constexpr int kRedElems = 64, kRedGroups = 16; // one block = 64 output elements x 16 partial groups
-// Blocks [0, nb_red) produce `red` (tiles element-major, pose vectors, scalars).  With tile images on (single GPU, reduced
-// system resident in the dense kernel's registers) further blocks produce the UNSCALED reduced system itself, entry by
-// entry in the order the dense kernel's tile owners load it (lower block triangle, 16 x 16 tiles, MFMA accumulator order):
-// the same fixed-order sum of the landmark / plane partials as red[e], plus the IMU factor blocks (odd factor first) and
-// the marginalization prior.  Entries outside the real lower triangle are never written (the image is zeroed at upload).
+// IMU factor blocks (odd factor first) and marginalization prior added to entry ((fa, ka), (fb, kb)), fb <= fa, of the
+// unscaled reduced system whose landmark / plane part is `val`
+__device__ __forceinline__ double reduced_entry_terms(const View &v, double val, int fa, int ka, int fb, int kb) {
+    if (v.dm.d != 15) return val;
+    const int N = v.dm.N;
+    if (v.dm.G_pre) {
+        // factor j couples frames j - 1 (local 0..14) and j (local 15..29)
+        const bool same = fa == fb, adj = fa == fb + 1;
+        const double hA = (fa >= 1 && (same || adj) && v.pre_valid[fa]) ? v.pre_H[(size_t)fa * 900 + (15 + ka) * 30 + (same ? 15 : 0) + kb] : 0.0;
+        const double hB = (same && fa + 1 < N && v.pre_valid[fa + 1]) ? v.pre_H[(size_t)(fa + 1) * 900 + ka * 30 + kb] : 0.0;
+        val = (fa & 1) ? (val + hA) + hB : (val + hB) + hA;
+    }
+    int pa = -1, pb = -1;
+    for (int q = 0; q < v.dm.prior_n; ++q) {
+        const int f = v.prior_frames[q];
+        pa = f == fa ? q : pa, pb = f == fb ? q : pb;
+    }
+    if (pa >= 0 && pb >= 0) val += v.prior_H[(size_t)(15 * pa + ka) * (15 * v.dm.prior_n) + 15 * pb + kb];
+    return val;
+}
+
+// Blocks [0, nb_red) produce `red` (tiles element-major, pose vectors, scalars).  With the tile image on (single GPU,
+// reduced system resident in the dense kernel's registers) the UNSCALED reduced system is also written entry by entry
+// where the dense kernel's tile owners load it (lower block triangle, 16 x 16 tiles, MFMA accumulator order): the thread
+// that finishes tile element red[e] adds the IMU factor blocks and the prior and stores the entry; the entries that have
+// no landmark / plane part (a velocity or bias coordinate) come from the blocks behind nb_red, which read no partials.
+// Entries outside the real lower triangle are never written (the image is zeroed at upload).
 __global__ void __launch_bounds__(kRedElems *kRedGroups) k_reduce(View v, int nb_red) {
-    if (v.ctrl->done || v.ctrl->lin_result == LIN_INVALID_STEP) return;
-    __shared__ double part[kRedGroups][kRedElems];
-    const int G = v.dm.G_lm + v.dm.G_plane;
+    // the control word is only needed before anything is written: its load travels together with the partials
+    const int ctl_done = v.ctrl->done, ctl_result = v.ctrl->lin_result;
     const size_t nS = (size_t)v.dm.n_tasks * 9, nV = (size_t)kNumPoseVec * v.dm.P6;
     const size_t total = nS + nV + kNumLinScal;
-    const int el = threadIdx.x & (kRedElems - 1), gg = threadIdx.x / kRedElems;
-    const bool img_block = (int)blockIdx.x >= nb_red;
-    size_t e = (size_t)blockIdx.x * kRedElems + el;
-    // image entry -> (row i, column k) of the reduced system and the tile element it sums (or none)
-    int i = 0, k = 0, fa = 0, ka = 0, fb = 0, kb = 0;
-    bool entry = false;
-    size_t pos = 0;
-    if (img_block) {
-        const int d = v.dm.d, P = v.dm.P, N = v.dm.N;
-        pos = (size_t)(blockIdx.x - nb_red) * kRedElems + el;
+    if ((int)blockIdx.x >= nb_red) {
+        if (ctl_done || ctl_result == LIN_INVALID_STEP) return;
+        const int d = v.dm.d, P = v.dm.P;
+        const size_t pos = ((size_t)(blockIdx.x - nb_red) * blockDim.x + threadIdx.x);
+        if (pos >= (size_t)v.dm.img_sz) return;
         const int ti = (int)(pos >> 8), w = (int)(pos & 255), ln = w >> 2, r = w & 3;
         int bi = (int)((sqrtf(8.0f * ti + 1.0f) - 1.0f) * 0.5f);
         while (((bi + 1) * (bi + 2)) >> 1 <= ti) ++bi;
         while (((bi * (bi + 1)) >> 1) > ti) --bi;
         const int bk = ti - ((bi * (bi + 1)) >> 1);
-        i = 16 * bi + (ln >> 4) + 4 * r, k = 16 * bk + (ln & 15);
-        entry = pos < (size_t)v.dm.img_sz && k <= i && i < P;
-        e = total; // no tile element unless set below
-        if (entry) {
-            fa = i / d, ka = i - d * fa, fb = k / d, kb = k - d * fb;
-            if (ka < 6 && kb < 6) {
-                const int p = fb * N - ((fb * (fb - 1)) >> 1) + (fa - fb); // tile tasks enumerate the upper block triangle (fb <= fa)
-                const int sa = ka >= 3, sb = kb >= 3, ra = ka - 3 * sa, rb = kb - 3 * sb;
-                const bool same = fa == fb;
-                const int t = 4 * p + (same ? 2 * sa + sb : 2 * sb + sa); // rows of an off-diagonal task = the earlier frame
-                const int q = same ? 3 * ra + rb : 3 * rb + ra;            // diagonal blocks come in full
-                e = (size_t)q * v.dm.n_tasks + t;
-            }
-        }
+        const int i = 16 * bi + (ln >> 4) + 4 * r, k = 16 * bk + (ln & 15);
+        if (k > i || i >= P) return;
+        const int fa = i / d, ka = i - d * fa, fb = k / d, kb = k - d * fb;
+        if (ka < 6 && kb < 6) return; // has a landmark / plane part: written by the thread that reduces it
+        v.img[pos] = reduced_entry_terms(v, 0.0, fa, ka, fb, kb);
+        return;
     }
+    __shared__ double part[kRedGroups][kRedElems];
+    const int G = v.dm.G_lm + v.dm.G_plane;
+    const int el = threadIdx.x & (kRedElems - 1), gg = threadIdx.x / kRedElems;
+    const size_t e = (size_t)blockIdx.x * kRedElems + el;
     // stage 1: group gg sums partials g = gg, gg + 16, ... (coalesced across el), four independent accumulators
     double s = 0;
     if (e < nS + nV) {
@@ -784,34 +796,22 @@ __global__ void __launch_bounds__(kRedElems *kRedGroups) k_reduce(View v, int nb
         const int q = (int)(e - nS - nV);
         for (int g = gg; g < G; g += kRedGroups) s = (q == 4) ? fmax(s, v.part_scal[(size_t)g * kNumLinScal + q]) : s + v.part_scal[(size_t)g * kNumLinScal + q];
     }
+    if (ctl_done || ctl_result == LIN_INVALID_STEP) return; // uniform
     part[gg][el] = s;
     __syncthreads();
     // stage 2: fixed-order combination of the 16 group sums
-    if (gg == 0 && (img_block ? entry : e < total)) {
+    if (gg == 0 && e < total) {
         const bool is_max = e >= nS + nV && (int)(e - nS - nV) == 4;
         double r = part[0][el];
         for (int q = 1; q < kRedGroups; ++q) r = is_max ? fmax(r, part[q][el]) : r + part[q][el];
-        if (!img_block) {
-            v.red[e] = r;
-        } else {
-            double val = r; // 0 unless both coordinates are pose coordinates
-            if (v.dm.d == 15) {
-                const int N = v.dm.N;
-                if (v.dm.G_pre) {
-                    // factor j couples frames j - 1 (local 0..14) and j (local 15..29); odd factors first
-                    const bool same = fa == fb, adj = fa == fb + 1;
-                    const double hA = (fa >= 1 && (same || adj) && v.pre_valid[fa]) ? v.pre_H[(size_t)fa * 900 + (15 + ka) * 30 + (same ? 15 : 0) + kb] : 0.0;
-                    const double hB = (same && fa + 1 < N && v.pre_valid[fa + 1]) ? v.pre_H[(size_t)(fa + 1) * 900 + ka * 30 + kb] : 0.0;
-                    val = (fa & 1) ? (val + hA) + hB : (val + hB) + hA;
-                }
-                int pa = -1, pb = -1;
-                for (int q = 0; q < v.dm.prior_n; ++q) {
-                    const int f = v.prior_frames[q];
-                    pa = f == fa ? q : pa, pb = f == fb ? q : pb;
-                }
-                if (pa >= 0 && pb >= 0) val += v.prior_H[(size_t)(15 * pa + ka) * (15 * v.dm.prior_n) + 15 * pb + kb];
-            }
-            v.img[pos] = val;
+        v.red[e] = r;
+        if (v.dm.use_img && e < nS) {
+            const int n_tasks = v.dm.n_tasks, ee = (int)e, q = ee / n_tasks, t = ee - q * n_tasks, d = v.dm.d;
+            int fi, fj, si, sj;
+            unpack_task(v.task_desc[t], fi, fj, si, sj);
+            const int ra = 3 * si + q / 3, ca = 3 * sj + q % 3; // coordinates inside frames fi (row of the task) and fj, fi <= fj
+            if (fi != fj) v.img[mat_at(d * fj + ca, d * fi + ra)] = reduced_entry_terms(v, r, fj, ca, fi, ra);
+            else if (ra >= ca) v.img[mat_at(d * fi + ra, d * fi + ca)] = reduced_entry_terms(v, r, fi, ra, fi, ca); // diagonal blocks come in full
         }
     }
 }
@@ -1018,7 +1018,6 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(View v) {
     // 256 threads = one wave per SIMD: the redundant 8 x 8 block factorization then costs each SIMD exactly once
     HIP_DYNAMIC_SHARED(double, lds)
     Ctrl *const cg = v.ctrl;
-    if (cg->done) return;
     const int N = v.dm.N, d = v.dm.d, P = v.dm.P, P6 = v.dm.P6, tid = threadIdx.x;
     constexpr int nthr = kDenseThreads;
     const size_t nS = (size_t)v.dm.n_tasks * 9;
@@ -1113,6 +1112,7 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(View v) {
         }
     }
     __syncthreads(); // the staged control inputs are in LDS (global loads stay in flight across the barrier)
+    if (c->done) return; // nothing was modified
     // ---------------- control (thread 0): Finalize the iteration in flight, decide what comes next ----------------
     if (tid == 0) {
         const int lr = c->lin_result;
@@ -2142,7 +2142,7 @@ hipError_t launch_linearize(const View &v, hipStream_t st) {
 hipError_t launch_reduce(const View &v, hipStream_t st) {
     const size_t total = (size_t)v.dm.n_tasks * 9 + (size_t)kNumPoseVec * v.dm.P6 + kNumLinScal;
     const int nb_red = (int)((total + kRedElems - 1) / kRedElems);
-    const int nb_img = v.dm.use_img ? (v.dm.img_sz + kRedElems - 1) / kRedElems : 0;
+    const int nb_img = v.dm.use_img ? (v.dm.img_sz + kRedElems * kRedGroups - 1) / (kRedElems * kRedGroups) : 0;
     hipLaunchKernelGGL(k_reduce, dim3(nb_red + nb_img), dim3(kRedElems * kRedGroups), 0, st, v, nb_red);
     return hipGetLastError();
 }
