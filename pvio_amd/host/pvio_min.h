@@ -162,6 +162,18 @@ class Config { // the three values the seam reads (pvio.h:70-112)
     virtual double plane_distance_cov() const { return 1.0e-4; }
 };
 
+class Image { // pvio/include/pvio/pvio.h:114-133 (evaluate() has no caller in the library and is left out)
+  public:
+    double t = 0;
+    virtual size_t width() const = 0;
+    virtual size_t height() const = 0;
+    virtual size_t level_num() const { return 0; }
+    virtual ~Image() = default;
+    virtual void preprocess() {}
+    virtual void detect_keypoints(std::vector<vector<2>> &keypoints, size_t max_points = 0, double keypoint_distance = 0.5) const = 0;
+    virtual void track_keypoints(const Image *next_image, const std::vector<vector<2>> &curr_keypoints, std::vector<vector<2>> &next_keypoints, std::vector<char> &result_status) const = 0;
+};
+
 class BundleAdjustor { // estimation/bundle_adjustor.h:29-42
   public:
     BundleAdjustor();

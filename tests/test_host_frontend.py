@@ -1,0 +1,156 @@
+"""Host side of the FeatureTracker seam (pvio_amd/host/feature_front.*): Poisson-disk filter, survivor selection, gyro
+keypoint prediction, and the pvio::Image adapter over the C ABI.  Checked against the independent restatement in
+oracle/oracle_front.cpp and against brute-force properties (the reference has no tests for this code)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import host_compare
+from oracle import oracle_py
+from pvio_amd import synth
+
+u8p, f64p, u64p = C.POINTER(C.c_uint8), C.POINTER(C.c_double), C.POINTER(C.c_uint64)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+@pytest.fixture(scope="module")
+def host():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(os.path.dirname(os.path.abspath(__file__)), "hipemu"), "libpvio_hipemu.so"])
+    return host_compare.load("libpvio_host_emu.so")
+
+
+@pytest.fixture(scope="module")
+def ora():
+    oracle_py.build()
+    return oracle_py.lib()
+
+
+def poisson(lib, prefix, radius, preset, pts):
+    acc = np.zeros(len(pts), np.uint8)
+    preset = np.ascontiguousarray(preset, np.float64).reshape(-1, 2)
+    pts = np.ascontiguousarray(pts, np.float64).reshape(-1, 2)
+    getattr(lib, prefix + "_poisson_insert")(C.c_double(radius), C.c_int(len(preset)), _p(preset if len(preset) else np.zeros((1, 2)), f64p),
+                                             C.c_int(len(pts)), _p(pts, f64p), _p(acc, u8p))
+    return acc.astype(bool)
+
+
+@pytest.mark.parametrize("seed,radius,n,extent", [(1, 20.0, 400, 300.0), (2, 7.5, 1500, 200.0), (3, 20.0, 50, 2000.0), (4, 1.0, 300, 6.0)])
+def test_poisson_filter_matches_oracle_and_is_a_maximal_packing(host, ora, seed, radius, n, extent):
+    rng = np.random.default_rng(seed)
+    pts = rng.uniform(-extent / 3, extent, (n, 2))  # negative coordinates too: the cell index is floor(), not truncation
+    a_host, a_ora = poisson(host, "host", radius, [], pts), poisson(ora, "oracle", radius, [], pts)
+    assert (a_host == a_ora).all()
+    acc = pts[a_host]
+    d = np.linalg.norm(acc[:, None, :] - acc[None, :, :], axis=2) + np.eye(len(acc)) * 1e9
+    assert d.min() >= radius  # the skipped corner cell and the extra probed cell never matter geometrically
+    for i in np.nonzero(~a_host)[0]:  # greedy in order: a rejected candidate is within radius of an EARLIER accepted one
+        earlier = pts[:i][a_host[:i]]
+        assert (np.linalg.norm(earlier - pts[i], axis=1) < radius).any()
+
+
+def test_poisson_preset_points_block_and_overwrite_their_cell(host, ora):
+    rng = np.random.default_rng(7)
+    preset = rng.uniform(0, 100, (40, 2))
+    pts = rng.uniform(0, 100, (300, 2))
+    a_host, a_ora = poisson(host, "host", 10.0, preset, pts), poisson(ora, "oracle", 10.0, preset, pts)
+    assert (a_host == a_ora).all()
+    # two presets in one cell: only the later one is remembered, so a candidate next to the EARLIER one can pass
+    r = 10.0
+    cell = r / np.sqrt(2.0)
+    first, second = np.array([0.1 * cell, 0.1 * cell]), np.array([0.9 * cell, 0.9 * cell])
+    cand = np.array([[-0.5 * cell, 0.1 * cell]])  # 0.6 cell from `first` (< r), farther than r from `second`
+    assert np.linalg.norm(cand[0] - first) < r <= np.linalg.norm(cand[0] - second)
+    for lib, prefix in ((host, "host"), (ora, "oracle")):
+        assert poisson(lib, prefix, r, [first], cand)[0] == False  # noqa: E712
+        assert poisson(lib, prefix, r, [first, second], cand)[0] == True  # noqa: E712
+
+
+@pytest.mark.parametrize("seed,n,ties", [(11, 300, False), (12, 800, True), (13, 5, True), (14, 0, False)])
+def test_survivor_selection_matches_oracle(host, ora, seed, n, ties):
+    rng = np.random.default_rng(seed)
+    nxt = np.ascontiguousarray(rng.uniform(20, 500, (max(n, 1), 2)))
+    length = (rng.integers(0, 4 if ties else 10**6, max(n, 1))).astype(np.uint64)  # 0 = keypoint without a track
+    status0 = (rng.uniform(size=max(n, 1)) < 0.8).astype(np.uint8)
+    out = {}
+    for lib, prefix in ((host, "host"), (ora, "oracle")):
+        st = status0.copy()
+        getattr(lib, prefix + "_select_tracked")(C.c_int(n), _p(nxt, f64p), _p(length, u64p), C.c_double(20.0), _p(st, u8p))
+        out[prefix] = st
+    assert (out["host"] == out["oracle"]).all()
+    st = out["host"][:n].astype(bool)
+    keep = st & (length[:n] > 0)
+    assert not (st & ~status0[:n].astype(bool)).any()  # nothing is resurrected
+    assert (st[length[:n] == 0] == status0[:n][length[:n] == 0].astype(bool)).all()  # trackless keypoints are left alone
+    if keep.sum() > 1:
+        p = nxt[:n][keep]
+        d = np.linalg.norm(p[:, None] - p[None], axis=2) + np.eye(len(p)) * 1e9
+        assert d.min() >= 20.0
+    if not ties and n:  # with distinct lengths the longest surviving input always survives
+        cand = np.nonzero(status0[:n].astype(bool) & (length[:n] > 0))[0]
+        if len(cand):
+            assert st[cand[np.argmax(length[:n][cand])]]
+
+
+def _rand_q(rng, angle):
+    ax = rng.normal(size=3)
+    ax /= np.linalg.norm(ax)
+    return np.concatenate([ax * np.sin(angle / 2), [np.cos(angle / 2)]])
+
+
+def test_keypoint_prediction_matches_oracle_and_rotates_bearings(host, ora):
+    rng = np.random.default_rng(5)
+    kp = np.ascontiguousarray(rng.uniform(-0.6, 0.6, (200, 2)))
+    K = np.array([458.654, 457.296, 367.215, 248.375])
+    q_ci, q_ii, dq, q_ij, q_cj = (_rand_q(rng, a) for a in (0.3, 0.0, 0.05, 0.0, 0.3))
+    q_cj = q_ci.copy()  # same rig
+    out = {}
+    for lib, prefix in ((host, "host"), (ora, "oracle")):
+        o = np.zeros_like(kp)
+        getattr(lib, prefix + "_predict_keypoints")(_p(q_ci, f64p), _p(q_ii, f64p), _p(dq, f64p), _p(q_ij, f64p), _p(q_cj, f64p), _p(K, f64p),
+                                                    C.c_int(len(kp)), _p(kp, f64p), _p(o, f64p))
+        out[prefix] = o
+    assert np.abs(out["host"] - out["oracle"]).max() < 1e-9
+    # no rotation between the frames: the prediction is the keypoint itself, in pixels
+    ident = np.array([0.0, 0, 0, 1])
+    o = np.zeros_like(kp)
+    host.host_predict_keypoints(_p(q_ci, f64p), _p(q_ii, f64p), _p(ident, f64p), _p(q_ij, f64p), _p(q_cj, f64p), _p(K, f64p), C.c_int(len(kp)), _p(kp, f64p), _p(o, f64p))
+    assert np.abs(o - (kp * K[:2] + K[2:])).max() < 1e-9
+    # 3 degrees of yaw move the image centre by about f * tan(3 deg)
+    assert 15 < np.abs(out["host"] - (kp * K[:2] + K[2:])).max() < 60
+
+
+def _image_seam(lib, oracle, w, h, n):
+    img0, img1, p, truth, init = synth.make_image_pair(w, h, n)
+    P0, P1 = oracle.build_pyramid(oracle.clahe(img0)), oracle.build_pyramid(oracle.clahe(img1))
+    n_ref, s_ref = oracle.klt_track(P0, P1, p, init)
+    gate = (n_ref[:, 0] < 20) | (n_ref[:, 0] >= w - 20) | (n_ref[:, 1] < 20) | (n_ref[:, 1] >= h - 20)  # opencv_image.cpp:106-108
+    s_ref = np.where(gate, 0, s_ref)
+    cur = np.ascontiguousarray(p, np.float64)
+    nxt = np.ascontiguousarray(init, np.float64)
+    st = np.zeros(n, np.uint8)
+    err = C.create_string_buffer(256)
+    rc = lib.host_image_track(_p(np.ascontiguousarray(img0), u8p), _p(np.ascontiguousarray(img1), u8p), C.c_int(w), C.c_int(h), C.c_int(n), _p(cur, f64p),
+                              _p(nxt, f64p), C.c_int(1), _p(st, u8p), err, C.c_int(256))
+    assert rc == 0, err.value
+    assert (st.astype(bool) == (s_ref > 0)).all()
+    ok = st > 0
+    assert np.abs(nxt - n_ref)[ok].max() <= 1e-3
+    if (~ok).any():
+        assert np.abs(nxt - init)[~ok].max() == 0.0  # failed tracks keep the caller's value (opencv_image.cpp:131-136)
+    return int(ok.sum())
+
+
+def test_image_seam_emulated(host, oracle):
+    assert _image_seam(host, oracle, 160, 120, 48) > 20
+
+
+@pytest.mark.gpu
+def test_image_seam_gpu(oracle):
+    lib = host_compare.load("libpvio_host.so")
+    assert _image_seam(lib, oracle, 512, 512, 1200) > 900
