@@ -168,3 +168,63 @@ int host_roundtrip_marginalize(const pvio_ba_problem *pb, const pvio_ba_state *s
 }
 
 } // extern "C"
+
+// ---- visual_inertial_pnp through the Map object graph: the window's last frame is taken out of the map (the reference
+// solves it before put_frame) and refined against the rest ------------------------------------------------------------
+#include "../../pvio_amd/host/pnp.h"
+
+extern "C" int host_roundtrip_pnp(const pvio_ba_problem *pb, pvio_ba_state *st, int32_t use_inertial, int32_t max_iter, double *state_out) {
+    Map map;
+    std::vector<Track *> lm_tracks;
+    build_map(pb, st, map, lm_tracks);
+    const int N = pb->n_frames;
+    std::unique_ptr<Frame> frame = std::move(map.frames.back());
+    map.frames.pop_back();
+    if (use_inertial) {
+        auto &d = frame->preintegration.delta;
+        const double *dl = pb->preint_delta + 11 * (N - 1);
+        d.t = dl[0];
+        std::memcpy(d.q.c, dl + 1, 32);
+        for (int k = 0; k < 3; ++k) d.p[k] = dl[5 + k], d.v[k] = dl[8 + k];
+        std::memcpy(d.sqrt_inv_cov, pb->preint_sqrt_inv_cov + 225 * (size_t)(N - 1), sizeof d.sqrt_inv_cov);
+        auto &jc = frame->preintegration.jacobian;
+        const double *j = pb->preint_jacobian + 45 * (size_t)(N - 1);
+        std::memcpy(jc.dq_dbg, j, 72), std::memcpy(jc.dp_dbg, j + 9, 72), std::memcpy(jc.dp_dba, j + 18, 72), std::memcpy(jc.dv_dbg, j + 27, 72), std::memcpy(jc.dv_dba, j + 36, 72);
+    }
+    Cfg cfg;
+    cfg.iters = (size_t)max_iter, cfg.plane_cov = 1e-4;
+    visual_inertial_pnp(&map, frame.get(), &cfg, use_inertial != 0);
+    std::memcpy(state_out, frame->pose.q.c, 32);
+    for (int k = 0; k < 3; ++k) state_out[4 + k] = frame->pose.p[k], state_out[7 + k] = frame->motion.v[k], state_out[10 + k] = frame->motion.bg[k], state_out[13 + k] = frame->motion.ba[k];
+    return 0;
+}
+
+// flat entry: world-point factors as well (PoseOnlyReprojectionXYZErrorCost)
+extern "C" int host_pnp_flat(const double *cam, const double *imu, const double *W, int32_t n, const double *anchor_states, const double *anchor_cams,
+                             const double *z_ref, const double *z_tgt, const double *rho, int32_t n_pts, const double *points, const double *z_pts,
+                             int32_t use_inertial, const double *last_state, const double *last_imu, const double *delta, const double *U, const double *jac,
+                             int32_t max_iter, double *state16, int32_t *iterations, int32_t *termination, double *costs2) {
+    PnpProblem pb;
+    std::memcpy(pb.cam, cam, 56), std::memcpy(pb.imu, imu, 56), std::memcpy(pb.sqrt_inv_cov, W, 32);
+    for (int k = 0; k < n; ++k) {
+        PnpFactor f;
+        std::memcpy(f.anchor_state, anchor_states + 16 * k, 128), std::memcpy(f.anchor_cam, anchor_cams + 7 * k, 56);
+        f.z_ref[0] = z_ref[2 * k], f.z_ref[1] = z_ref[2 * k + 1], f.z_tgt[0] = z_tgt[2 * k], f.z_tgt[1] = z_tgt[2 * k + 1], f.inv_depth = rho[k];
+        pb.factors.push_back(f);
+    }
+    for (int k = 0; k < n_pts; ++k) {
+        PnpPointFactor f;
+        std::memcpy(f.point, points + 3 * k, 24);
+        f.z_tgt[0] = z_pts[2 * k], f.z_tgt[1] = z_pts[2 * k + 1];
+        pb.point_factors.push_back(f);
+    }
+    pb.use_inertial = use_inertial != 0;
+    if (use_inertial) {
+        std::memcpy(pb.last_state, last_state, 128), std::memcpy(pb.last_imu, last_imu, 56);
+        std::memcpy(pb.delta, delta, 88), std::memcpy(pb.sqrt_inv_cov_imu, U, 1800), std::memcpy(pb.jac, jac, 360);
+    }
+    const dense::Summary s = solve_pnp(pb, state16, max_iter);
+    *iterations = s.iterations, *termination = s.termination;
+    costs2[0] = s.initial_cost, costs2[1] = s.final_cost;
+    return 0;
+}

@@ -132,8 +132,11 @@ class DenseProblem:
 
 def solve(pb, O, state_update=True):
     """Returns (trace list of dicts, final frame_state, final rho, termination)."""
-    D = DenseProblem(pb, O)
-    fs, rho = pb.frame_state.copy(), pb.lm_inv_depth.copy()
+    return solve_dense(DenseProblem(pb, O), pb.frame_state.copy(), pb.lm_inv_depth.copy(), pb.max_iterations, state_update)
+
+
+def solve_dense(D, fs, rho, max_iterations, state_update=True):
+    """The loop itself, for any problem object with evaluate(fs, rho, user, jac) / plus / ambient / ncols."""
     user = fs.copy()
     best = (fs.copy(), rho.copy())
     trace = []
@@ -162,7 +165,7 @@ def solve(pb, O, state_update=True):
                           state=np.concatenate([fs.ravel(), rho])))
         if success and state_update:
             user = best[0].copy()
-        if it >= pb.max_iterations:
+        if it >= max_iterations:
             term = 1
             break
         if success and grad_max <= 1e-10:
