@@ -53,10 +53,35 @@ using namespace pv;
 // ------------------------------------------------------------------------------------------------------
 // small reductions
 // ------------------------------------------------------------------------------------------------------
+// Wave reductions without the LDS crossbar: `__shfl_xor` on a double is two ds_bpermute per step (~100 cycles of
+// latency each, twelve per reduction); DPP moves inside the rows of 16 lanes plus four lane reads cost a tenth of that.
+// dpp_f64(x, ctrl): the value of the lane the DPP pattern pairs this lane with.
+__device__ __forceinline__ double dpp_f64(double x, int pattern /* 0: ^1, 1: ^2, 2: mirror in 8, 3: mirror in 16 */) {
+#ifdef PV_HIPEMU
+    const int lane = threadIdx.x & 63;
+    const int src = pattern == 0 ? (lane ^ 1) : pattern == 1 ? (lane ^ 2) : pattern == 2 ? ((lane & ~7) | (7 - (lane & 7))) : ((lane & ~15) | (15 - (lane & 15)));
+    return __shfl(x, src);
+#else
+    union { double d; int i[2]; } u, t;
+    u.d = x;
+    switch (pattern) {
+    case 0: t.i[0] = __builtin_amdgcn_update_dpp(0, u.i[0], 0xB1, 0xF, 0xF, true), t.i[1] = __builtin_amdgcn_update_dpp(0, u.i[1], 0xB1, 0xF, 0xF, true); break;   // quad_perm [1,0,3,2]
+    case 1: t.i[0] = __builtin_amdgcn_update_dpp(0, u.i[0], 0x4E, 0xF, 0xF, true), t.i[1] = __builtin_amdgcn_update_dpp(0, u.i[1], 0x4E, 0xF, 0xF, true); break;   // quad_perm [2,3,0,1]
+    case 2: t.i[0] = __builtin_amdgcn_update_dpp(0, u.i[0], 0x141, 0xF, 0xF, true), t.i[1] = __builtin_amdgcn_update_dpp(0, u.i[1], 0x141, 0xF, 0xF, true); break; // row_half_mirror
+    default: t.i[0] = __builtin_amdgcn_update_dpp(0, u.i[0], 0x140, 0xF, 0xF, true), t.i[1] = __builtin_amdgcn_update_dpp(0, u.i[1], 0x140, 0xF, 0xF, true); break; // row_mirror
+    }
+    return t.d;
+#endif
+}
+__device__ __forceinline__ double readlane_f64(double x, int src);
+// sum over the wave, result in every lane; fixed pairing: inside rows of 16 (^1, ^2, the other quad pair, the other
+// half row), then rows 0..3 in order
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    v += dpp_f64(v, 0);
+    v += dpp_f64(v, 1);
+    v += dpp_f64(v, 2);
+    v += dpp_f64(v, 3);
+    return ((readlane_f64(v, 0) + readlane_f64(v, 16)) + readlane_f64(v, 32)) + readlane_f64(v, 48);
 }
 // 1/sqrt(x) for the pivot chain of the block factorization: v_rsq_f64 (~2^-23 relative) + two Newton steps
 // (-> ~1 ulp).  ocml's correctly rounded sqrt + divide is ~40 dependent FP64 instructions per pivot.
@@ -77,27 +102,17 @@ __device__ __forceinline__ double readlane_f64(double x, int src) {
 // sum over aligned groups of 8 lanes, result in every lane of the group: quad_perm [1,0,3,2], quad_perm [2,3,0,1], then
 // row_half_mirror (lane i <-> 7 - i inside the group; the quads are uniform by then).  DPP moves, no LDS crossbar.
 __device__ __forceinline__ double group8_sum(double x) {
-#ifdef PV_HIPEMU
-    x += __shfl_xor(x, 1);
-    x += __shfl_xor(x, 2);
-    x += __shfl_xor(x, 4);
+    x += dpp_f64(x, 0);
+    x += dpp_f64(x, 1);
+    x += dpp_f64(x, 2);
     return x;
-#else
-    union { double d; int i[2]; } u, t;
-    u.d = x;
-    t.i[0] = __builtin_amdgcn_update_dpp(0, u.i[0], 0xB1, 0xF, 0xF, true), t.i[1] = __builtin_amdgcn_update_dpp(0, u.i[1], 0xB1, 0xF, 0xF, true);
-    u.d += t.d;
-    t.i[0] = __builtin_amdgcn_update_dpp(0, u.i[0], 0x4E, 0xF, 0xF, true), t.i[1] = __builtin_amdgcn_update_dpp(0, u.i[1], 0x4E, 0xF, 0xF, true);
-    u.d += t.d;
-    t.i[0] = __builtin_amdgcn_update_dpp(0, u.i[0], 0x141, 0xF, 0xF, true), t.i[1] = __builtin_amdgcn_update_dpp(0, u.i[1], 0x141, 0xF, 0xF, true);
-    u.d += t.d;
-    return u.d;
-#endif
 }
 __device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
-    return v;
+    v = fmax(v, dpp_f64(v, 0));
+    v = fmax(v, dpp_f64(v, 1));
+    v = fmax(v, dpp_f64(v, 2));
+    v = fmax(v, dpp_f64(v, 3));
+    return fmax(fmax(readlane_f64(v, 0), readlane_f64(v, 16)), fmax(readlane_f64(v, 32), readlane_f64(v, 48)));
 }
 // sums NV values over the block; result valid in every thread.  scratch: NV * 16 doubles of LDS.
 template <int NV, bool MAX_LAST = false>
@@ -643,7 +658,7 @@ __device__ void role_prior(const View &v, double *lds, const Pro *pro, int b, in
             for (int k = part; k < D; k += 16) ss += Sr[k] * e[k], tt += Lr[k] * e[k];
         }
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o), tt += __shfl_xor(tt, o);
+        for (int pat = 3; pat >= 0; --pat) ss += dpp_f64(ss, pat), tt += dpp_f64(tt, pat); // 16 lanes = one DPP row
         if (r < 15 && part == 0) rs[r] = ss + v.prior_s[row], rt[r] = tt + v.prior_eta[row];
     }
     __syncthreads();
