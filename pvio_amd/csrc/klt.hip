@@ -165,10 +165,36 @@ __global__ void k_pyr_down(LevelDesc src, LevelDesc dst) {
 }
 
 // ---- pyramidal LK: one wavefront per track --------------------------------------------------------------------------
+// sum over the wave, result in every lane.  DPP moves inside the rows of 16 lanes, then the four row sums by lane reads
+// in a fixed order: a `__shfl_xor` butterfly is six ds_bpermute round trips (~250 cycles), this is ~90.
+__device__ __forceinline__ float dpp_f32(float x, int pattern /* 0: ^1, 1: ^2, 2: mirror in 8, 3: mirror in 16 */) {
+#ifdef PV_HIPEMU
+    const int lane = threadIdx.x & 63;
+    const int src = pattern == 0 ? (lane ^ 1) : pattern == 1 ? (lane ^ 2) : pattern == 2 ? ((lane & ~7) | (7 - (lane & 7))) : ((lane & ~15) | (15 - (lane & 15)));
+    return __shfl(x, src);
+#else
+    const int i = __float_as_int(x);
+    switch (pattern) {
+    case 0: return __int_as_float(__builtin_amdgcn_update_dpp(0, i, 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
+    case 1: return __int_as_float(__builtin_amdgcn_update_dpp(0, i, 0x4E, 0xF, 0xF, true));  // quad_perm [2,3,0,1]
+    case 2: return __int_as_float(__builtin_amdgcn_update_dpp(0, i, 0x141, 0xF, 0xF, true)); // row_half_mirror
+    default: return __int_as_float(__builtin_amdgcn_update_dpp(0, i, 0x140, 0xF, 0xF, true)); // row_mirror
+    }
+#endif
+}
+__device__ __forceinline__ float readlane_f32(float x, int src) {
+#ifdef PV_HIPEMU
+    return __shfl(x, src);
+#else
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), src));
+#endif
+}
 __device__ __forceinline__ float wave_sum_f(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    v += dpp_f32(v, 0);
+    v += dpp_f32(v, 1);
+    v += dpp_f32(v, 2);
+    v += dpp_f32(v, 3);
+    return ((readlane_f32(v, 0) + readlane_f32(v, 16)) + readlane_f32(v, 32)) + readlane_f32(v, 48);
 }
 
 __global__ void __launch_bounds__(256) k_lk_track(TrackArgs a) {
