@@ -197,16 +197,20 @@ __device__ __forceinline__ float wave_sum_f(float v) {
     return ((readlane_f32(v, 0) + readlane_f32(v, 16)) + readlane_f32(v, 32)) + readlane_f32(v, 48);
 }
 
+// Lane l < 63 owns 7 consecutive pixels of one row of the 21 x 21 window (row l / 3, columns 7 (l % 3) ..): the bilinear
+// taps of neighbouring pixels overlap, so a lane fetches 2 x 8 bytes per iteration instead of 7 x 4, and its share of the
+// template (intensity + both derivatives, 14-bit fixed point like OpenCV) stays in registers -- no LDS in the loop.
 __global__ void __launch_bounds__(256) k_lk_track(TrackArgs a) {
 #if defined(__clang__)
 #pragma clang fp contract(off)
 #endif
-    __shared__ int16_t s_I[4][kWinPix];
-    __shared__ int16_t s_dI[4][kWinPix * 2];
+    constexpr int kRun = 7; // pixels per lane; kWin = 3 * kRun
+    static_assert(kWin == 3 * kRun, "window / lane mapping");
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int p = blockIdx.x * 4 + wv;
     if (p >= a.n) return; // whole wave exits together
-    int16_t *Iw = s_I[wv], *dIw = s_dI[wv];
+    const bool live = lane < kWin * 3;
+    const int wy = live ? lane / 3 : 0, wx = live ? kRun * (lane - 3 * wy) : 0;
     const float half = (kWin - 1) * 0.5f, FLT_SCALE = 1.f / (1 << 20);
     const int W_BITS = 14;
     const float pxf = a.prev_xy[2 * p], pyf = a.prev_xy[2 * p + 1];
@@ -230,17 +234,25 @@ __global__ void __launch_bounds__(256) k_lk_track(TrackArgs a) {
         int iw01 = (int)rintf(fa * (1.f - fb) * (float)(1 << W_BITS));
         int iw10 = (int)rintf((1.f - fa) * fb * (float)(1 << W_BITS));
         int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+        int tI[kRun], tX[kRun], tY[kRun]; // this lane's part of the template
         float sA11 = 0, sA12 = 0, sA22 = 0;
-        for (int i = lane; i < kWinPix; i += 64) {
-            const int y = i / kWin, x = i - y * kWin;
-            const size_t o = (size_t)(ipy + y + kPad) * I.pitch + (ipx + x + kPad);
-            const uint8_t *s = I.img + o;
-            const int16_t *d = I.drv + 2 * o;
-            const int ival = (s[0] * iw00 + s[1] * iw01 + s[I.pitch] * iw10 + s[I.pitch + 1] * iw11 + (1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
-            const int ixval = (d[0] * iw00 + d[2] * iw01 + d[2 * I.pitch] * iw10 + d[2 * I.pitch + 2] * iw11 + (1 << (W_BITS - 1))) >> W_BITS;
-            const int iyval = (d[1] * iw00 + d[3] * iw01 + d[2 * I.pitch + 1] * iw10 + d[2 * I.pitch + 3] * iw11 + (1 << (W_BITS - 1))) >> W_BITS;
-            Iw[i] = (int16_t)ival, dIw[2 * i] = (int16_t)ixval, dIw[2 * i + 1] = (int16_t)iyval;
-            sA11 += (float)(ixval * ixval), sA12 += (float)(ixval * iyval), sA22 += (float)(iyval * iyval);
+        {
+            const size_t o = (size_t)(ipy + wy + kPad) * I.pitch + (ipx + wx + kPad);
+            const uint8_t *s0 = I.img + o, *s1 = s0 + I.pitch;
+            const int16_t *d0 = I.drv + 2 * o, *d1 = d0 + 2 * I.pitch;
+            int r0[kRun + 1], r1[kRun + 1], x0[kRun + 1], x1[kRun + 1], y0[kRun + 1], y1[kRun + 1];
+#pragma unroll
+            for (int k = 0; k <= kRun; ++k) {
+                r0[k] = s0[k], r1[k] = s1[k];
+                x0[k] = d0[2 * k], y0[k] = d0[2 * k + 1], x1[k] = d1[2 * k], y1[k] = d1[2 * k + 1];
+            }
+#pragma unroll
+            for (int k = 0; k < kRun; ++k) {
+                tI[k] = (r0[k] * iw00 + r0[k + 1] * iw01 + r1[k] * iw10 + r1[k + 1] * iw11 + (1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
+                tX[k] = (x0[k] * iw00 + x0[k + 1] * iw01 + x1[k] * iw10 + x1[k + 1] * iw11 + (1 << (W_BITS - 1))) >> W_BITS;
+                tY[k] = (y0[k] * iw00 + y0[k + 1] * iw01 + y1[k] * iw10 + y1[k + 1] * iw11 + (1 << (W_BITS - 1))) >> W_BITS;
+                if (live) sA11 += (float)(tX[k] * tX[k]), sA12 += (float)(tX[k] * tY[k]), sA22 += (float)(tY[k] * tY[k]);
+            }
         }
         const float A11 = wave_sum_f(sA11) * FLT_SCALE, A12 = wave_sum_f(sA12) * FLT_SCALE, A22 = wave_sum_f(sA22) * FLT_SCALE;
         float D = A11 * A22 - A12 * A12;
@@ -263,13 +275,17 @@ __global__ void __launch_bounds__(256) k_lk_track(TrackArgs a) {
             iw01 = (int)rintf(fa * (1.f - fb) * (float)(1 << W_BITS));
             iw10 = (int)rintf((1.f - fa) * fb * (float)(1 << W_BITS));
             iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+            const uint8_t *s0 = J.img + (size_t)(iny + wy + kPad) * J.pitch + (inx + wx + kPad), *s1 = s0 + J.pitch;
+            int r0[kRun + 1], r1[kRun + 1];
+#pragma unroll
+            for (int k = 0; k <= kRun; ++k) r0[k] = s0[k], r1[k] = s1[k];
             float sb1 = 0, sb2 = 0;
-            for (int i = lane; i < kWinPix; i += 64) {
-                const int y = i / kWin, x = i - y * kWin;
-                const uint8_t *s = J.img + (size_t)(iny + y + kPad) * J.pitch + (inx + x + kPad);
-                const int diff = ((s[0] * iw00 + s[1] * iw01 + s[J.pitch] * iw10 + s[J.pitch + 1] * iw11 + (1 << (W_BITS - 5 - 1))) >> (W_BITS - 5)) - Iw[i];
-                sb1 += (float)(diff * dIw[2 * i]), sb2 += (float)(diff * dIw[2 * i + 1]);
+#pragma unroll
+            for (int k = 0; k < kRun; ++k) {
+                const int diff = ((r0[k] * iw00 + r0[k + 1] * iw01 + r1[k] * iw10 + r1[k + 1] * iw11 + (1 << (W_BITS - 5 - 1))) >> (W_BITS - 5)) - tI[k];
+                sb1 += (float)(diff * tX[k]), sb2 += (float)(diff * tY[k]);
             }
+            if (!live) sb1 = 0.f, sb2 = 0.f;
             const float b1 = wave_sum_f(sb1) * FLT_SCALE, b2 = wave_sum_f(sb2) * FLT_SCALE;
             const float dx = (A12 * b2 - A22 * b1) * D, dy = (A12 * b1 - A11 * b2) * D;
             nx += dx, ny += dy;
