@@ -2006,12 +2006,60 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(View v) {
 // ------------------------------------------------------------------------------------------------------
 // k_backsub: landmark back-substitution + landmark parts of the dogleg scalars; <= 64 WGs, one row each
 // ------------------------------------------------------------------------------------------------------
+// Sixteen lanes (one DPP row) per landmark: lane `sub` takes observations sub, sub + 16, ... so that the dependent
+// obs_frame -> step loads of all observations travel together (a thread walking its landmark's ~10 observations in turn
+// pays ten L2 round trips back to back); the two dot products are summed over the row and lane 0 finishes the landmark.
+// The control word and the first operands are requested together: nothing is written before the word has arrived.
 __global__ void __launch_bounds__(256) k_backsub(View v) {
     const Ctrl *c = v.ctrl;
-    if (c->done || !c->solve_ok) return;
+    const int done = c->done, solve_ok = c->solve_ok, lin = c->lin;
+    const double mu = c->mu;
     __shared__ double scratch[6 * 16];
+    const int M = v.dm.M, d = v.dm.d;
+    const size_t Ms = (size_t)M, Fs = (size_t)v.dm.F;
+    const int sub = threadIdx.x & 15, per_block = blockDim.x >> 4;
     double s[6] = {0, 0, 0, 0, 0, 0};
-    backsub_landmarks(v, c->lin, c->mu, v.vstep, v.ystep, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x, s);
+    for (int l0 = blockIdx.x * per_block; l0 < M; l0 += gridDim.x * per_block) { // uniform trip count per block
+        const int l = l0 + (threadIdx.x >> 4);
+        const bool in = l < M;
+        const int lc = in ? l : M - 1;
+        const int o0 = v.lm_ptr[lc], o1 = v.lm_ptr[lc + 1], a = v.lm_anchor[lc];
+        if (done || !solve_ok) return; // uniform (the loads above were only issued)
+        const double *Wa = v.Wa + lin * Ms * 6, *Wt = v.Wt + lin * Fs * 6;
+        double Wv = 0, Wy = 0; // W_l . (C_p v_p), W_l . (C_p y'_p)
+        if (sub < 6) Wv = Wa[(size_t)lc * 6 + sub] * v.vstep[d * a + sub], Wy = Wa[(size_t)lc * 6 + sub] * v.ystep[d * a + sub];
+        for (int o = o0 + sub; o < o1; o += 16) {
+            const int t = v.obs_frame[o];
+            const double *w = Wt + (size_t)o * 6, *vs = v.vstep + d * t, *ys = v.ystep + d * t;
+            double av = 0, ay = 0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) av += w[k] * vs[k], ay += w[k] * ys[k];
+            Wv += av, Wy += ay;
+        }
+#pragma unroll
+        for (int pat = 0; pat < 4; ++pat) Wv += dpp_f64(Wv, pat), Wy += dpp_f64(Wy, pat);
+        if (sub == 0 && in) {
+            double *gnl = v.gnl + lin * Ms;
+            if (o1 == o0) {
+                gnl[l] = 0.0;
+            } else {
+                const double Hll = v.Hll[lin * Ms + l], bl = v.bl[lin * Ms + l], D = v.Dl[lin * Ms + l], gh = v.ghl[lin * Ms + l], cl = v.cl[l];
+                const double Hs = cl * cl * Hll, A = Hs + mu * D * D;
+                const double w = cl * cl / A;
+                const double yl = -cl * (bl + Wy) / A; // y'_l
+                const double vl = gh / D;
+                const double gn = D * yl;
+                gnl[l] = gn;
+                s[0] += gn * gn;
+                s[1] += gh * gn;
+                s[2] += w * Wv * Wv + 2 * cl * vl * Wv + Hs * vl * vl;            // v^T H v (landmark + add-back)
+                s[3] += w * Wv * Wy + cl * vl * Wy + cl * yl * Wv + Hs * vl * yl; // v^T H y'
+                s[4] += w * Wy * Wy + 2 * cl * yl * Wy + Hs * yl * yl;            // y'^T H y'
+                s[5] += cl * bl * yl;                                             // g_s^T y'
+            }
+        }
+    }
+    if (done || !solve_ok) return;
     block_sum<6>(s, scratch);
     if (threadIdx.x == 0) {
         double *row = v.back_part + (size_t)blockIdx.x * kNumBackScal;

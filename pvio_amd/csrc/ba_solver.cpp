@@ -191,7 +191,7 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st) {
     }
     dm.n_chunks = (int)chunk_lm.size() - 1;
     dm.G_lm = std::max(1, std::min(dm.n_chunks, lm_cus));
-    dm.G_back = std::max(1, std::min(64, (M + 255) / 256));
+    dm.G_back = std::max(1, std::min(64, (M + 15) / 16)); // 16 landmarks per workgroup (16 lanes each); <= 64 partial rows
     dm.fuse_backsub = (world_ == 1 && M <= 256) ? 1 : 0; // beyond one landmark per thread the separate launch is faster
     dm.n_back_rows = (world_ > 1 || dm.fuse_backsub) ? 1 : dm.G_back;
 
