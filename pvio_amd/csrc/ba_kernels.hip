@@ -737,7 +737,8 @@ __global__ void __launch_bounds__(kLinThreads) k_linearize(View v) {
 // ------------------------------------------------------------------------------------------------------
 // k_reduce: fixed-order sums of the WG partials -> red = [S tiles (element-major) | 3 pose vectors | 8 scalars]
 // ------------------------------------------------------------------------------------------------------
-constexpr int kRedElems = 64, kRedGroups = 16; // one block = 64 output elements x 16 partial groups
+constexpr int kRedElems = 16, kRedGroups = 64; // one block = 16 output elements (one 128-byte line per partial row) x 64 partial groups:
+                                                // the partials are pulled by ~8x more CUs than there are kilobytes per element
 // IMU factor blocks (odd factor first) and marginalization prior added to entry ((fa, ka), (fb, kb)), fb <= fa, of the
 // unscaled reduced system whose landmark / plane part is `val`
 __device__ __forceinline__ double reduced_entry_terms(const View &v, double val, int fa, int ka, int fb, int kb) {
@@ -788,6 +789,7 @@ __global__ void __launch_bounds__(kRedElems *kRedGroups) k_reduce(View v, int nb
         return;
     }
     __shared__ double part[kRedGroups][kRedElems];
+    __shared__ double quarter[4][kRedElems];
     const int G = v.dm.G_lm + v.dm.G_plane;
     const int el = threadIdx.x & (kRedElems - 1), gg = threadIdx.x / kRedElems;
     const size_t e = (size_t)blockIdx.x * kRedElems + el;
@@ -796,16 +798,16 @@ __global__ void __launch_bounds__(kRedElems *kRedGroups) k_reduce(View v, int nb
     if (e < nS + nV) {
         const double *src = e < nS ? v.part_S + e : v.part_vec + (e - nS);
         const size_t stride = e < nS ? nS : nV;
-        // <= 16 values per thread per round, all loads issued before the first add (one memory latency per round)
-        for (int g0 = gg; g0 < G; g0 += 16 * kRedGroups) {
-            double vals[16];
+        // <= 4 values per thread per round (one round up to 256 partial rows), all loads issued before the first add
+        for (int g0 = gg; g0 < G; g0 += 4 * kRedGroups) {
+            double vals[4];
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
+            for (int q = 0; q < 4; ++q) {
                 const int g = g0 + q * kRedGroups;
                 vals[q] = g < G ? src[(size_t)g * stride] : 0.0;
             }
 #pragma unroll
-            for (int q = 0; q < 16; ++q) s += vals[q];
+            for (int q = 0; q < 4; ++q) s += vals[q];
         }
     } else if (e < total) {
         const int q = (int)(e - nS - nV);
@@ -814,11 +816,17 @@ __global__ void __launch_bounds__(kRedElems *kRedGroups) k_reduce(View v, int nb
     if (ctl_done || ctl_result == LIN_INVALID_STEP) return; // uniform
     part[gg][el] = s;
     __syncthreads();
-    // stage 2: fixed-order combination of the 16 group sums
+    // stage 2: fixed-order combination of the group sums, four quarters first
+    const bool is_max = e >= nS + nV && e < total && (int)(e - nS - nV) == 4;
+    if (gg < 4) {
+        double r = part[gg * (kRedGroups / 4)][el];
+        for (int q = 1; q < kRedGroups / 4; ++q) r = is_max ? fmax(r, part[gg * (kRedGroups / 4) + q][el]) : r + part[gg * (kRedGroups / 4) + q][el];
+        quarter[gg][el] = r;
+    }
+    __syncthreads();
     if (gg == 0 && e < total) {
-        const bool is_max = e >= nS + nV && (int)(e - nS - nV) == 4;
-        double r = part[0][el];
-        for (int q = 1; q < kRedGroups; ++q) r = is_max ? fmax(r, part[q][el]) : r + part[q][el];
+        double r = quarter[0][el];
+        for (int q = 1; q < 4; ++q) r = is_max ? fmax(r, quarter[q][el]) : r + quarter[q][el];
         v.red[e] = r;
         if (v.dm.use_img && e < nS) {
             const int n_tasks = v.dm.n_tasks, ee = (int)e, q = ee / n_tasks, t = ee - q * n_tasks, d = v.dm.d;
