@@ -593,13 +593,18 @@ __device__ void role_planes(const View &v, double *lds, const Pro *pro, int wg, 
 __device__ void role_preint(const View &v, double *lds, const Pro *pro, int j) {
     const int N = v.dm.N, tid = threadIdx.x;
     const double *est = lds;
-    double *work = lds + common_lds_doubles(N); // raw[16] G[450] J[450] r[16]
-    double *raw = work, *G = work + 16, *J = work + 466, *r = work + 916;
+    double *work = lds + common_lds_doubles(N); // raw[16] G[450] J[450] r[16] U[225]
+    double *raw = work, *G = work + 16, *J = work + 466, *r = work + 916, *Ul = work + 932;
     const int i = j - 1;
+    // all threads: clear G and bring the 15 x 15 square-root information into LDS while thread 0 does the factor's
+    // scalar geometry (a single thread clearing 450 LDS words alone costs ~3 us)
+    for (int e = tid; e < 450; e += kLinThreads) G[e] = 0.0;
+    if (tid < 225) Ul[tid] = v.pre_U[225 * (size_t)j + tid];
+    __syncthreads();
     if (tid == 0) {
         // live bias read: the accepted linearization keeps the biases it was evaluated with (RELIN must reuse them)
         const double *b0 = (pro->mode == MODE_RELIN) ? v.bias0_lin + 6 * i : v.fs_user + 16 * i + 10;
-        preint_raw(est + 16 * i, est + 16 * j, b0, v.pre_delta + 11 * j, v.pre_jac + 45 * j, v.imu_ext + 7 * i, v.imu_ext + 7 * j, raw, G);
+        preint_raw(est + 16 * i, est + 16 * j, b0, v.pre_delta + 11 * j, v.pre_jac + 45 * j, v.imu_ext + 7 * i, v.imu_ext + 7 * j, raw, G, /*G_is_zero=*/true);
         const bool fi = pro->mode != MODE_MARG && v.frame_fixed[i] != 0, fj = pro->mode != MODE_MARG && v.frame_fixed[j] != 0;
         for (int row = 0; row < 15; ++row)
             for (int c = 0; c < 6; ++c) {
@@ -608,7 +613,7 @@ __device__ void role_preint(const View &v, double *lds, const Pro *pro, int j) {
             }
     }
     __syncthreads();
-    const double *U = v.pre_U + 225 * (size_t)j;
+    const double *U = Ul;
     for (int e = tid; e < 450; e += kLinThreads) {
         const int row = e / 30, c = e - 30 * row;
         double s = 0;
@@ -2174,7 +2179,7 @@ size_t linearize_lds_bytes(const Dims &dm) {
     size_t common = (size_t)(N * 16 + N * kFrameRec + 160 + 16);
     size_t lm = (size_t)dm.lm_slots * (40 * N + 46) + dm.lm_slots + 2 * ((dm.lm_slots + 1) / 2) + 4;
     size_t pl = (size_t)dm.plane_slots * (dm.P6 + 2);
-    size_t pre = 16 + 450 + 450 + 16;
+    size_t pre = 16 + 450 + 450 + 16 + 225;
     size_t pri = (size_t)dm.prior_n * (15 + 9) + 40;
     size_t role = lm;
     if (pl > role) role = pl;
