@@ -1518,10 +1518,14 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(View v) {
                 }
             const int irow = j0 + tid; // row owner (LDV <= 176 < 256 threads)
             double x[kPanel];
-            if (irow < LDV) {
+            {
+                // every thread loads and carries a row (threads past the last row re-read the last one and discard the
+                // result): the forward substitution below then shares a basic block with the pivot chain and fills its
+                // dependency stalls instead of running after it
+                const int ir = irow < LDV ? irow : LDV - 1;
 #pragma unroll
                 for (int h = 0; h < 4; ++h) {
-                    const lds_d2 g2 = *reinterpret_cast<const lds_d2 *>(Xs + irow * 8 + 2 * h);
+                    const lds_d2 g2 = *reinterpret_cast<const lds_d2 *>(Xs + ir * 8 + 2 * h);
                     x[2 * h] = -g2[0], x[2 * h + 1] = -g2[1];
                 }
             }
@@ -1541,6 +1545,9 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(View v) {
                 for (int r = cc + 1; r < kPanel; ++r)
 #pragma unroll
                     for (int c2 = cc + 1; c2 <= r; ++c2) Ld[r][c2] -= Ld[r][cc] * Ls[c2][cc];
+                // forward substitution of this thread's row, step cc (unscaled entries: one dependent FMA per step)
+#pragma unroll
+                for (int c2 = cc + 1; c2 < kPanel; ++c2) x[c2] -= x[cc] * Ls[c2][cc];
             }
             if (j0 == 0) PV_STAMP(2, 9);
             if (j0 == 80) PV_STAMP(2, 14);
@@ -1553,14 +1560,8 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(View v) {
                 tmp[j0 + tid] = iv; // 1 / L_jj for the back substitution
             }
             if (irow < LDV) {
-                // forward substitution of the owner's row; the chain carries the UNscaled entries (one dependent FMA per
-                // step, Ld's columns were pre-multiplied by 1 / L_cc above), scaling and the mask of the panel's own rows
-                // (their strictly upper entries are not L) come after it
-#pragma unroll
-                for (int cc = 0; cc < kPanel; ++cc) {
-#pragma unroll
-                    for (int c2 = cc + 1; c2 < kPanel; ++c2) x[c2] -= x[cc] * Ls[c2][cc];
-                }
+                // the owner's row went through the forward substitution inside the pivot loop; scaling and the mask of the
+                // panel's own rows (their strictly upper entries are not L) come last
                 if (j0 == 80) PV_STAMPV(2, 19, x[7]);
 #pragma unroll
                 for (int cc = 0; cc < kPanel; ++cc) x[cc] = (j0 + cc <= irow) ? x[cc] * inv[cc] : 0.0;
