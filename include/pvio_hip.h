@@ -60,7 +60,12 @@ typedef struct pvio_hip_opts {
     int32_t rank;            /* landmark-shard index of this process (0 when single GPU) */
     int32_t world_size;      /* number of landmark shards / processes (1 when single GPU) */
     int32_t use_graph;       /* 1: replay the per-iteration kernel sequence from a hipGraph */
-    int32_t reserved[4];
+    /* fault injection for tests of the rarely taken solver paths (0 in production): the first N Cholesky factorizations
+     * of a solve are treated as failed (-> mu escalation, re-linearization), the first N trust-region steps as invalid
+     * (-> HandleInvalidStep; five in a row = FAILURE) */
+    int32_t debug_fail_factorizations;
+    int32_t debug_invalid_steps;
+    int32_t reserved[2];
 } pvio_hip_opts;
 
 /* ------------------------------------------------------------------------------------------------

@@ -336,6 +336,10 @@ double ambient_sqnorm_diff(const Layout &L, const double *fa, const double *ra, 
     return s;
 }
 
+// fault injection mirroring pvio_hip_opts::debug_* (tests of the rarely taken paths)
+static int g_dbg_fail_factorizations = 0, g_dbg_invalid_steps = 0;
+static int g_dbg_fail_left = 0, g_dbg_invalid_left = 0;
+
 struct Solver {
     const pvio_ba_problem &pb;
     Layout L;
@@ -442,7 +446,9 @@ struct Solver {
             bool solved = false;
             gnp.assign(P, 0.0), gnl.assign(M, 0.0);
             while (mu < 1.0) {
-                if (solve_gauss_newton()) {
+                const bool injected = g_dbg_fail_left > 0;
+                if (injected) --g_dbg_fail_left;
+                if (solve_gauss_newton() && !injected) {
                     solved = true;
                     break;
                 }
@@ -601,7 +607,10 @@ void quality_pass(const pvio_ba_problem &pb, const double *fs, const double *rho
 extern "C" {
 
 // ceres::Solve(...) as configured at bundle_adjustor.cpp:244-249 + post passes :277-296
+void oracle_debug_fault_injection(int32_t fail_factorizations, int32_t invalid_steps) { g_dbg_fail_factorizations = fail_factorizations, g_dbg_invalid_steps = invalid_steps; }
+
 int32_t oracle_ba_solve(const pvio_ba_problem *pbp, pvio_ba_state *state, pvio_ba_summary *sum) {
+    g_dbg_fail_left = g_dbg_fail_factorizations, g_dbg_invalid_left = g_dbg_invalid_steps;
     auto t0 = std::chrono::steady_clock::now();
     const pvio_ba_problem &pb = *pbp;
     Solver S(pb);
@@ -667,6 +676,7 @@ int32_t oracle_ba_solve(const pvio_ba_problem *pbp, pvio_ba_state *state, pvio_b
             double q = S.quad(S.stp.data(), S.stl.data(), S.stp.data(), S.stl.data());
             S.model_cost_change = -(gs + 0.5 * q); // == -(J step)^T (r + J step / 2)
             it_valid = S.model_cost_change > 0.0;
+            if (g_dbg_invalid_left > 0) --g_dbg_invalid_left, it_valid = false;
         }
         if (!it_valid) { // HandleInvalidStep
             if (++S.invalid_steps >= 5) {

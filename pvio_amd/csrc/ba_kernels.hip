@@ -210,7 +210,7 @@ __device__ void lin_prologue(const View &v, double *lds, Pro *&pro_out) {
                 const double q = ca * ca * qvv + 2 * ca * cb * qvy + cb * cb * qyy;
                 const double mcc = -(gs + 0.5 * q);
                 pro->ca = ca, pro->cb = cb;
-                pro->valid = (mcc > 0.0) ? 1 : 0;
+                pro->valid = (mcc > 0.0 && c->dbg_invalid_left <= 0) ? 1 : 0; // (fault injection: tests only)
                 if (blockIdx.x == 0) {
                     Ctrl *cw = v.ctrl;
                     cw->ca = ca, cw->cb = cb, cw->dogleg_step_norm = sn, cw->model_cost_change = mcc;
@@ -860,6 +860,7 @@ __device__ int record_trace(const View &v, Ctrl *c, int iteration) {
 
 struct DenseShared {
     int do_solve, do_trace, trace_slot, accepted, first;
+    int replay_first, replay_count; // trace slots written by the linear-solver-failure replay
     double x_cost_new;
 };
 
@@ -1139,12 +1140,15 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(View v) {
             }
         }
     }
+    // every thread takes the termination flag from its own load: thread 0 may set the LDS copy's `done` in the control
+    // section below while slower waves are still on their way to this test
+    const int was_done = cg->done;
     __syncthreads(); // the staged control inputs are in LDS (global loads stay in flight across the barrier)
-    if (c->done) return; // nothing was modified
+    if (was_done) return; // nothing was modified
     // ---------------- control (thread 0): Finalize the iteration in flight, decide what comes next ----------------
     if (tid == 0) {
         const int lr = c->lin_result;
-        sh.do_solve = 0, sh.do_trace = 0, sh.accepted = 0, sh.first = 0;
+        sh.do_solve = 0, sh.do_trace = 0, sh.accepted = 0, sh.first = 0, sh.replay_first = -1, sh.replay_count = 0;
         double aux_cost = 0;
         if (lr != LIN_INVALID_STEP) {
             for (int j = 1; j < N; ++j) aux_cost += aux_costs[j]; // 0 where there is no factor (x + 0 is exact)
@@ -1201,6 +1205,7 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(View v) {
                 }
             }
         } else if (lr == LIN_INVALID_STEP) { // HandleInvalidStep
+            if (c->dbg_invalid_left > 0) c->dbg_invalid_left--;
             c->it_valid = 0, c->it_success = 0, c->it_cost = c->x_cost, c->it_cost_change = 0, c->it_step_norm = 0, c->it_rel = 0;
             if (++c->invalid_steps >= 5) {
                 c->termination = 2, c->done = 1;
@@ -1951,7 +1956,9 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(View v) {
         nbad = sb[0];
     }
     if (tid == 0) {
-        const int ok = !sh_fail && nbad == 0.0;
+        const int injected = c->dbg_fail_left > 0; // fault injection (tests only)
+        if (injected) c->dbg_fail_left--;
+        const int ok = !sh_fail && nbad == 0.0 && !injected;
         if (ok) {
             c->solve_ok = 1, c->mode = MODE_CANDIDATE, c->scaling_ready = 1, c->retry_relin = 0;
         } else {
@@ -1962,15 +1969,47 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(View v) {
             if (c->mu < 1.0) {
                 c->mode = MODE_RELIN, c->retry_relin = 1;
             } else {
-                // mu >= max_mu: Ceres would now burn 5 consecutive invalid iterations without moving x and return
-                // FAILURE; the iterate is identical, so terminate right away.
-                c->termination = 2, c->done = 1, c->mode = MODE_DONE;
+                // mu >= max_mu: ComputeTrustRegionStep fails -> invalid step, and so will every following iteration
+                // (x does not move, mu only grows).  Ceres walks them one by one until the fifth consecutive invalid step
+                // (FAILURE) or the iteration limit; replay that bookkeeping here instead of burning launches on it.
+                sh.replay_first = -1, sh.replay_count = 0;
+                while (true) {
+                    if (++c->invalid_steps >= 5) { // HandleInvalidStep
+                        c->termination = 2;
+                        break;
+                    }
+                    c->mu *= 10.0; // DoglegStrategy::StepIsInvalid
+                    c->it_valid = 0, c->it_success = 0, c->it_cost = c->x_cost, c->it_cost_change = 0, c->it_step_norm = 0, c->it_rel = 0;
+                    const int slot = record_trace(v, c, c->iter); // Finalize
+                    if (slot >= 0) {
+                        if (sh.replay_first < 0) sh.replay_first = slot;
+                        sh.replay_count++;
+                    }
+                    if (c->iter >= v.dm.max_iter) {
+                        c->termination = 1;
+                        break;
+                    }
+                    if (c->radius <= 1e-32) {
+                        c->termination = 0;
+                        break;
+                    }
+                    c->iter++;
+                }
+                c->done = 1, c->mode = MODE_DONE;
             }
         }
         sh.do_solve = ok;
     }
     __syncthreads();
     if (!sh.do_solve) {
+        if (c->done && v.trace_states && sh.replay_count > 0) { // the replayed iterations all sit at the accepted iterate
+            const int cur = c->cur;
+            for (int q = 0; q < sh.replay_count; ++q) {
+                double *dst = v.trace_states + (size_t)(sh.replay_first + q) * (N * 16 + v.dm.M);
+                for (int e = tid; e < N * 16; e += nthr) dst[e] = v.fs[(size_t)cur * N * 16 + e];
+                for (int e = tid; e < v.dm.M; e += nthr) dst[N * 16 + e] = v.rho[(size_t)cur * v.dm.M + e];
+            }
+        }
         if (tid == 0) *cg = *c;
         return;
     }

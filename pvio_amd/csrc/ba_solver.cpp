@@ -399,6 +399,7 @@ int BASolver::solve(pvio_ba_summary *sum, pvio_ba_kernel_times *prof) {
     h_ctrl_->mu = 1e-8;           // DoglegStrategy kMinMu
     h_ctrl_->termination = PVIO_TERM_NO_CONVERGENCE;
     h_ctrl_->trace_cap = trace_cap_;
+    h_ctrl_->dbg_fail_left = dbg_fail_, h_ctrl_->dbg_invalid_left = dbg_invalid_;
     if (check(hipMemcpyAsync(v_.ctrl, h_ctrl_, sizeof(Ctrl), hipMemcpyHostToDevice, stream_), "reset ctrl")) return PVIO_ERR_HIP;
     if (check(hipEventRecord(ev0_, stream_), "event")) return PVIO_ERR_HIP;
     // every slot = one pass of [linearize, reduce, dense, backsub]; iteration 0 + max_iter iterations (+ slack for

@@ -65,6 +65,7 @@ struct Ctrl {
     // bookkeeping for the record of the iteration in flight
     double it_cost, it_cost_change, it_step_norm, it_rel;
     int32_t it_valid, it_success;
+    int32_t dbg_fail_left, dbg_invalid_left; // fault injection (pvio_hip_opts::debug_*), counted down by k_dense
 };
 
 struct Dims {

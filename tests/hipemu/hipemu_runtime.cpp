@@ -7,6 +7,7 @@
 namespace hipemu {
 
 ThreadCtx *g_cur = nullptr;
+const char *g_kernel_name = "?";
 alignas(64) static char dyn_smem_pool[160 * 1024];
 char *g_dyn_smem = dyn_smem_pool;
 
@@ -133,8 +134,12 @@ void launch(dim3 grid, dim3 block, size_t shmem, Stream *s, std::function<void()
                             }
                         }
                         if (!progressed && ++spins > 20000) {
-                            std::fprintf(stderr, "hipemu: launch #%ld (%d threads) block (%u,%u,%u) deadlocked: bar_arrived=%d n_done=%d (divergent barrier / shuffle?)\n", launch_counter, nt, bx, by, bz, bar_arrived, n_done);
+                            std::fprintf(stderr, "hipemu: kernel %s (%d threads) block (%u,%u,%u) deadlocked: bar_arrived=%d n_done=%d (divergent barrier / shuffle?)\n", g_kernel_name, nt, bx, by, bz, bar_arrived, n_done);
                             for (size_t w = 0; w < waves.size(); ++w) std::fprintf(stderr, "  wave %zu: arrived=%d alive=%d readers=%d\n", w, waves[w].arrived, waves[w].alive, waves[w].readers);
+                            std::fprintf(stderr, "  threads still running:");
+                            for (int t = 0, shown = 0; t < nt && shown < 16; ++t)
+                                if (!fibers[t].done) std::fprintf(stderr, " %d", t), ++shown;
+                            std::fprintf(stderr, "\n");
                             std::abort();
                         }
                         if (progressed) spins = 0;

@@ -47,6 +47,7 @@ enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDevice
 enum hipStreamCaptureMode { hipStreamCaptureModeGlobal, hipStreamCaptureModeThreadLocal, hipStreamCaptureModeRelaxed };
 
 namespace hipemu {
+extern const char *g_kernel_name; // name of the kernel being emulated (deadlock diagnostics)
 struct Stream {
     bool capturing = false;
     std::vector<std::function<void()>> *graph = nullptr;
@@ -87,7 +88,7 @@ using std::min;
 #define HIP_DYNAMIC_SHARED(type, var) type *var = reinterpret_cast<type *>(hipemu::g_dyn_smem);
 #define HIP_KERNEL_NAME(...) __VA_ARGS__
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
-    hipemu::launch((grid), (block), (shmem), (stream), [=]() { kernel(__VA_ARGS__); })
+    hipemu::launch((grid), (block), (shmem), (stream), [=]() { hipemu::g_kernel_name = #kernel; kernel(__VA_ARGS__); })
 
 // ---- device intrinsics ---------------------------------------------------------------------------------
 inline void __syncthreads() { hipemu::syncthreads(); }

@@ -75,3 +75,39 @@ def test_emulated_marginalize_last_frame_no_prior(emu_ctx, oracle):
     S1, s1, IM1, iv1 = emu_ctx.marginalize(pb, st, 3)
     np.testing.assert_allclose(IM1, IM0, rtol=1e-7, atol=1e-9 * np.abs(IM0).max())
     np.testing.assert_allclose(S1.T @ S1, S0.T @ S0, rtol=1e-6, atol=1e-7 * np.abs(IM0).max())
+
+
+# ---- rarely taken solver paths, forced by fault injection on both sides (pvio_hip_opts::debug_*, oracle_debug_fault_injection) ----
+FAULTS = [
+    dict(fail=1, invalid=0),   # one failed factorization: mu x10, the accepted point is re-linearized, the iteration goes on
+    dict(fail=3, invalid=0),   # three in a row inside one iteration
+    dict(fail=0, invalid=1),   # HandleInvalidStep once
+    dict(fail=0, invalid=2),
+    dict(fail=0, invalid=5),   # five consecutive invalid steps = FAILURE, x unchanged
+    dict(fail=8, invalid=0),   # mu escalates to max_mu: linear solver failure until the five-strikes rule ends the solve
+]
+
+
+def _fault_case(make_ctx, oracle, fail, invalid, **kw):
+    import ctypes as C
+
+    from oracle import oracle_py
+    from pvio_amd import synth
+
+    pb = synth.make_window(**kw) if not kw.get("use_inertial") else synth.make_window(preintegrate=oracle_py.preintegrate, **kw)
+    L = oracle_py.lib()
+    L.oracle_debug_fault_injection(C.c_int32(fail), C.c_int32(invalid))
+    ctx = make_ctx(fail, invalid)
+    try:
+        return ba_compare.check_against_oracle(ctx, oracle, pb)
+    finally:
+        L.oracle_debug_fault_injection(C.c_int32(0), C.c_int32(0))
+        ctx.close()
+
+
+@pytest.mark.parametrize("fault", FAULTS, ids=lambda f: "fail%d_invalid%d" % (f["fail"], f["invalid"]))
+@pytest.mark.parametrize("inertial", [False, True])
+def test_emulated_fault_paths_match_oracle(oracle, fault, inertial):
+    lib = capi.load(os.path.join(EMU_DIR, "libpvio_hipemu.so"))
+    mk = lambda f, i: HipContext(lib=lib, debug_fail_factorizations=f, debug_invalid_steps=i)  # noqa: E731
+    _fault_case(mk, oracle, fault["fail"], fault["invalid"], n_frames=4, n_landmarks=30, use_inertial=inertial)

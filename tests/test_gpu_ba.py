@@ -84,3 +84,25 @@ def test_gpu_reprojection_error_matches_oracle(gpu_ctx, oracle):
 def test_gpu_marginalize_matches_oracle(gpu_ctx, oracle, victim):
     import marg_compare
     print(marg_compare.check_marginalize(gpu_ctx, oracle, victim, n_frames=10, n_landmarks=300, use_inertial=True, visibility=6))
+
+
+# rarely taken solver paths (failed factorization -> mu escalation + re-linearization, invalid steps, solver failure), forced
+# by fault injection on both sides; includes the metric-size window so that the register-resident dense path is the one hit
+@pytest.mark.parametrize("fail,invalid", [(1, 0), (3, 0), (0, 1), (0, 2), (0, 5), (8, 0)])
+@pytest.mark.parametrize("case", ["vio_small", "metric_10x1000_vio"])
+def test_gpu_fault_paths_match_oracle(oracle, fail, invalid, case):
+    import ctypes as C
+
+    from oracle import oracle_py
+    from pvio_amd.solver import HipContext
+
+    kw = ba_compare.CASES.get(case) or ba_compare.BIG_CASES[case]
+    pb = ba_compare.make(oracle, **kw)
+    L = oracle_py.lib()
+    L.oracle_debug_fault_injection(C.c_int32(fail), C.c_int32(invalid))
+    ctx = HipContext(device=0, debug_fail_factorizations=fail, debug_invalid_steps=invalid)
+    try:
+        print(case, fail, invalid, ba_compare.check_against_oracle(ctx, oracle, pb))
+    finally:
+        L.oracle_debug_fault_injection(C.c_int32(0), C.c_int32(0))
+        ctx.close()
