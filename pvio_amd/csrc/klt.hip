@@ -248,9 +248,9 @@ __global__ void __launch_bounds__(256) k_lk_track(TrackArgs a) {
             }
 #pragma unroll
             for (int k = 0; k < kRun; ++k) {
-                tI[k] = (r0[k] * iw00 + r0[k + 1] * iw01 + r1[k] * iw10 + r1[k + 1] * iw11 + (1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
-                tX[k] = (x0[k] * iw00 + x0[k + 1] * iw01 + x1[k] * iw10 + x1[k + 1] * iw11 + (1 << (W_BITS - 1))) >> W_BITS;
-                tY[k] = (y0[k] * iw00 + y0[k + 1] * iw01 + y1[k] * iw10 + y1[k + 1] * iw11 + (1 << (W_BITS - 1))) >> W_BITS;
+                tI[k] = (__mul24(r0[k], iw00) + __mul24(r0[k + 1], iw01) + __mul24(r1[k], iw10) + __mul24(r1[k + 1], iw11) + (1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
+                tX[k] = (__mul24(x0[k], iw00) + __mul24(x0[k + 1], iw01) + __mul24(x1[k], iw10) + __mul24(x1[k + 1], iw11) + (1 << (W_BITS - 1))) >> W_BITS;
+                tY[k] = (__mul24(y0[k], iw00) + __mul24(y0[k + 1], iw01) + __mul24(y1[k], iw10) + __mul24(y1[k + 1], iw11) + (1 << (W_BITS - 1))) >> W_BITS;
                 if (live) sA11 += (float)(tX[k] * tX[k]), sA12 += (float)(tX[k] * tY[k]), sA22 += (float)(tY[k] * tY[k]);
             }
         }
@@ -264,6 +264,7 @@ __global__ void __launch_bounds__(256) k_lk_track(TrackArgs a) {
         D = 1.f / D;
         nx -= half, ny -= half;
         float pdx = 0, pdy = 0;
+        int r0[kRun + 1], r1[kRun + 1], cinx = -(1 << 30), ciny = -(1 << 30); // the lane's taps of the search window, kept while its integer origin stays
         for (int j = 0; j < 30; ++j) {
             const int inx = (int)floorf(nx), iny = (int)floorf(ny);
             if (inx < -kWin || inx >= J.w || iny < -kWin || iny >= J.h) {
@@ -275,15 +276,17 @@ __global__ void __launch_bounds__(256) k_lk_track(TrackArgs a) {
             iw01 = (int)rintf(fa * (1.f - fb) * (float)(1 << W_BITS));
             iw10 = (int)rintf((1.f - fa) * fb * (float)(1 << W_BITS));
             iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
-            const uint8_t *s0 = J.img + (size_t)(iny + wy + kPad) * J.pitch + (inx + wx + kPad), *s1 = s0 + J.pitch;
-            int r0[kRun + 1], r1[kRun + 1];
+            if (inx != cinx || iny != ciny) { // uniform: the window only moves to other pixels every few iterations
+                const uint8_t *s0 = J.img + (size_t)(iny + wy + kPad) * J.pitch + (inx + wx + kPad), *s1 = s0 + J.pitch;
 #pragma unroll
-            for (int k = 0; k <= kRun; ++k) r0[k] = s0[k], r1[k] = s1[k];
+                for (int k = 0; k <= kRun; ++k) r0[k] = s0[k], r1[k] = s1[k];
+                cinx = inx, ciny = iny;
+            }
             float sb1 = 0, sb2 = 0;
 #pragma unroll
             for (int k = 0; k < kRun; ++k) {
-                const int diff = ((r0[k] * iw00 + r0[k + 1] * iw01 + r1[k] * iw10 + r1[k + 1] * iw11 + (1 << (W_BITS - 5 - 1))) >> (W_BITS - 5)) - tI[k];
-                sb1 += (float)(diff * tX[k]), sb2 += (float)(diff * tY[k]);
+                const int diff = ((__mul24(r0[k], iw00) + __mul24(r0[k + 1], iw01) + __mul24(r1[k], iw10) + __mul24(r1[k + 1], iw11) + (1 << (W_BITS - 5 - 1))) >> (W_BITS - 5)) - tI[k];
+                sb1 += (float)__mul24(diff, tX[k]), sb2 += (float)__mul24(diff, tY[k]);
             }
             if (!live) sb1 = 0.f, sb2 = 0.f;
             const float b1 = wave_sum_f(sb1) * FLT_SCALE, b2 = wave_sum_f(sb2) * FLT_SCALE;
