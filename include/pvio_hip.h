@@ -231,6 +231,16 @@ int32_t pvio_hip_image_download_level(pvio_hip_ctx *ctx, const pvio_hip_image *i
 int32_t pvio_hip_klt_track(pvio_hip_ctx *ctx, const pvio_hip_image *prev, const pvio_hip_image *next,
                            int32_t n, const float *prev_xy, float *next_xy, uint8_t *status);
 
+/* Harris corners of the preprocessed image, replaces `gftt()->detect(image, keypoints)` (opencv_image.cpp:61, detector
+ * created at :183 as GFTTDetector::create(1000, 1e-3, 20, 3, useHarrisDetector = true) -> k = 0.04, blockSize 3,
+ * Sobel aperture 3): response map, 3x3 non-maximum suppression and compaction on the device, ordering by response and
+ * the minimum-distance grid selection of cv::goodFeaturesToTrack on the host side of this call.  xy / response take up
+ * to max_corners entries, in selection order (strongest first); *n receives the count. */
+int32_t pvio_hip_image_detect(pvio_hip_ctx *ctx, const pvio_hip_image *img, int32_t max_corners, double quality_level,
+                              double min_distance, float *xy, float *response, int32_t *n);
+/* tests: response map (h x w floats) of the last pvio_hip_image_detect call on an image of this size */
+int32_t pvio_hip_image_download_response(pvio_hip_ctx *ctx, const pvio_hip_image *img, float *response);
+
 /* hipEvent duration [ms] of the LK kernel of the last pvio_hip_klt_track call (bench.py: tracks/ms, pyramids resident) */
 double pvio_hip_klt_last_device_ms(const pvio_hip_ctx *ctx);
 

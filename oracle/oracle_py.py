@@ -193,3 +193,26 @@ def klt_track(prev_levels, next_levels, prev_xy, next_xy_init):
     L.oracle_klt_track(n_levels, ws.ctypes.data_as(i32p), hs.ctypes.data_as(i32p), PI, PD, NI, n, prev_xy.ctypes.data_as(f32p),
                        nxt.ctypes.data_as(f32p), status.ctypes.data_as(u8p))
     return nxt, status
+
+
+def harris_response(img):
+    """oracle_harris_response: float32 response map of a (CLAHE'd) u8 image."""
+    L = lib()
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    out = np.zeros((h, w), np.float32)
+    L.oracle_harris_response(img.ctypes.data_as(C.POINTER(C.c_uint8)), C.c_int(w), C.c_int(h), out.ctypes.data_as(C.POINTER(C.c_float)))
+    return out
+
+
+def good_features(resp, max_corners=1000, quality=1.0e-3, min_distance=20.0):
+    """oracle_good_features: (xy float32 [n, 2], response float32 [n]) in selection order."""
+    L = lib()
+    L.oracle_good_features.restype = C.c_int
+    resp = np.ascontiguousarray(resp, np.float32)
+    h, w = resp.shape
+    xy = np.zeros((max(max_corners, 1), 2), np.float32)
+    r = np.zeros(max(max_corners, 1), np.float32)
+    n = L.oracle_good_features(resp.ctypes.data_as(C.POINTER(C.c_float)), C.c_int(w), C.c_int(h), C.c_int(max_corners), C.c_double(quality), C.c_double(min_distance),
+                               xy.ctypes.data_as(C.POINTER(C.c_float)), r.ctypes.data_as(C.POINTER(C.c_float)))
+    return xy[:n].copy(), r[:n].copy()

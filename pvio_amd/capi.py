@@ -82,7 +82,7 @@ EXPORTS = [
     "pvio_hip_ba_solve", "pvio_hip_ba_marginalize", "pvio_hip_ba_reprojection_error",
     "pvio_hip_ba_upload", "pvio_hip_ba_solve_resident", "pvio_hip_ba_download", "pvio_hip_ba_profile_resident",
     "pvio_hip_comm_unique_id", "pvio_hip_comm_init", "pvio_preintegrate",
-    "pvio_hip_image_create", "pvio_hip_image_release", "pvio_hip_image_download_level", "pvio_hip_klt_track",
+    "pvio_hip_image_create", "pvio_hip_image_release", "pvio_hip_image_download_level", "pvio_hip_klt_track", "pvio_hip_image_detect", "pvio_hip_image_download_response",
     "pvio_hip_klt_last_device_ms",
 ]
 
@@ -138,6 +138,10 @@ def load(path=None):
     lib.pvio_hip_image_download_level.restype = C.c_int32
     lib.pvio_hip_klt_track.argtypes = [vp, vp, vp, C.c_int32, c_float_p, c_float_p, c_uint8_p]
     lib.pvio_hip_klt_track.restype = C.c_int32
+    lib.pvio_hip_image_detect.argtypes = [vp, vp, C.c_int32, C.c_double, C.c_double, c_float_p, c_float_p, C.POINTER(C.c_int32)]
+    lib.pvio_hip_image_detect.restype = C.c_int32
+    lib.pvio_hip_image_download_response.argtypes = [vp, vp, c_float_p]
+    lib.pvio_hip_image_download_response.restype = C.c_int32
     lib.pvio_hip_klt_last_device_ms.argtypes = [vp]
     lib.pvio_hip_klt_last_device_ms.restype = C.c_double
     if path is None:

@@ -120,6 +120,20 @@ int32_t pvio_hip_image_download_level(pvio_hip_ctx *ctx, const pvio_hip_image *i
     if (!ctx || !img) return PVIO_ERR_INVALID_ARGUMENT;
     return ctx->klt->download_level(reinterpret_cast<const pvklt::Image *>(img), level, pixels, deriv, w, h);
 }
+int32_t pvio_hip_image_detect(pvio_hip_ctx *ctx, const pvio_hip_image *img, int32_t max_corners, double quality_level, double min_distance, float *xy,
+                              float *response, int32_t *n) {
+    if (!ctx || !img || !xy || !response || !n || max_corners <= 0 || !(quality_level > 0)) return PVIO_ERR_INVALID_ARGUMENT;
+    int cnt = 0;
+    const int rc = ctx->klt->detect(reinterpret_cast<const pvklt::Image *>(img), max_corners, quality_level, min_distance, xy, response, &cnt);
+    *n = cnt;
+    return rc;
+}
+
+int32_t pvio_hip_image_download_response(pvio_hip_ctx *ctx, const pvio_hip_image *img, float *response) {
+    if (!ctx || !img || !response) return PVIO_ERR_INVALID_ARGUMENT;
+    return ctx->klt->download_response(reinterpret_cast<const pvklt::Image *>(img), response);
+}
+
 int32_t pvio_hip_klt_track(pvio_hip_ctx *ctx, const pvio_hip_image *prev, const pvio_hip_image *next, int32_t n, const float *prev_xy,
                            float *next_xy, uint8_t *status) {
     if (!ctx || !prev || !next || n < 0 || (n > 0 && (!prev_xy || !next_xy || !status))) return PVIO_ERR_INVALID_ARGUMENT;

@@ -17,6 +17,9 @@ class Klt {
     void release_image(Image *img);
     int download_level(const Image *img, int level, uint8_t *pixels, int16_t *deriv, int32_t *w, int32_t *h);
     int track(const Image *prev, const Image *next, int n, const float *prev_xy, float *next_xy, uint8_t *status);
+    // Harris corners of level 0 (cv::goodFeaturesToTrack semantics); xy / response need room for max_corners entries
+    int detect(const Image *img, int max_corners, double quality, double min_distance, float *xy, float *response, int *n_out);
+    int download_response(const Image *img, float *resp);
     const std::string &error() const { return err_; }
     double last_track_ms() const { return last_ms_; } // hipEvent time of the last k_lk_track launch
 
@@ -28,6 +31,8 @@ class Klt {
     std::string err_;
     void *d_pts_ = nullptr;
     size_t pts_cap_ = 0;
+    void *d_det_ = nullptr; // detection scratch: cov planes, response map, candidates
+    size_t det_cap_ = 0;
 };
 
 } // namespace pvklt

@@ -16,7 +16,9 @@
 #include "klt.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstring>
+#include <utility>
 #include <vector>
 
 #include "../../include/pvio_hip.h"
@@ -334,6 +336,7 @@ Klt::Klt(int device) : device_(device) {
 }
 Klt::~Klt() {
     if (d_pts_) (void)hipFree(d_pts_);
+    if (d_det_) (void)hipFree(d_det_);
     if (ev0_) (void)hipEventDestroy(ev0_);
     if (ev1_) (void)hipEventDestroy(ev1_);
     if (stream_) (void)hipStreamDestroy(stream_);
@@ -486,6 +489,171 @@ int Klt::track(const Image *prev, const Image *next, int n, const float *prev_xy
     float ms = 0;
     (void)hipEventElapsedTime(&ms, ev0_, ev1_);
     last_ms_ = ms;
+    return PVIO_OK;
+}
+
+// ---- corner detection: cv::goodFeaturesToTrack with the Harris measure (opencv_image.cpp:61, detector :183) ---------
+// Streaming image kernels over level 0 (the CLAHE output, padded with its REFLECT_101 border); the float operations
+// follow ONE fixed order (stated in oracle/oracle_gftt.cpp) so that the response map is reproducible bit for bit.
+__global__ void __launch_bounds__(256) k_harris_cov(LevelDesc L, float *cxx, float *cxy, float *cyy) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= L.w) return;
+    const uint8_t *p = L.img + (size_t)(y + kPad) * L.pitch + (x + kPad);
+    const int a0 = p[-L.pitch - 1], a1 = p[-L.pitch], a2 = p[-L.pitch + 1], b0 = p[-1], b2 = p[1], c0 = p[L.pitch - 1], c1 = p[L.pitch], c2 = p[L.pitch + 1];
+    const float s = (float)(1.0 / (4.0 * 3.0 * 255.0)), s2 = 2.0f * s;
+    float dx = s * (float)((a2 - a0) + (c2 - c0));
+    dx = dx + s2 * (float)(b2 - b0);
+    const float dy = s * (float)((c0 + 2 * c1 + c2) - (a0 + 2 * a1 + a2));
+    const size_t o = (size_t)y * L.w + x;
+    cxx[o] = dx * dx, cxy[o] = dx * dy, cyy[o] = dy * dy;
+}
+
+__global__ void __launch_bounds__(256) k_harris_response(int w, int h, const float *cxx, const float *cxy, const float *cyy, float *resp, int *max_bits) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+    __shared__ float smax[4];
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    float r = -INFINITY;
+    if (x < w) {
+        float a = 0, b = 0, c = 0;
+#pragma unroll
+        for (int j = -1; j <= 1; ++j) {
+            const size_t row = (size_t)reflect101(y + j, h) * w;
+#pragma unroll
+            for (int i = -1; i <= 1; ++i) {
+                const size_t o = row + reflect101(x + i, w);
+                a += cxx[o], b += cxy[o], c += cyy[o];
+            }
+        }
+        const float t = a + c;
+        r = a * c;
+        r = r - b * b;
+        r = r - (0.04f * t) * t;
+        resp[(size_t)y * w + x] = r;
+    }
+    // block maximum -> one atomic per block (float order == int order of the bit patterns for non-negative values; a negative
+    // maximum never beats the 0 the cell starts from: the threshold is then 0 and TOZERO keeps nothing negative, as in OpenCV)
+    float m = r;
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) smax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
+        if (m > 0.0f) atomicMax(max_bits, __float_as_int(m));
+    }
+}
+
+__global__ void __launch_bounds__(256) k_harris_collect(int w, int h, const float *resp, const int *max_bits, float quality, int cap, int *count, float *cand_val,
+                                                        int *cand_pos) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x < 1 || x >= w - 1 || y < 1 || y >= h - 1) return;
+    const float mx = __int_as_float(*max_bits);
+    const float thr = (float)((double)mx * (double)quality);
+    const float v0 = resp[(size_t)y * w + x];
+    const float v = v0 > thr ? v0 : 0.0f;
+    if (v == 0.0f) return;
+    float m = v;
+#pragma unroll
+    for (int j = -1; j <= 1; ++j)
+#pragma unroll
+        for (int i = -1; i <= 1; ++i) {
+            const float q = resp[(size_t)(y + j) * w + x + i];
+            m = fmaxf(m, q > thr ? q : 0.0f);
+        }
+    if (v == m) {
+        const int slot = atomicAdd(count, 1);
+        if (slot < cap) cand_val[slot] = v, cand_pos[slot] = y * w + x;
+    }
+}
+
+int Klt::detect(const Image *img, int max_corners, double quality, double min_distance, float *xy, float *response, int *n_out) {
+    *n_out = 0;
+    (void)hipSetDevice(device_);
+    const int w = img->w, h = img->h;
+    const size_t px = (size_t)w * h;
+    const int cap = (int)(px / 4 + 64);
+    const size_t need = px * 4 * sizeof(float) + (size_t)cap * 8 + 256;
+    if (need > det_cap_) {
+        if (d_det_) (void)hipFree(d_det_);
+        d_det_ = nullptr;
+        if (hipMalloc(&d_det_, need) != hipSuccess) {
+            det_cap_ = 0;
+            err_ = "hipMalloc failed";
+            return PVIO_ERR_OUT_OF_MEMORY;
+        }
+        det_cap_ = need;
+    }
+    float *cxx = static_cast<float *>(d_det_), *cxy = cxx + px, *cyy = cxy + px, *resp = cyy + px, *cand_val = resp + px;
+    int *cand_pos = reinterpret_cast<int *>(cand_val + cap), *scal = cand_pos + cap; // scal[0] = max bits, scal[1] = count
+    (void)hipMemsetAsync(scal, 0, 8, stream_);
+    const dim3 grid((w + 255) / 256, h), blk(256);
+    hipLaunchKernelGGL(k_harris_cov, grid, blk, 0, stream_, img->lv[0], cxx, cxy, cyy);
+    hipLaunchKernelGGL(k_harris_response, grid, blk, 0, stream_, w, h, (const float *)cxx, (const float *)cxy, (const float *)cyy, resp, scal);
+    hipLaunchKernelGGL(k_harris_collect, grid, blk, 0, stream_, w, h, (const float *)resp, (const int *)scal, (float)quality, cap, scal + 1, cand_val, cand_pos);
+    int hs[2] = {0, 0};
+    bool ok = hipMemcpyAsync(hs, scal, 8, hipMemcpyDeviceToHost, stream_) == hipSuccess && hipStreamSynchronize(stream_) == hipSuccess && hipGetLastError() == hipSuccess;
+    const int nc = std::min(hs[1], cap);
+    std::vector<float> val((size_t)nc);
+    std::vector<int> pos((size_t)nc);
+    if (ok && nc > 0) {
+        ok = hipMemcpyAsync(val.data(), cand_val, (size_t)nc * 4, hipMemcpyDeviceToHost, stream_) == hipSuccess;
+        ok = ok && hipMemcpyAsync(pos.data(), cand_pos, (size_t)nc * 4, hipMemcpyDeviceToHost, stream_) == hipSuccess && hipStreamSynchronize(stream_) == hipSuccess;
+    }
+    if (!ok) {
+        err_ = "corner detection failed";
+        return PVIO_ERR_HIP;
+    }
+    // the order the atomics handed the slots out in is arbitrary: (response, address) descending makes it canonical again
+    std::vector<int> order((size_t)nc);
+    for (int i = 0; i < nc; ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](int p, int q) { return val[p] > val[q] ? true : (val[p] < val[q] ? false : pos[p] > pos[q]); });
+    int n = 0;
+    if (min_distance >= 1) { // greedy minimum-distance selection on a grid (goodFeaturesToTrack)
+        const int cell = (int)std::lround(min_distance), gw = (w + cell - 1) / cell, gh = (h + cell - 1) / cell;
+        std::vector<std::vector<std::pair<float, float>>> grid2((size_t)gw * gh);
+        const double md2 = min_distance * min_distance;
+        for (int idx : order) {
+            const int y = pos[idx] / w, x = pos[idx] - y * w, xc = x / cell, yc = y / cell;
+            bool good = true;
+            for (int yy = std::max(0, yc - 1); yy <= std::min(gh - 1, yc + 1) && good; ++yy)
+                for (int xx = std::max(0, xc - 1); xx <= std::min(gw - 1, xc + 1) && good; ++xx)
+                    for (const auto &q : grid2[(size_t)yy * gw + xx]) {
+                        const float dx = x - q.first, dy = y - q.second;
+                        if (dx * dx + dy * dy < md2) {
+                            good = false;
+                            break;
+                        }
+                    }
+            if (!good) continue;
+            grid2[(size_t)yc * gw + xc].push_back({(float)x, (float)y});
+            xy[2 * n] = (float)x, xy[2 * n + 1] = (float)y, response[n] = val[idx];
+            if (++n >= max_corners && max_corners > 0) break;
+        }
+    } else {
+        for (int idx : order) {
+            xy[2 * n] = (float)(pos[idx] % w), xy[2 * n + 1] = (float)(pos[idx] / w), response[n] = val[idx];
+            if (++n >= max_corners && max_corners > 0) break;
+        }
+    }
+    *n_out = n;
+    return PVIO_OK;
+}
+
+int Klt::download_response(const Image *img, float *resp) { // tests: the last detect()'s response map
+    const size_t px = (size_t)img->w * img->h;
+    if (!d_det_ || det_cap_ < px * 16) {
+        err_ = "no response map (call detect first)";
+        return PVIO_ERR_INVALID_ARGUMENT;
+    }
+    const float *r = static_cast<const float *>(d_det_) + 3 * px;
+    if (hipMemcpy(resp, r, px * 4, hipMemcpyDeviceToHost) != hipSuccess) return PVIO_ERR_HIP;
     return PVIO_OK;
 }
 

@@ -145,8 +145,34 @@ void HipImage::preprocess() {
     if (rc != 0) throw std::runtime_error(std::string("pvio_hip_image_create: ") + pvio_hip_last_error(ctx_)); // no CPU path
 }
 
-void HipImage::detect_keypoints(std::vector<vector<2>> &, size_t, double) const {
-    // corner detection (cv::GFTTDetector, opencv_image.cpp:54-86) is not part of this back end yet: no points are added
+void HipImage::detect_keypoints(std::vector<vector<2>> &keypoints, size_t max_points, double keypoint_distance) const {
+    // opencv_image.cpp:54-86.  `max_points` only gets a default there and is not passed on: the detector is the fixed
+    // GFTTDetector::create(1000, 1e-3, 20, 3, useHarris = true) of :183.
+    if (max_points == 0) max_points = 100;
+    (void)max_points;
+    if (!img_) throw std::runtime_error("HipImage::detect_keypoints: preprocess() was not called");
+    constexpr int kMaxCorners = 1000;
+    std::vector<float> xy(2 * kMaxCorners), resp(kMaxCorners);
+    int32_t n = 0;
+    const int32_t rc = pvio_hip_image_detect(ctx_, img_, kMaxCorners, 1.0e-3, 20.0, xy.data(), resp.data(), &n);
+    if (rc != 0) throw std::runtime_error(std::string("pvio_hip_image_detect: ") + pvio_hip_last_error(ctx_));
+    if (n == 0) return;
+    // strongest first (the device call already returns them in that order; the reference re-sorts by response, :64-66)
+    std::vector<int> order((size_t)n);
+    for (int i = 0; i < n; ++i) order[(size_t)i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return resp[(size_t)a] > resp[(size_t)b]; });
+    std::vector<vector<2>> fresh;
+    fresh.reserve((size_t)n);
+    for (int i : order) {
+        vector<2> p;
+        p[0] = xy[2 * (size_t)i], p[1] = xy[2 * (size_t)i + 1];
+        fresh.push_back(p);
+    }
+    PoissonDisk2 filter(keypoint_distance);
+    for (const auto &p : keypoints) filter.preset_point(p); // existing keypoints block their neighbourhood (:72-73)
+    filter.insert_points(fresh);
+    for (const auto &p : fresh)
+        if (!(p[0] < 20 || p[1] < 20 || p[0] >= w_ - 20 || p[1] >= h_ - 20)) keypoints.push_back(p); // 20 px border (:76-82)
 }
 
 void HipImage::track_keypoints(const Image *next_image, const std::vector<vector<2>> &curr_keypoints, std::vector<vector<2>> &next_keypoints, std::vector<char> &result_status) const {

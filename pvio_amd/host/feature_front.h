@@ -7,9 +7,10 @@
 //   select_tracked          pvio/src/pvio/map/frame.cpp:108-130  (track-length order + Poisson-disk acceptance)
 //   HipImage                pvio-extra/src/pvio/extra/opencv_image.cpp:88-160 behind pvio::Image (pvio.h:114-133):
 //                           preprocess() = CLAHE + pyramid + Scharr on the GPU, track_keypoints() = device LK + the 20 px
-//                           border gate.  The F-matrix RANSAC of :113-129 (cv::findFundamentalMat, third party) and
-//                           detect_keypoints (cv::GFTTDetector) are SURVEY 8(f) row 2 and are NOT part of this class yet:
-//                           set_outlier_filter() lets the caller plug a rejection step in the same place.
+//                           border gate, detect_keypoints() = Harris corners on the GPU (goodFeaturesToTrack semantics) +
+//                           Poisson-disk filter against the existing points + 20 px border.  The F-matrix RANSAC of
+//                           :113-129 (cv::findFundamentalMat, third party) is SURVEY 8(f) row 2 and NOT part of this class
+//                           yet: set_outlier_filter() lets the caller plug a rejection step in the same place.
 #pragma once
 #include <array>
 #include <cstddef>

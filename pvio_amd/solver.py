@@ -144,3 +144,18 @@ def preintegrate(t, w, a, t_end, bg, ba, noise, lib=None):
     if rc != 0:
         raise HipError("pvio_preintegrate failed: %d" % rc)
     return delta, cov, U, jac
+
+
+def detect_corners(ctx, img, max_corners=1000, quality=1.0e-3, min_distance=20.0, want_response_map=False):
+    """pvio_hip_image_detect: Harris corners (goodFeaturesToTrack semantics) of a preprocessed HipImage.
+    Returns (xy float32 [n, 2], response float32 [n]) and, on request, the response map."""
+    xy = np.zeros((max_corners, 2), np.float32)
+    resp = np.zeros(max_corners, np.float32)
+    n = C.c_int32(0)
+    ctx._check(ctx.lib.pvio_hip_image_detect(ctx.ctx, img.handle, max_corners, quality, min_distance, xy.ctypes.data_as(capi.c_float_p),
+                                             resp.ctypes.data_as(capi.c_float_p), C.byref(n)), "pvio_hip_image_detect")
+    if not want_response_map:
+        return xy[:n.value].copy(), resp[:n.value].copy()
+    rmap = np.zeros((img.h, img.w), np.float32)
+    ctx._check(ctx.lib.pvio_hip_image_download_response(ctx.ctx, img.handle, rmap.ctypes.data_as(capi.c_float_p)), "pvio_hip_image_download_response")
+    return xy[:n.value].copy(), resp[:n.value].copy(), rmap

@@ -93,6 +93,8 @@ using std::min;
 // ---- device intrinsics ---------------------------------------------------------------------------------
 inline void __syncthreads() { hipemu::syncthreads(); }
 inline double rsqrt(double x) { return 1.0 / std::sqrt(x); }
+inline int __float_as_int(float f) { int i; std::memcpy(&i, &f, 4); return i; }
+inline float __int_as_float(int i) { float f; std::memcpy(&f, &i, 4); return f; }
 inline int __mul24(int a, int b) { return a * b; } // operands are within 24 bits wherever the kernels use it
 inline double __builtin_amdgcn_rsq(double x) { return (double)(float)(1.0 / std::sqrt(x)); } // deliberately low precision, like v_rsq_f64
 inline long long clock64() { return (long long)(hipemu::now_ms() * 1e6); }

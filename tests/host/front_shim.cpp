@@ -78,4 +78,32 @@ int host_image_track(const uint8_t *img0, const uint8_t *img1, int w, int h, int
     return rc;
 }
 
+// pvio::Image seam, detection: existing keypoints in, all keypoints out (existing first); returns the total or -1
+int host_image_detect(const uint8_t *img, int w, int h, int n_existing, const double *existing_xy, double keypoint_distance, int cap, double *out_xy, char *err,
+                      int err_len) {
+    pvio_hip_ctx *ctx = nullptr;
+    pvio_hip_opts opts;
+    std::memset(&opts, 0, sizeof(opts));
+    if (pvio_hip_create(&opts, &ctx) != 0 || !ctx) {
+        std::strncpy(err, "pvio_hip_create failed (no GPU?)", (size_t)err_len - 1);
+        return -1;
+    }
+    int n = -1;
+    try {
+        HipImage a(ctx, img, w, h, w, 0.0);
+        a.preprocess();
+        std::vector<vector<2>> kps((size_t)n_existing);
+        for (int i = 0; i < n_existing; ++i) kps[i][0] = existing_xy[2 * i], kps[i][1] = existing_xy[2 * i + 1];
+        const Image *im = &a;
+        im->detect_keypoints(kps, 0, keypoint_distance);
+        n = (int)kps.size() < cap ? (int)kps.size() : cap;
+        for (int i = 0; i < n; ++i) out_xy[2 * i] = kps[i][0], out_xy[2 * i + 1] = kps[i][1];
+    } catch (const std::exception &e) {
+        std::strncpy(err, e.what(), (size_t)err_len - 1);
+        n = -1;
+    }
+    pvio_hip_destroy(ctx);
+    return n;
+}
+
 } // extern "C"

@@ -34,3 +34,10 @@ def test_gpu_klt_no_clahe_and_empty(gpu_ctx, oracle):
     # identical images: zero motion
     q, st, _ = klt_track(gpu_ctx, A, A, p, p)
     assert st.all() and np.abs(q - p).max() < 1e-3
+
+
+def test_gpu_corner_detection_matches_oracle(gpu_ctx, oracle):
+    import gftt_compare
+    print(gftt_compare.check_detect(gpu_ctx, oracle, 752, 480))   # EuRoC size
+    print(gftt_compare.check_detect(gpu_ctx, oracle, 512, 512, max_corners=300, min_distance=11.0))  # TUM-VI size
+    print(gftt_compare.check_detect(gpu_ctx, oracle, 333, 241, quality=0.05))

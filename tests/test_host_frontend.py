@@ -154,3 +154,41 @@ def test_image_seam_emulated(host, oracle):
 def test_image_seam_gpu(oracle):
     lib = host_compare.load("libpvio_host.so")
     assert _image_seam(lib, oracle, 512, 512, 1200) > 900
+
+
+def _detect_seam(lib, oracle, w, h):
+    """pvio::Image::detect_keypoints through the host adapter == oracle response map + goodFeaturesToTrack selection, then
+    the reference's own post-processing (Poisson filter against the existing points, 20 px border) done independently here."""
+    img0, _, _, _, _ = synth.make_image_pair(w, h, 8)
+    r = oracle.harris_response(oracle.clahe(img0))
+    xy, resp = oracle.good_features(r, 1000, 1e-3, 20.0)
+    rng = np.random.default_rng(9)
+    existing = np.ascontiguousarray(np.stack([rng.uniform(20, w - 20, 12), rng.uniform(20, h - 20, 12)], 1))
+    dist = 15.0
+    acc = poisson(oracle_lib(), "oracle", dist, existing, xy.astype(np.float64))
+    want = [tuple(p) for p, a in zip(xy.astype(np.float64), acc) if a and not (p[0] < 20 or p[1] < 20 or p[0] >= w - 20 or p[1] >= h - 20)]
+    out = np.zeros((2000, 2))
+    err = C.create_string_buffer(256)
+    lib.host_image_detect.restype = C.c_int
+    n = lib.host_image_detect(_p(np.ascontiguousarray(img0), u8p), C.c_int(w), C.c_int(h), C.c_int(len(existing)), _p(existing, f64p), C.c_double(dist), C.c_int(2000),
+                              _p(out, f64p), err, C.c_int(256))
+    assert n >= 0, err.value
+    got = out[:n]
+    assert (got[:len(existing)] == existing).all()  # existing keypoints stay where they are, new ones are appended
+    assert [tuple(p) for p in got[len(existing):]] == want
+    return len(want)
+
+
+def oracle_lib():
+    oracle_py.build()
+    return oracle_py.lib()
+
+
+def test_detect_seam_emulated(host, oracle):
+    assert _detect_seam(host, oracle, 200, 160) > 5
+
+
+@pytest.mark.gpu
+def test_detect_seam_gpu(oracle):
+    lib = host_compare.load("libpvio_host.so")
+    assert _detect_seam(lib, oracle, 752, 480) > 100
