@@ -1,6 +1,8 @@
 // feature_front.cpp -- see feature_front.h.  Host C++ above the C ABI; no OpenCV, no Eigen.
 #include "feature_front.h"
 
+#include "fundamental_ransac.h"
+
 #include <algorithm>
 #include <cmath>
 #include <stdexcept>
@@ -198,6 +200,22 @@ void HipImage::track_keypoints(const Image *next_image, const std::vector<vector
         std::vector<vector<2>> nxt(n);
         for (size_t i = 0; i < n; ++i) nxt[i][0] = next_xy[2 * i], nxt[i][1] = next_xy[2 * i + 1];
         filter_(curr_keypoints, nxt, result_status);
+    } else if (ransac_) {
+        // opencv_image.cpp:113-129: fundamental-matrix RANSAC (threshold 1 px, confidence 0.99) over the survivors, when
+        // there are at least eight of them; its outliers are dropped
+        std::vector<size_t> l;
+        std::vector<float> p, q;
+        for (size_t i = 0; i < n; ++i)
+            if (result_status[i] != 0) {
+                l.push_back(i);
+                p.push_back(prev_xy[2 * i]), p.push_back(prev_xy[2 * i + 1]), q.push_back(next_xy[2 * i]), q.push_back(next_xy[2 * i + 1]);
+            }
+        if (l.size() >= 8) {
+            std::vector<uint8_t> mask;
+            find_fundamental_ransac((int)l.size(), p.data(), q.data(), 1.0, 0.99, mask);
+            for (size_t i = 0; i < l.size(); ++i)
+                if (mask[i] == 0) result_status[l[i]] = 0;
+        }
     }
     for (size_t i = 0; i < n; ++i)
         if (result_status[i]) next_keypoints[i][0] = next_xy[2 * i], next_keypoints[i][1] = next_xy[2 * i + 1];

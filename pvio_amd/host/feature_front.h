@@ -8,9 +8,9 @@
 //   HipImage                pvio-extra/src/pvio/extra/opencv_image.cpp:88-160 behind pvio::Image (pvio.h:114-133):
 //                           preprocess() = CLAHE + pyramid + Scharr on the GPU, track_keypoints() = device LK + the 20 px
 //                           border gate, detect_keypoints() = Harris corners on the GPU (goodFeaturesToTrack semantics) +
-//                           Poisson-disk filter against the existing points + 20 px border.  The F-matrix RANSAC of
-//                           :113-129 (cv::findFundamentalMat, third party) is SURVEY 8(f) row 2 and NOT part of this class
-//                           yet: set_outlier_filter() lets the caller plug a rejection step in the same place.
+//                           Poisson-disk filter against the existing points + 20 px border; the fundamental-matrix RANSAC
+//                           of :113-129 runs on the host (fundamental_ransac.h, a restatement of OpenCV's published
+//                           algorithm); set_outlier_filter() replaces it with a caller-supplied rejection step.
 #pragma once
 #include <array>
 #include <cstddef>
@@ -75,6 +75,7 @@ class HipImage : public Image {
     // optional rejection step after the border gate (the place of the reference's fundamental-matrix RANSAC)
     using OutlierFilter = std::function<void(const std::vector<vector<2>> &curr, const std::vector<vector<2>> &next, std::vector<char> &status)>;
     void set_outlier_filter(OutlierFilter f) { filter_ = std::move(f); }
+    void enable_ransac(bool on) { ransac_ = on; } // default on, like the reference; a custom filter takes precedence
     const pvio_hip_image *device_image() const { return img_; }
 
   private:
@@ -83,6 +84,7 @@ class HipImage : public Image {
     int w_, h_;
     pvio_hip_image *img_ = nullptr;
     OutlierFilter filter_;
+    bool ransac_ = true;
 };
 
 } // namespace pvio

@@ -4,6 +4,7 @@
 #include <memory>
 
 #include "../../pvio_amd/host/feature_front.h"
+#include "../../pvio_amd/host/fundamental_ransac.h"
 
 using namespace pvio;
 
@@ -48,7 +49,7 @@ void host_predict_keypoints(const double q_cam_i[4], const double q_imu_i[4], co
 
 // pvio::Image seam: two images, preprocess both, track with an initial guess; returns 0 or -1 (message in err)
 int host_image_track(const uint8_t *img0, const uint8_t *img1, int w, int h, int n, const double *curr_xy, double *next_xy /* in: guess, out */,
-                     int use_guess, uint8_t *status, char *err, int err_len) {
+                     int use_guess, int use_ransac, uint8_t *status, char *err, int err_len) {
     pvio_hip_ctx *ctx = nullptr;
     pvio_hip_opts opts;
     std::memset(&opts, 0, sizeof(opts));
@@ -60,6 +61,7 @@ int host_image_track(const uint8_t *img0, const uint8_t *img1, int w, int h, int
     try {
         HipImage a(ctx, img0, w, h, w, 0.0), b(ctx, img1, w, h, w, 0.05);
         a.preprocess(), b.preprocess();
+        a.enable_ransac(use_ransac != 0);
         std::vector<vector<2>> cur((size_t)n), nxt;
         for (int i = 0; i < n; ++i) cur[i][0] = curr_xy[2 * i], cur[i][1] = curr_xy[2 * i + 1];
         if (use_guess) {
@@ -77,6 +79,15 @@ int host_image_track(const uint8_t *img0, const uint8_t *img1, int w, int h, int
     pvio_hip_destroy(ctx);
     return rc;
 }
+
+int host_ransac(int n, const float *p, const float *q, double threshold, double confidence, uint8_t *mask, double *F) {
+    std::vector<uint8_t> m;
+    const int good = find_fundamental_ransac(n, p, q, threshold, confidence, m, F);
+    for (int i = 0; i < n; ++i) mask[i] = m[(size_t)i];
+    return good;
+}
+
+int host_7point(const float *p, const float *q, double *F27) { return fundamental_7point(p, q, F27); }
 
 // pvio::Image seam, detection: existing keypoints in, all keypoints out (existing first); returns the total or -1
 int host_image_detect(const uint8_t *img, int w, int h, int n_existing, const double *existing_xy, double keypoint_distance, int cap, double *out_xy, char *err,

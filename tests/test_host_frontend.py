@@ -136,7 +136,7 @@ def _image_seam(lib, oracle, w, h, n):
     st = np.zeros(n, np.uint8)
     err = C.create_string_buffer(256)
     rc = lib.host_image_track(_p(np.ascontiguousarray(img0), u8p), _p(np.ascontiguousarray(img1), u8p), C.c_int(w), C.c_int(h), C.c_int(n), _p(cur, f64p),
-                              _p(nxt, f64p), C.c_int(1), _p(st, u8p), err, C.c_int(256))
+                              _p(nxt, f64p), C.c_int(1), C.c_int(0), _p(st, u8p), err, C.c_int(256))
     assert rc == 0, err.value
     assert (st.astype(bool) == (s_ref > 0)).all()
     ok = st > 0
@@ -192,3 +192,25 @@ def test_detect_seam_emulated(host, oracle):
 def test_detect_seam_gpu(oracle):
     lib = host_compare.load("libpvio_host.so")
     assert _detect_seam(lib, oracle, 752, 480) > 100
+
+
+def test_image_seam_with_ransac_rejects_planted_outliers(host, oracle):
+    """Full track_keypoints semantics (LK + border gate + fundamental-matrix RANSAC): tracks whose initial guess is far off
+    converge somewhere else and are inconsistent with the epipolar geometry of the rest -> dropped by the RANSAC stage."""
+    w, h, n = 240, 200, 160
+    img0, img1, p, truth, init = synth.make_image_pair(w, h, n)
+    cur, nxt0 = np.ascontiguousarray(p, np.float64), np.ascontiguousarray(init, np.float64)
+    res = {}
+    for use_ransac in (0, 1):
+        nxt, st, err = nxt0.copy(), np.zeros(n, np.uint8), C.create_string_buffer(256)
+        rc = host.host_image_track(_p(np.ascontiguousarray(img0), u8p), _p(np.ascontiguousarray(img1), u8p), C.c_int(w), C.c_int(h), C.c_int(n), _p(cur, f64p),
+                                   _p(nxt, f64p), C.c_int(1), C.c_int(use_ransac), _p(st, u8p), err, C.c_int(256))
+        assert rc == 0, err.value
+        res[use_ransac] = (st.astype(bool), nxt)
+    lk, (rs, nxt) = res[0][0], res[1]
+    assert not (rs & ~lk).any() and rs.sum() >= 8  # RANSAC only removes
+    e = np.linalg.norm(nxt - truth, axis=1)
+    assert np.median(e[rs]) < 0.3
+    # what it removed is, on average, worse than what it kept
+    if (lk & ~rs).any():
+        assert e[lk & ~rs].mean() >= e[rs].mean()

@@ -1,0 +1,95 @@
+"""Fundamental-matrix RANSAC of the host adapter (the place of cv::findFundamentalMat in OpenCvImage::track_keypoints)
+against an independent numpy restatement and against ground truth."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import host_compare
+import np_ransac
+
+f32p, u8p, f64p = C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.POINTER(C.c_double)
+
+
+@pytest.fixture(scope="module")
+def host():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(os.path.dirname(os.path.abspath(__file__)), "hipemu"), "libpvio_hipemu.so"])
+    lib = host_compare.load("libpvio_host_emu.so")
+    lib.host_ransac.restype = C.c_int
+    lib.host_7point.restype = C.c_int
+    return lib
+
+
+def two_views(n, outlier_frac, noise, seed):
+    """n correspondences of a random scene seen by two cameras 0.3 m apart (pixels, EuRoC intrinsics)."""
+    rng = np.random.default_rng(seed)
+    K = np.array([[458.654, 0, 367.215], [0, 457.296, 248.375], [0, 0, 1]])
+    X = np.stack([rng.uniform(-3, 3, n), rng.uniform(-2, 2, n), rng.uniform(3, 9, n)], 1)
+    a = 0.06
+    R = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+    t = np.array([0.3, 0.02, 0.05])
+
+    def proj(Xc):
+        x = (K @ (Xc / Xc[:, 2:3]).T).T
+        return x[:, :2]
+
+    p, q = proj(X), proj((R @ X.T).T + t)
+    p, q = p + rng.normal(0, noise, p.shape), q + rng.normal(0, noise, q.shape)
+    out = rng.uniform(size=n) < outlier_frac
+    q[out] += rng.uniform(8, 60, (out.sum(), 2)) * rng.choice([-1, 1], (out.sum(), 2))
+    return p.astype(np.float32), q.astype(np.float32), out
+
+
+def run_host(host, p, q, thr=1.0, conf=0.99):
+    mask = np.zeros(len(p), np.uint8)
+    F = np.zeros(9)
+    good = host.host_ransac(C.c_int(len(p)), np.ascontiguousarray(p).ctypes.data_as(f32p), np.ascontiguousarray(q).ctypes.data_as(f32p), C.c_double(thr), C.c_double(conf),
+                            mask.ctypes.data_as(u8p), F.ctypes.data_as(f64p))
+    return good, mask.astype(bool), F.reshape(3, 3)
+
+
+def test_seven_point_solutions_satisfy_the_constraints(host):
+    p, q, _ = two_views(7, 0.0, 0.0, 1)
+    F = np.zeros(27)
+    n = host.host_7point(np.ascontiguousarray(p).ctypes.data_as(f32p), np.ascontiguousarray(q).ctypes.data_as(f32p), F.ctypes.data_as(f64p))
+    assert n in (1, 3)
+    ref = np_ransac.seven_point(p, q)
+    assert len(ref) == n
+    for k in range(n):
+        Fk = F[9 * k:9 * k + 9].reshape(3, 3)
+        res = [np.array([q[i][0], q[i][1], 1.0]) @ Fk @ np.array([p[i][0], p[i][1], 1.0]) for i in range(7)]
+        assert np.abs(res).max() < 1e-6 * np.abs(Fk).max() * 1e6
+        assert abs(np.linalg.det(Fk / np.linalg.norm(Fk))) < 1e-9  # rank 2
+        assert min(np.abs(Fk / np.linalg.norm(Fk) - G / np.linalg.norm(G)).max() for G in ref) < 1e-6 or \
+            min(np.abs(Fk / np.linalg.norm(Fk) + G / np.linalg.norm(G)).max() for G in ref) < 1e-6
+
+
+@pytest.mark.parametrize("n,frac,noise,seed", [(300, 0.2, 0.3, 2), (120, 0.4, 0.2, 3), (60, 0.0, 0.5, 4), (800, 0.1, 0.1, 5), (9, 0.0, 0.05, 6)])
+def test_ransac_matches_numpy_restatement_and_finds_the_outliers(host, n, frac, noise, seed):
+    p, q, out = two_views(n, frac, noise, seed)
+    good, mask, F = run_host(host, p, q)
+    ref_mask, ref_F = np_ransac.ransac(p, q)
+    # same sampler, same models: the inlier sets agree (a point exactly at the 1 px threshold may flip with the rounding)
+    assert (mask != ref_mask).sum() <= max(1, n // 200)
+    assert good == mask.sum()
+    # ground truth: gross outliers are rejected, the bulk of the true inliers is kept
+    assert mask[out].sum() <= max(1, int(0.02 * n))
+    assert mask[~out].mean() > 0.6  # the model is the best MINIMAL-sample model (no refit, as in OpenCV): noisy samples lose some inliers
+    if good:
+        x1 = np.c_[p.astype(float), np.ones(n)]
+        x2 = np.c_[q.astype(float), np.ones(n)]
+        l = x1 @ F.T
+        d = np.abs((x2 * l).sum(1)) / np.hypot(l[:, 0], l[:, 1])
+        assert (d[mask] <= 1.0 + 1e-6).all()
+
+
+def test_ransac_degenerate_inputs(host):
+    p, q, _ = two_views(6, 0.0, 0.0, 7)
+    good, mask, _ = run_host(host, p, q)
+    assert good == 0 and not mask.any()  # fewer than seven points: no model
+    # all points identical: every sample is degenerate -> no model, nothing flagged as inlier
+    p = np.tile(np.array([[100.0, 120.0]], np.float32), (20, 1))
+    good, mask, _ = run_host(host, p, p.copy())
+    assert good == 0 and not mask.any()
