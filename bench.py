@@ -226,7 +226,7 @@ def main():
                                    % (n_frames, n_lm, "full VIO factor set (IMU pre-integration + gauge prior)" if vio else "reprojection only",
                                       pb_full.n_obs, pb_full.max_iterations),
                        "parallelism": "landmark shards x%d, RCCL all-reduce of the reduced pose system" % world if world > 1 else "single GPU",
-                       "graph": not args.no_graph},
+                       "graph": (not args.no_graph) and world == 1},
             "iterations_per_solve": iters / args.steps,
             "device_ms_per_step": 1e3 * dev_s / args.steps,
             "roofline": roofline,

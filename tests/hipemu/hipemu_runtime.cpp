@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <cstdlib>
 #include <ucontext.h>
 
 namespace hipemu {
@@ -28,6 +29,7 @@ std::vector<WaveState> waves;
 ucontext_t sched_ctx;
 int n_threads = 0, bar_arrived = 0, bar_generation = 0, n_done = 0;
 long launch_counter = 0;
+int g_order = [] { const char *e = std::getenv("HIPEMU_ORDER"); return !e ? 0 : (e[0] == 'r' ? 1 : (e[0] == 'i' ? 2 : 0)); }();
 std::function<void()> *cur_body = nullptr;
 Fiber *cur_fiber = nullptr;
 
@@ -122,7 +124,10 @@ void launch(dim3 grid, dim3 block, size_t shmem, Stream *s, std::function<void()
                     long spins = 0;
                     while (remaining > 0) {
                         int progressed = 0;
-                        for (int t = 0; t < nt; ++t) {
+                        for (int tt = 0; tt < nt; ++tt) {
+                            // HIPEMU_ORDER=reverse / interleave: run the fibers of a barrier interval in another order, to
+                            // flush out code that only works because thread 0 happens to run first
+                            const int t = g_order == 1 ? nt - 1 - tt : (g_order == 2 ? ((tt & 1) ? nt - 1 - (tt >> 1) : (tt >> 1)) : tt);
                             Fiber &f = fibers[t];
                             if (f.done) continue;
                             cur_fiber = &f;
