@@ -107,6 +107,37 @@ def bench_klt(ctx, args, width=512, height=512, n_points=1500, reps=50):
     return out
 
 
+def bench_concurrent_windows(pb, streams=3, steps=60):
+    """Aggregate iterations/s of `streams` independent windows solved at the same time (one context = one stream + one
+    hipGraph each, one host thread each).  Not the headline metric (a VIO session solves one window at a time): it shows how
+    much of the GPU the latency-bound single-window solve leaves free for other sessions."""
+    import threading
+    from pvio_amd import BASummary
+    from pvio_amd.solver import HipContext
+    ctxs = [HipContext(device=0) for _ in range(streams)]
+    for c in ctxs:
+        c.upload(pb)
+        for _ in range(5):
+            c.solve_resident(BASummary(pb, trace=False))
+    iters = [0] * streams
+
+    def work(i):
+        sm = BASummary(pb, trace=False)
+        for _ in range(steps):
+            ctxs[i].solve_resident(sm)
+            iters[i] += sm.num_iterations
+    th = [threading.Thread(target=work, args=(i,)) for i in range(streams)]
+    t0 = time.perf_counter()
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dt = time.perf_counter() - t0
+    for c in ctxs:
+        c.close()
+    return {"streams": streams, "value": sum(iters) / dt, "unit": "iterations/s (aggregate)", "steps_per_stream": steps}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -216,6 +247,10 @@ def main():
     if rank == 0 and args.gpus == 1 and not args.no_klt:
         klt = bench_klt(ctx, args)
 
+    multi = None
+    if rank == 0 and args.gpus == 1 and not args.no_klt:
+        multi = bench_concurrent_windows(pb_full)
+
     if rank == 0:
         value = iters / elapsed
         out = {
@@ -232,6 +267,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "klt": klt,
+            "concurrent_windows": multi,
         }
         if cpu:
             out["speedup_vs_cpu_baseline"] = value / cpu["value"]
