@@ -261,3 +261,69 @@ def solve_dense(D, fs, rho, max_iterations, state_update=True):
             reuse = True
             rec["cost"] = cand_cost
     return trace, best[0], best[1], term, it
+
+
+def marginalize(pb, O, fs, rho, victim):
+    """Information matrix / vector of the prior left by BundleAdjustor::marginalize_frame (bundle_adjustor.cpp:348-599),
+    restated from the dense Jacobian: stack every factor that touches the victim (old prior, the one or two
+    pre-integration factors, every reprojection factor of a landmark the victim sees; no robust loss, every frame a
+    free 15-dof column block), form J^T J / J^T r and take the Schur complement over {those landmarks, the victim}.
+    Independent of the oracle's hand-indexed block accumulation; only the single-factor evaluators are shared."""
+    L = O.lib()
+    N = pb.n_frames
+    seen = []
+    for l in range(pb.n_landmarks):
+        fr = [pb.lm_anchor_frame[l]] + list(pb.obs_frame[pb.lm_obs_ptr[l]:pb.lm_obs_ptr[l + 1]])
+        if victim in fr and pb.lm_obs_ptr[l + 1] > pb.lm_obs_ptr[l]:
+            seen.append(l)
+    lm_col = {l: 15 * N + k for k, l in enumerate(seen)}
+    ncols = 15 * N + len(seen)
+    rows_r, rows_J = [], []
+    if pb.prior_frames.shape[0] > 0:
+        n = pb.prior_frames.shape[0]
+        st = np.ascontiguousarray(fs[pb.prior_frames])
+        r, J = np.zeros(15 * n), np.zeros((15 * n, 15 * n))
+        L.oracle_eval_prior(n, _d(st), _d(pb.prior_lin_state), _d(pb.prior_S), _d(pb.prior_s), _d(r), _d(J))
+        Jr = np.zeros((15 * n, ncols))
+        for i, f in enumerate(pb.prior_frames):
+            Jr[:, 15 * f:15 * f + 15] += J[:, 15 * i:15 * i + 15]
+        rows_r.append(r), rows_J.append(Jr)
+    if pb.use_inertial:
+        for j in (victim, victim + 1):
+            if j <= 0 or j >= N or not pb.preint_valid[j]:
+                continue
+            i = j - 1
+            r, J = np.zeros(15), np.zeros((15, 30))
+            bias0 = np.ascontiguousarray(fs[i, 10:16])  # the live bias is the linearization bias here (:416-450)
+            L.oracle_eval_preintegration(_d(fs[i]), _d(fs[j]), _d(bias0), _d(pb.preint_delta[j]), _d(pb.preint_sqrt_inv_cov[j]),
+                                         _d(pb.preint_jacobian[j]), _d(pb.imu_extrinsic[i]), _d(pb.imu_extrinsic[j]), _d(r), _d(J))
+            Jr = np.zeros((15, ncols))
+            Jr[:, 15 * i:15 * i + 30] = J
+            rows_r.append(r), rows_J.append(Jr)
+    for l in seen:
+        a = pb.lm_anchor_frame[l]
+        for o in range(pb.lm_obs_ptr[l], pb.lm_obs_ptr[l + 1]):
+            t = pb.obs_frame[o]
+            r, J = np.zeros(2), np.zeros((2, 13))
+            L.oracle_eval_reprojection(_d(fs[t]), _d(fs[a]), float(rho[l]), _d(pb.lm_anchor_z[l]), _d(pb.obs_z[o]),
+                                       _d(pb.cam_extrinsic[a]), _d(pb.cam_extrinsic[t]), _d(pb.sqrt_inv_cov[t]), _d(r), _d(J))
+            Jr = np.zeros((2, ncols))
+            Jr[:, 15 * t:15 * t + 6] += J[:, 0:6]
+            Jr[:, 15 * a:15 * a + 6] += J[:, 6:12]
+            Jr[:, lm_col[l]] += J[:, 12]
+            rows_r.append(r), rows_J.append(Jr)
+    r, J = np.concatenate(rows_r), np.concatenate(rows_J)
+    H, b = J.T @ J, J.T @ r
+    F = 15 * N
+    # landmarks first (diagonal block), then the victim's 15x15 block: the same elimination order as the reference,
+    # which matters numerically when the first-time gauge prior (information ~1e30) sits on the victim
+    Hll = np.diag(H)[F:]
+    ok = np.isfinite(1.0 / Hll)
+    W = H[:F, F:][:, ok]
+    Hf = H[:F, :F] - (W / Hll[ok]) @ W.T
+    bf = b[:F] - (W / Hll[ok]) @ b[F:][ok]
+    v = np.arange(15 * victim, 15 * victim + 15)
+    rest = np.setdiff1d(np.arange(F), v)
+    Hvv_inv = np.linalg.inv(Hf[np.ix_(v, v)])
+    T = Hf[np.ix_(rest, v)] @ Hvv_inv
+    return Hf[np.ix_(rest, rest)] - T @ Hf[np.ix_(v, rest)], bf[rest] - T @ bf[v]

@@ -1,0 +1,75 @@
+"""The committed fixtures of tests/golden/ (full inputs + frozen oracle outputs, see tests/golden_io.py) against
+ - the CPU oracle as built now                      (CPU suite: a change of oracle behaviour shows up here),
+ - the product kernels through the fiber emulator   (CPU suite),
+ - the product kernels through libpvio_hip.so       (-m gpu).
+The fixtures do not pin the oracle to Ceres / OpenCV (neither can be built here): parity stays "unpinned"."""
+import os
+import subprocess
+
+import pytest
+
+import golden_checks as gc
+from pvio_amd import capi
+from pvio_amd.solver import HipContext
+
+EMU_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hipemu")
+
+
+@pytest.fixture(scope="module")
+def emu_ctx():
+    subprocess.check_call(["make", "-s", "-C", EMU_DIR, "libpvio_hipemu.so"])
+    ctx = HipContext(lib=capi.load(os.path.join(EMU_DIR, "libpvio_hipemu.so")), use_graph=True)
+    yield ctx
+    ctx.close()
+
+
+@pytest.fixture(scope="module")
+def gpu_ctx():
+    ctx = HipContext(device=0, use_graph=True)  # raises without the library or a GPU: no fallback
+    yield ctx
+    ctx.close()
+
+
+@pytest.mark.parametrize("name", gc.BA_FIXTURES)
+def test_oracle_reproduces_golden_ba(oracle, name):
+    gc.ba_oracle(oracle, name)
+
+
+@pytest.mark.parametrize("name", gc.MARG_FIXTURES)
+def test_oracle_reproduces_golden_marginalization(oracle, name):
+    gc.marg(oracle, name, rtol=1e-10)
+
+
+def test_oracle_reproduces_golden_front_end(oracle):
+    gc.front_oracle(oracle)
+
+
+@pytest.mark.parametrize("name", gc.BA_FIXTURES)
+def test_emulated_kernels_reproduce_golden_ba(emu_ctx, name):
+    gc.ba_ctx(emu_ctx, name)
+
+
+@pytest.mark.parametrize("name", gc.MARG_FIXTURES)
+def test_emulated_kernels_reproduce_golden_marginalization(emu_ctx, name):
+    gc.marg(emu_ctx, name, rtol=1e-7)
+
+
+def test_emulated_kernels_reproduce_golden_front_end(emu_ctx):
+    gc.front_ctx(emu_ctx)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", gc.BA_FIXTURES)
+def test_gpu_reproduces_golden_ba(gpu_ctx, name):
+    print(name, "worst state difference", gc.ba_ctx(gpu_ctx, name))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", gc.MARG_FIXTURES)
+def test_gpu_reproduces_golden_marginalization(gpu_ctx, name):
+    gc.marg(gpu_ctx, name, rtol=1e-7)
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_golden_front_end(gpu_ctx):
+    gc.front_ctx(gpu_ctx)

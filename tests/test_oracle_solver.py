@@ -102,3 +102,19 @@ def test_metric_config_converges_and_reduces_cost(oracle):
     tr = sm.trace()
     costs = [t["cost"] for t in tr if t["step_is_successful"]]
     assert all(b < a for a, b in zip(costs, costs[1:]))
+
+
+@pytest.mark.parametrize("case,victim", [("vio", 0), ("vio", 1), ("vio", 3), ("vio_partial", 0), ("vio_partial", 2),
+                                         ("vio_partial", 5), ("vio_plane", 0), ("vio_plane", 4)])
+def test_oracle_marginalization_matches_dense_numpy(oracle, case, victim):
+    """marginalize_frame (bundle_adjustor.cpp:348-599): the oracle's block accumulation + two-stage elimination against
+    the Schur complement of a dense J^T J (np_reference.marginalize)."""
+    import marg_compare
+    pb, st = marg_compare.solved_window(oracle, regular_prior=(victim != 0), **CASES[case])
+    S, s, IM, iv = oracle.marginalize(pb, st, victim)
+    IM2, iv2 = np_reference.marginalize(pb, oracle, st.frame_state, st.lm_inv_depth, victim)
+    scale = np.abs(IM).max()
+    np.testing.assert_allclose(IM, IM2, rtol=0, atol=1e-11 * scale)
+    np.testing.assert_allclose(iv, iv2, rtol=0, atol=1e-11 * np.abs(iv).max())
+    # the square-root form reproduces both (eigenvalues <= 1e-8 dropped, :583-590)
+    np.testing.assert_allclose(S.T @ S, IM2, rtol=0, atol=1e-7 * scale)
