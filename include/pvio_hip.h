@@ -65,7 +65,11 @@ typedef struct pvio_hip_opts {
      * (-> HandleInvalidStep; five in a row = FAILURE) */
     int32_t debug_fail_factorizations;
     int32_t debug_invalid_steps;
-    int32_t reserved[2];
+    /* how k_linearize accumulates the landmark Schur complement: 0 = choose by window size (register 3x3 tiles on the
+     * FP64 VALU while every workgroup has a single landmark chunk, 16x16 f64 MFMA tiles once workgroups walk many),
+     * 1 = always the VALU tiles, 2 = always the MFMA tiles */
+    int32_t linearize_mode;
+    int32_t reserved;
 } pvio_hip_opts;
 
 /* ------------------------------------------------------------------------------------------------

@@ -191,7 +191,15 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st) {
     }
     dm.n_chunks = (int)chunk_lm.size() - 1;
     dm.G_lm = std::max(1, std::min(dm.n_chunks, lm_cus));
-    dm.G_back = std::max(1, std::min(64, (M + 15) / 16)); // 16 landmarks per workgroup (16 lanes each); <= 64 partial rows
+    // A workgroup that walks many chunks spends its time in the Schur outer products: those go to the matrix cores then
+    dm.lm_mm = lin_mode_ == 2 || (lin_mode_ == 0 && dm.n_chunks > 2 * dm.G_lm);
+    if (dm.lm_mm) { // contiguous chunk ranges (a range mostly shares one anchor frame): no more workgroups than ranges
+        const int per_wg = (dm.n_chunks + dm.G_lm - 1) / dm.G_lm;
+        dm.G_lm = std::max(1, (dm.n_chunks + per_wg - 1) / per_wg);
+    }
+    // 16 landmarks per workgroup pass (16 lanes each); <= 64 partial rows (one per lane of the wave that sums them) until a
+    // large window needs the whole chip
+    dm.G_back = M <= 4096 ? std::max(1, std::min(64, (M + 15) / 16)) : std::min(cus, (M + 63) / 64);
     dm.fuse_backsub = (world_ == 1 && M <= 256) ? 1 : 0; // beyond one landmark per thread the separate launch is faster
     dm.n_back_rows = (world_ > 1 || dm.fuse_backsub) ? 1 : dm.G_back;
 
@@ -608,8 +616,8 @@ int BASolver::marginalize(const pvio_ba_problem *pb, const pvio_ba_state *st, in
         for (int el = 0; el < 9; ++el) {
             const int r = 15 * fi + 3 * si + el / 3, c = 15 * fj + 3 * sj + el % 3;
             const double val = red[(size_t)el * dm.n_tasks + t];
-            H[(size_t)r * D + c] = val;
-            if (fi != fj) H[(size_t)c * D + r] = val;
+            if (fi != fj) H[(size_t)r * D + c] = H[(size_t)c * D + r] = val;
+            else if (r >= c) H[(size_t)r * D + c] = H[(size_t)c * D + r] = val; // only the lower half of a diagonal block is complete
         }
     }
     for (int f = 0; f < N; ++f)

@@ -37,6 +37,7 @@ class BASolver {
   public:
     BASolver(int device, int rank, int world, bool use_graph);
     void set_fault_injection(int fail_factorizations, int invalid_steps) { dbg_fail_ = fail_factorizations, dbg_invalid_ = invalid_steps; }
+    void set_linearize_mode(int m) { lin_mode_ = m; }
     ~BASolver();
     int upload(const pvio_ba_problem *pb, const pvio_ba_state *st);   // H2D of the flat problem + initial state
     int solve(pvio_ba_summary *sum, pvio_ba_kernel_times *prof = nullptr); // runs from the uploaded initial state
@@ -56,6 +57,7 @@ class BASolver {
 
     int device_, rank_, world_;
     bool use_graph_;
+    int lin_mode_ = 0; // pvio_hip_opts::linearize_mode
     int dbg_fail_ = 0, dbg_invalid_ = 0; // tests only: forced factorization failures / invalid steps per solve
     hipStream_t stream_ = nullptr;
     hipEvent_t ev0_ = nullptr, ev1_ = nullptr;

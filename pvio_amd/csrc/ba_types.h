@@ -87,7 +87,7 @@ struct Dims {
     int32_t fuse_backsub; // landmark back-substitution inside k_dense (small windows, single GPU)
     int32_t use_img;      // k_reduce also assembles the reduced system as a tile image the dense kernel loads straight into registers
     int32_t img_sz;       // doubles in the image (tiles * 256)
-    int32_t pad_;
+    int32_t lm_mm;        // landmark workgroups accumulate the Schur complement as 16x16 f64 MFMA tiles and walk a contiguous chunk range
 };
 
 struct View { // passed by value to every kernel

@@ -111,3 +111,33 @@ def test_emulated_fault_paths_match_oracle(oracle, fault, inertial):
     lib = capi.load(os.path.join(EMU_DIR, "libpvio_hipemu.so"))
     mk = lambda f, i: HipContext(lib=lib, debug_fail_factorizations=f, debug_invalid_steps=i)  # noqa: E731
     _fault_case(mk, oracle, fault["fail"], fault["invalid"], n_frames=4, n_landmarks=30, use_inertial=inertial)
+
+
+# ---- large-window accumulation (linearize_mode = 2): Schur complement on 16x16 f64 MFMA tiles, per-frame direct rows,
+# contiguous chunk ranges with anchor flushes; forced here on windows small enough for the emulator ----
+MM_CASES = {
+    "vio_small": ba_compare.CASES["vio_small"],
+    "vision_partial": ba_compare.CASES["vision_partial"],
+    "vio_plane": ba_compare.CASES["vio_plane"],
+    "vio_10x200_anchor_changes": dict(n_frames=10, n_landmarks=200, use_inertial=True, visibility=5),  # one workgroup, 8 chunks, 6 anchors
+    "vision_16x120_twelve_tiles_per_wave": dict(n_frames=16, n_landmarks=120, visibility=9),
+}
+
+
+@pytest.fixture(scope="module")
+def emu_ctx_mm(emu_ctx):
+    ctx = HipContext(lib=emu_ctx.lib, use_graph=True, linearize_mode=2)
+    yield ctx
+    ctx.close()
+
+
+@pytest.mark.parametrize("name", sorted(MM_CASES))
+def test_emulated_mfma_tile_linearization_matches_oracle(emu_ctx_mm, oracle, name):
+    pb = ba_compare.make(oracle, **MM_CASES[name])
+    ba_compare.check_against_oracle(emu_ctx_mm, oracle, pb)
+
+
+@pytest.mark.parametrize("victim", [0, 2, 5])
+def test_emulated_mfma_tile_marginalization_matches_oracle(emu_ctx_mm, oracle, victim):
+    import marg_compare
+    marg_compare.check_marginalize(emu_ctx_mm, oracle, victim, n_frames=6, n_landmarks=40, use_inertial=True, visibility=4)

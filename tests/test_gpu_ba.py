@@ -106,3 +106,42 @@ def test_gpu_fault_paths_match_oracle(oracle, fail, invalid, case):
     finally:
         L.oracle_debug_fault_injection(C.c_int32(0), C.c_int32(0))
         ctx.close()
+
+
+# ---- large windows: workgroups walk many chunks, the Schur complement accumulates on the matrix cores ----
+LARGE_CASES = {
+    "vio_30x4000_vis12": dict(n_frames=30, n_landmarks=4000, use_inertial=True, visibility=12),   # anchors change inside a workgroup's range
+    "vision_10x20000": dict(n_frames=10, n_landmarks=20000),
+    "vio_plane_20x6000": dict(n_frames=20, n_landmarks=6000, use_inertial=True, plane_fraction=0.2, visibility=10),
+}
+
+
+@pytest.mark.parametrize("name", sorted(LARGE_CASES))
+def test_gpu_large_window_matches_oracle(gpu_ctx, oracle, name):
+    pb = ba_compare.make(oracle, **LARGE_CASES[name])
+    print(name, ba_compare.check_against_oracle(gpu_ctx, oracle, pb))
+
+
+@pytest.mark.parametrize("name", ["metric_10x1000_vio", "vio_plane_10x600"])
+def test_gpu_mfma_tiles_forced_on_small_windows(oracle, name):
+    """linearize_mode = 2: the large-window accumulation on windows that would use the register tiles."""
+    from pvio_amd.solver import HipContext
+    ctx = HipContext(device=0, linearize_mode=2)
+    pb = ba_compare.make(oracle, **ba_compare.BIG_CASES[name])
+    print(name, ba_compare.check_against_oracle(ctx, oracle, pb))
+    ctx.close()
+
+
+def test_gpu_both_linearize_modes_agree_on_a_large_window(oracle):
+    from pvio_amd.solver import HipContext
+    pb = ba_compare.make(oracle, n_frames=24, n_landmarks=8000, use_inertial=True, visibility=9)
+    out = []
+    for mode in (1, 2):
+        ctx = HipContext(device=0, linearize_mode=mode)
+        st, sm = ctx.solve(pb)
+        out.append((st.frame_state.copy(), st.lm_inv_depth.copy(), sm.num_iterations, sm.final_cost))
+        ctx.close()
+    assert out[0][2] == out[1][2]
+    np.testing.assert_allclose(out[0][0], out[1][0], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(out[0][1], out[1][1], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(out[0][3], out[1][3], rtol=1e-9)
