@@ -1297,6 +1297,45 @@ __device__ __forceinline__ void dense_build(const View &v, double *A, const doub
     }
 }
 
+// The same system from the tile image k_reduce assembled (single GPU): the image already holds landmark / plane tiles +
+// IMU blocks + prior, unscaled, in the layout of A, so the build is one coalesced sweep (32 bytes per lane and step)
+// instead of four passes whose read-modify-writes each wait on a global round trip when A lives in HBM.
+__device__ __forceinline__ void dense_build_image(const View &v, double *A, const double *cm, const double *rhs_s, int P, int Pp, int nbk) {
+    const int tid = threadIdx.x;
+    constexpr int nthr = kDenseThreads;
+    const int ntile = (nbk * (nbk + 1)) >> 1;
+    const int ln = tid & 63, lr = ln & 15, lk = ln >> 4;
+    int ti = tid >> 6, bi = 0, bk = ti;
+    while (bk > bi) bk -= bi + 1, ++bi;
+    for (; ti < ntile; ti += nthr / 64) {
+        const double *src = v.img + ((size_t)ti << 8) + 4 * ln;
+        double *dst = A + ((size_t)ti << 8) + 4 * ln;
+        const lds_d2 s01 = *reinterpret_cast<const lds_d2 *>(src), s23 = *reinterpret_cast<const lds_d2 *>(src + 2);
+        const int k = 16 * bk + lr;
+        const double ck = k < P ? cm[k] : 0.0;
+        double o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 16 * bi + lk + 4 * r;
+            const double val = r < 2 ? s01[r & 1] : s23[r & 1];
+            if (i == Pp) o[r] = k < P ? -rhs_s[k] : 0.0;                                   // augmented row: scaled rhs
+            else if (i > Pp || k > i) o[r] = 0.0;
+            else if (i == k) o[r] = (i < P && ck != 0.0) ? -(val * ck * ck) : -1.0;        // unit rows: inactive coordinates, panel padding
+            else {
+                const double sc = (i < P ? cm[i] : 0.0) * ck;
+                o[r] = sc != 0.0 ? -(val * sc) : 0.0;
+            }
+        }
+        lds_d2 w01, w23;
+        w01[0] = o[0], w01[1] = o[1], w23[0] = o[2], w23[1] = o[3];
+        *reinterpret_cast<lds_d2 *>(dst) = w01;
+        *reinterpret_cast<lds_d2 *>(dst + 2) = w23;
+        bk += nthr / 64;
+        while (bk > bi) bk -= bi + 1, ++bi;
+    }
+    __syncthreads();
+}
+
 template <bool LDSMAT> // compile-time storage choice: a runtime LDS-or-global pointer select degrades every access to FLAT
 __global__ void __launch_bounds__(kDenseThreads) k_dense(View v) {
     // 256 threads = one wave per SIMD: the redundant 8 x 8 block factorization then costs each SIMD exactly once
@@ -1631,7 +1670,8 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(View v) {
         for (int e = tid; e < 8 * LDV; e += nthr) Lp[e] = 0.0;
         __syncthreads();
         PV_STAMP(2, 21);
-        dense_build(v, A, cpl, yv, pvalid, pframe, P, Pp, nbk);
+        if (!LDSMAT && v.dm.use_img) dense_build_image(v, A, cpl, yv, P, Pp, nbk);
+        else dense_build(v, A, cpl, yv, pvalid, pframe, P, Pp, nbk);
         PV_STAMP(2, 22);
         // pose quadratic form with the Schur-reduced scaled matrix (mu D^2 not yet added): v^T S v = sum S_ik v_i v_k
         // (thread = one (row, column) of every tile; the vector S v itself is not needed: v^T S y' follows from the solve)

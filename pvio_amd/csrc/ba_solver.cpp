@@ -287,7 +287,7 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st) {
         int lds_matrix = 0;
         dense_lds_bytes(dm, &lds_matrix);
         const size_t img_sz = dense_tile_doubles(dm);
-        v.dm.use_img = (world_ == 1 && lds_matrix) ? 1 : 0;
+        v.dm.use_img = world_ == 1 ? 1 : 0; // (landmark-sharded runs all-reduce `red`, the dense kernel then builds from it)
         v.dm.img_sz = (int)img_sz;
         dm.use_img = v.dm.use_img, dm.img_sz = v.dm.img_sz;
         ok &= dev(pool_, "img", img_sz, &v.img, &grew);
