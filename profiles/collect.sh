@@ -11,6 +11,17 @@ cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $OUT/${TAG}_bench_vio.json 2> $OUT/${TAG}_bench_vio.err
 python $R/bench.py --workload vision > $OUT/${TAG}_bench_vision.json 2> $OUT/${TAG}_bench_vision.err
 (cd $R && python -m pytest tests -m gpu -q 2>&1 | tail -5) > $OUT/${TAG}_pytest_gpu.txt
+# large windows (k_linearize in its matrix-core form): bench lines + kernel stats + HBM counters of the 30 KF x 50k VIO window
+for W in 30x50000_vio 30x50000_vision 10x50000_vio; do
+  python $R/bench.py --workload $W --steps 10 --warmup 2 --no-klt --no-cpu-baseline > $OUT/${TAG}_bench_$W.json 2> $OUT/${TAG}_bench_$W.err
+done
+LARGE="python $R/bench.py --workload 30x50000_vio --steps 4 --warmup 1 --no-klt --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_large_stats -- $LARGE > $OUT/${TAG}_prof_large_stats.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_prof_large_fetch -- $LARGE > $OUT/${TAG}_prof_large_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_prof_large_write -- $LARGE > $OUT/${TAG}_prof_large_write.log 2>&1
+python $R/profiles/summarize_pmc.py $OUT/${TAG}_prof_large_fetch $OUT/${TAG}_prof_large_write $OUT/${TAG}_pmc_hbm_30x50000_vio.json > /dev/null
+find $OUT/${TAG}_prof_large_stats -name '*kernel_stats.csv' -exec cp {} $OUT/${TAG}_kernel_stats_bench_30x50000_vio.csv \;
+rm -rf $OUT/${TAG}_prof_large_fetch/*/*kernel_trace.csv $OUT/${TAG}_prof_large_write/*/*kernel_trace.csv $OUT/${TAG}_prof_large_stats/*/*kernel_trace.csv 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_stats -- python $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline > $OUT/${TAG}_prof_stats.log 2>&1
 # counters in their own passes, kernel trace only (no sys / runtime traces)
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_prof_fetch -- python $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline > $OUT/${TAG}_prof_fetch.log 2>&1

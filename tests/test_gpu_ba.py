@@ -145,3 +145,36 @@ def test_gpu_both_linearize_modes_agree_on_a_large_window(oracle):
     np.testing.assert_allclose(out[0][0], out[1][0], rtol=0, atol=1e-7)
     np.testing.assert_allclose(out[0][1], out[1][1], rtol=0, atol=1e-7)
     np.testing.assert_allclose(out[0][3], out[1][3], rtol=1e-9)
+
+
+def test_gpu_full_size_window_properties(oracle):
+    """BASELINE.json configs[4] (30 KF x 50 000 landmarks, 1.45 M factors, full VIO factor set) at full size, through
+    properties that do not need the oracle's solve: the cost the solver reports for its final state is the cost the
+    oracle's evaluator computes for that state; accepted steps decrease the cost; the two accumulation forms of
+    k_linearize agree; iterating again from the result does not move it (the solve has converged or hit the cap)."""
+    from pvio_amd.solver import HipContext
+    pb = ba_compare.make(oracle, n_frames=30, n_landmarks=50000, use_inertial=True)
+    res = {}
+    for mode in (2, 1):
+        ctx = HipContext(device=0, linearize_mode=mode)
+        st, sm = ctx.solve(pb)
+        res[mode] = (st, sm)
+        ctx.close()
+    st, sm = res[2]
+    assert sm.is_usable == 1 and sm.final_cost < 0.7 * sm.initial_cost
+    costs = [t["cost"] for t in sm.trace() if t["step_is_successful"]]
+    assert all(b < a for a, b in zip(costs, costs[1:]))
+    # the IMU factors read the biases of the user state live (preintegration_error_cost.h:57-58); the accepted candidate was
+    # evaluated while the user state still was the previous iterate
+    tr = sm.trace()
+    k_last = max(k for k, t in enumerate(tr) if t["step_is_successful"])
+    nfs = pb.n_frames * 16
+    user = sm.trace_states[k_last - 1][:nfs].reshape(pb.n_frames, 16)
+    c = oracle.cost(pb, st.frame_state, st.lm_inv_depth, user=user)
+    np.testing.assert_allclose(sm.final_cost, c, rtol=1e-9)
+    np.testing.assert_allclose(oracle.cost(pb, pb.frame_state, pb.lm_inv_depth), sm.initial_cost, rtol=1e-9)
+    st1, sm1 = res[1]
+    assert sm1.num_iterations == sm.num_iterations
+    np.testing.assert_allclose(sm1.final_cost, sm.final_cost, rtol=1e-9)
+    np.testing.assert_allclose(st1.frame_state, st.frame_state, rtol=0, atol=1e-7)
+    np.testing.assert_allclose(st1.lm_inv_depth, st.lm_inv_depth, rtol=0, atol=1e-7)
