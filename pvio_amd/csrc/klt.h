@@ -4,6 +4,8 @@
 
 #include <cstdint>
 #include <string>
+#include <utility>
+#include <vector>
 
 namespace pvklt {
 
@@ -33,6 +35,11 @@ class Klt {
     size_t pts_cap_ = 0;
     void *d_det_ = nullptr; // detection scratch: cov planes, response map, candidates
     size_t det_cap_ = 0;
+    // released pyramid slabs, reused by the next image of the same size: a camera stream allocates once (hipMalloc +
+    // hipFree per frame cost more than the whole pyramid build)
+    std::vector<std::pair<size_t, void *>> slab_pool_;
+    void *staging_ = nullptr; // pinned host buffer for the pixel upload
+    size_t staging_cap_ = 0;
 };
 
 } // namespace pvklt

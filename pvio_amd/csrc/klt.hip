@@ -337,6 +337,8 @@ Klt::Klt(int device) : device_(device) {
 Klt::~Klt() {
     if (d_pts_) (void)hipFree(d_pts_);
     if (d_det_) (void)hipFree(d_det_);
+    for (auto &s : slab_pool_) (void)hipFree(s.second);
+    if (staging_) (void)hipHostFree(staging_);
     if (ev0_) (void)hipEventDestroy(ev0_);
     if (ev1_) (void)hipEventDestroy(ev1_);
     if (stream_) (void)hipStreamDestroy(stream_);
@@ -367,7 +369,13 @@ int Klt::create_image(const uint8_t *pixels, int w, int h, int stride, bool clah
         o_drv[l] = carve((size_t)(hs[l] + 2 * kPad) * im->lv[l].pitch * 4);
     }
     im->slab_bytes = off;
-    if (hipMalloc(&im->slab, off) != hipSuccess) {
+    for (size_t i = 0; i < slab_pool_.size(); ++i)
+        if (slab_pool_[i].first == off) {
+            im->slab = slab_pool_[i].second;
+            slab_pool_.erase(slab_pool_.begin() + i);
+            break;
+        }
+    if (!im->slab && hipMalloc(&im->slab, off) != hipSuccess) {
         delete im;
         err_ = "hipMalloc failed";
         return PVIO_ERR_OUT_OF_MEMORY;
@@ -381,13 +389,19 @@ int Klt::create_image(const uint8_t *pixels, int w, int h, int stride, bool clah
     }
     // derivative borders are BORDER_CONSTANT zeros; image borders are written by k_border
     (void)hipMemsetAsync(im->slab, 0, off, stream_);
-    std::vector<uint8_t> packed;
-    const uint8_t *src = pixels;
-    if (stride != w) {
-        packed.resize((size_t)w * h);
-        for (int y = 0; y < h; ++y) std::memcpy(&packed[(size_t)y * w], pixels + (size_t)y * stride, w);
-        src = packed.data();
+    // pixels go through a pinned staging buffer (packed rows): the copy is a real asynchronous DMA then
+    if ((size_t)w * h > staging_cap_) {
+        if (staging_) (void)hipHostFree(staging_);
+        staging_ = nullptr, staging_cap_ = 0;
+        if (hipHostMalloc(&staging_, (size_t)w * h) != hipSuccess) {
+            release_image(im);
+            err_ = "hipHostMalloc failed";
+            return PVIO_ERR_OUT_OF_MEMORY;
+        }
+        staging_cap_ = (size_t)w * h;
     }
+    for (int y = 0; y < h; ++y) std::memcpy(static_cast<uint8_t *>(staging_) + (size_t)y * w, pixels + (size_t)y * stride, w);
+    const uint8_t *src = static_cast<const uint8_t *>(staging_);
     if (hipMemcpyAsync(im->raw, src, (size_t)w * h, hipMemcpyHostToDevice, stream_) != hipSuccess) {
         release_image(im);
         err_ = "H2D failed";
@@ -424,7 +438,10 @@ int Klt::create_image(const uint8_t *pixels, int w, int h, int stride, bool clah
 
 void Klt::release_image(Image *img) {
     if (!img) return;
-    if (img->slab) (void)hipFree(img->slab);
+    if (img->slab) {
+        if (slab_pool_.size() < 8) slab_pool_.emplace_back(img->slab_bytes, img->slab);
+        else (void)hipFree(img->slab);
+    }
     delete img;
 }
 
