@@ -33,11 +33,13 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/*_pmc_hbm.json: separate
-    FETCH_SIZE / WRITE_SIZE runs of this same command, FETCH_SIZE doubled per the gfx950 correction).  None if absent."""
+def pmc_traffic(kernel, workload="vio"):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/*_pmc_hbm[_<workload>].json:
+    separate FETCH_SIZE / WRITE_SIZE runs of this same command, FETCH_SIZE doubled per the gfx950 correction).  None if
+    there is no pass for this workload (the headline file was collected on the default VIO window)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm.json")))
+    suffix = "" if workload == "vio" else "_" + workload
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm%s.json" % suffix)))
     if not files:
         return None
     try:
@@ -225,7 +227,7 @@ def main():
     achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
     roofline = {
         "bound": "hbm", "kernel": "k_linearize", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("k_linearize"),
+        "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("k_linearize", args.workload),
         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": avg_s * 1e6,
         "kernel_us": {k: (v[0] / max(v[1], 1)) * 1e3 for k, v in prof.items()},
         "note": "working set < 1 MB: L2/Infinity-Cache resident, the iteration is launch/dependency-latency bound",
