@@ -16,6 +16,8 @@ scalars are all-reduced with RCCL once per linearization / back-substitution -> 
 Extra objects on the JSON line:
   roofline      dominant kernel (k_linearize): algorithmic bytes per launch / its average duration, measured here with
                 hipEvents on the solver's own stream (pvio_hip_ba_profile_resident), against the 8 TB/s HBM peak.
+  scaling_window  the 10 KF x 50 000 landmark VIO window (the one north_star states the 8-GPU target on), sharded the
+                same way, a few solves: its iterations/s at this N next to the headline value.
   cpu_baseline  the CPU oracle (oracle/, a single-threaded restatement of the reference's Ceres path; the real
                 reference cannot be built here) timed on the same window on this box's host cores.
 """
@@ -147,6 +149,37 @@ def bench_concurrent_windows(pb, streams=3, steps=60):
     return {"streams": streams, "value": sum(iters) / dt, "unit": "iterations/s (aggregate)", "steps_per_stream": steps}
 
 
+def bench_scaling_window(ctx, args, rank, world, dist, barrier, preintegrate, n_frames=10, n_landmarks=50000, steps=10, warmup=2):
+    """BA iterations/s of the 10 KF x 50 000 landmark VIO window (BASELINE.json north_star: the window the 8-GPU scaling
+    target is stated on), landmark-sharded over the ranks like the headline window.  Every rank builds the same seeded
+    window and keeps its contiguous CSR range; timing = barrier + synchronize on both sides, max over ranks."""
+    import torch
+    from pvio_amd import BASummary, synth
+    pb_full = synth.make_window(n_frames=n_frames, n_landmarks=n_landmarks, use_inertial=True, preintegrate=preintegrate)
+    pb = pb_full.shard(rank, world)
+    ctx.upload(pb)
+    sm = BASummary(pb, trace=False)
+    for _ in range(warmup):
+        ctx.solve_resident(sm)
+    barrier()
+    t0 = time.perf_counter()
+    iters = 0
+    for _ in range(steps):
+        ctx.solve_resident(sm)
+        iters += sm.num_iterations
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    prof = ctx.profile_resident(BASummary(pb, trace=False))
+    return {"workload": "%d KF x %d landmarks, full VIO factor set, %d reprojection factors (%d on this rank)" % (n_frames, n_landmarks, pb_full.n_obs, pb.n_obs),
+            "value": iters / elapsed, "unit": "iterations/s", "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
+            "iterations_per_solve": iters / steps, "final_cost": float(sm.final_cost),
+            "kernel_us_rank0": {k: (v[0] / max(v[1], 1)) * 1e3 for k, v in prof.items()}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -157,6 +190,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline sample budget (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-klt", action="store_true")
+    ap.add_argument("--no-scaling-window", action="store_true", help="skip the 10 KF x 50 000 landmark leg")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -233,6 +267,15 @@ def main():
         "note": "working set < 1 MB: L2/Infinity-Cache resident, the iteration is launch/dependency-latency bound",
     }
 
+    # ---- scaling window: the window north_star's multi-GPU sentence names (10 KF x 50 000 landmarks, full factor set),
+    # sharded exactly like the headline window, same context and communicator; a few solves, barrier-bracketed ----
+    scaling_window = None
+    if not args.no_scaling_window and args.workload in ("vio", "vision"):
+        try:
+            scaling_window = bench_scaling_window(ctx, args, rank, world, dist, barrier, preintegrate)
+        except Exception as e:  # the headline line must still be printed
+            scaling_window = {"error": repr(e)}
+
     cpu = None
     if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
         from oracle import oracle_py as O
@@ -277,6 +320,7 @@ def main():
             "cpu_baseline": cpu,
             "klt": klt,
             "concurrent_windows": multi,
+            "scaling_window": scaling_window,
         }
         if cpu:
             out["speedup_vs_cpu_baseline"] = value / cpu["value"]

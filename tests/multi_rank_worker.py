@@ -16,6 +16,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 def main():
     out_dir = sys.argv[1]
     case = sys.argv[2]
+    linearize_mode = int(sys.argv[3]) if len(sys.argv) > 3 else 0
     dist.init_process_group(backend="gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     import ba_compare
@@ -35,7 +36,7 @@ def main():
     lib.hipemu_set_allreduce(allreduce)
     pb = ba_compare.make(O, **ba_compare.CASES[case])
     shard = pb.shard(rank, world)
-    ctx = HipContext(lib=lib, rank=rank, world_size=world, use_graph=False)
+    ctx = HipContext(lib=lib, rank=rank, world_size=world, use_graph=False, linearize_mode=linearize_mode)
     uid = (C.c_uint8 * 128)()
     assert lib.pvio_hip_comm_unique_id(uid) == 0
     assert lib.pvio_hip_comm_init(ctx.ctx, uid, rank, world) == 0

@@ -29,3 +29,4 @@ def test_emulated_klt_odd_size_no_clahe(emu_ctx, oracle):
 
 def test_emulated_clahe_odd_size(emu_ctx, oracle):
     klt_compare.check_klt(emu_ctx, oracle, 150, 117, 30, clahe=True)
+

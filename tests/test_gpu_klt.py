@@ -22,6 +22,10 @@ def test_gpu_klt_matches_oracle(gpu_ctx, oracle, size):
     print(size, klt_compare.check_klt(gpu_ctx, oracle, *size))
 
 
+def test_gpu_klt_large_batch(gpu_ctx, oracle):
+    print(klt_compare.check_klt(gpu_ctx, oracle, 512, 512, 3000))
+
+
 def test_gpu_klt_no_clahe_and_empty(gpu_ctx, oracle):
     import numpy as np
     from pvio_amd import synth

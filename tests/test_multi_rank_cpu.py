@@ -14,8 +14,9 @@ from pvio_amd import BAState, BASummary
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("case,world", [("vio_partial", 2), ("vio_plane", 2), ("vision_partial", 3)])
-def test_sharded_solve_matches_oracle(oracle, case, world):
+# mode 2 = the matrix-core form of k_linearize (what sharded large windows run: bench.py's scaling_window leg)
+@pytest.mark.parametrize("case,world,mode", [("vio_partial", 2, 0), ("vio_plane", 2, 0), ("vision_partial", 3, 0), ("vio_partial", 2, 2)])
+def test_sharded_solve_matches_oracle(oracle, case, world, mode):
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "hipemu"), "libpvio_hipemu.so"])
     pb = ba_compare.make(oracle, **ba_compare.CASES[case])
     st0, sm0 = BAState(pb), BASummary(pb)
@@ -23,7 +24,7 @@ def test_sharded_solve_matches_oracle(oracle, case, world):
     with tempfile.TemporaryDirectory() as d:
         port = 29500 + (os.getpid() % 2000)
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
-               "--master-port", str(port), os.path.join(ROOT, "tests", "multi_rank_worker.py"), d, case]
+               "--master-port", str(port), os.path.join(ROOT, "tests", "multi_rank_worker.py"), d, case, str(mode)]
         env = dict(os.environ, OMP_NUM_THREADS="1")
         subprocess.run(cmd, check=True, timeout=600, env=env, capture_output=True)
         rho = np.zeros(pb.n_landmarks)
