@@ -54,6 +54,7 @@ typedef enum pvio_termination {
 
 typedef struct pvio_hip_ctx pvio_hip_ctx;
 typedef struct pvio_hip_image pvio_hip_image;
+typedef struct pvio_hip_undistort pvio_hip_undistort;
 
 typedef struct pvio_hip_opts {
     int32_t device;          /* HIP device ordinal */
@@ -224,6 +225,20 @@ int32_t pvio_preintegrate(int32_t n_samples, const double *imu_t, const double *
 int32_t pvio_hip_image_create(pvio_hip_ctx *ctx, const uint8_t *pixels, int32_t width, int32_t height,
                               int32_t stride, int32_t apply_clahe, pvio_hip_image **out);
 void pvio_hip_image_release(pvio_hip_ctx *ctx, pvio_hip_image *img);
+/* Image undistortion in front of the pyramid.  Replaces cv::undistort(img, K, dist) of the EuRoC reader
+ * (pvio-pc/src/euroc_dataset_reader.cpp:72-75) and ImageUndistorter::undistort_image = cv::remap(map_x, map_y, INTER_LINEAR,
+ * BORDER_CONSTANT) of the TUM-VI reader (pvio-extra/include/pvio/extra/image_undistorter.h:44-46, tum_dataset_reader.cpp:81).
+ * The maps are what those calls hold internally (OpenCV's fixed-point pair): map_xy [h][w][2] int16 = integer source
+ * position (x, y), map_frac [h][w] uint16 = (fy << 5) | fx with 5-bit fractions.  The host side builds them once per camera
+ * (pvio_amd/host/undistort_maps.h); they stay resident, every frame is uploaded distorted and remapped on the device. */
+int32_t pvio_hip_undistort_create(pvio_hip_ctx *ctx, const int16_t *map_xy, const uint16_t *map_frac, int32_t width,
+                                  int32_t height, pvio_hip_undistort **out);
+void pvio_hip_undistort_release(pvio_hip_ctx *ctx, pvio_hip_undistort *ud);
+/* pvio_hip_image_create on the undistorted pixels: (width, height, stride) describe the DISTORTED source, the pyramid
+ * has the map's size.  With apply_clahe = 0 level 0 is the remap output itself (pvio_hip_image_download_level). */
+int32_t pvio_hip_image_create_undistorted(pvio_hip_ctx *ctx, const pvio_hip_undistort *ud, const uint8_t *pixels,
+                                          int32_t width, int32_t height, int32_t stride, int32_t apply_clahe,
+                                          pvio_hip_image **out);
 /* copy a pyramid level back (tests): level l image u8 [h_l][w_l] and/or derivatives int16 [h_l][w_l][2] */
 int32_t pvio_hip_image_download_level(pvio_hip_ctx *ctx, const pvio_hip_image *img, int32_t level,
                                       uint8_t *pixels, int16_t *deriv, int32_t *w, int32_t *h);

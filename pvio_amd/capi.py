@@ -84,6 +84,7 @@ EXPORTS = [
     "pvio_hip_comm_unique_id", "pvio_hip_comm_init", "pvio_preintegrate",
     "pvio_hip_image_create", "pvio_hip_image_release", "pvio_hip_image_download_level", "pvio_hip_klt_track", "pvio_hip_image_detect", "pvio_hip_image_download_response",
     "pvio_hip_klt_last_device_ms",
+    "pvio_hip_undistort_create", "pvio_hip_undistort_release", "pvio_hip_image_create_undistorted",
 ]
 
 _lib = None
@@ -132,6 +133,13 @@ def load(path=None):
     lib.pvio_preintegrate.restype = C.c_int32
     lib.pvio_hip_image_create.argtypes = [vp, c_uint8_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]
     lib.pvio_hip_image_create.restype = C.c_int32
+    c_uint16_p = C.POINTER(C.c_uint16)
+    lib.pvio_hip_undistort_create.argtypes = [vp, c_int16_p, c_uint16_p, C.c_int32, C.c_int32, C.POINTER(vp)]
+    lib.pvio_hip_undistort_create.restype = C.c_int32
+    lib.pvio_hip_undistort_release.argtypes = [vp, vp]
+    lib.pvio_hip_undistort_release.restype = None
+    lib.pvio_hip_image_create_undistorted.argtypes = [vp, vp, c_uint8_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]
+    lib.pvio_hip_image_create_undistorted.restype = C.c_int32
     lib.pvio_hip_image_release.argtypes = [vp, vp]
     lib.pvio_hip_image_release.restype = None
     lib.pvio_hip_image_download_level.argtypes = [vp, vp, C.c_int32, c_uint8_p, c_int16_p, c_int32_p, c_int32_p]

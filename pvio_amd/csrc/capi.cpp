@@ -112,6 +112,20 @@ int32_t pvio_hip_image_create(pvio_hip_ctx *ctx, const uint8_t *pixels, int32_t 
     if (!ctx || !pixels || !out) return PVIO_ERR_INVALID_ARGUMENT;
     return ctx->klt->create_image(pixels, width, height, stride, apply_clahe != 0, reinterpret_cast<pvklt::Image **>(out));
 }
+int32_t pvio_hip_undistort_create(pvio_hip_ctx *ctx, const int16_t *map_xy, const uint16_t *map_frac, int32_t width, int32_t height,
+                                  pvio_hip_undistort **out) {
+    if (!ctx || !out) return PVIO_ERR_INVALID_ARGUMENT;
+    return ctx->klt->create_undistort(map_xy, map_frac, width, height, reinterpret_cast<pvklt::Undistort **>(out));
+}
+void pvio_hip_undistort_release(pvio_hip_ctx *ctx, pvio_hip_undistort *ud) {
+    if (ctx && ud) ctx->klt->release_undistort(reinterpret_cast<pvklt::Undistort *>(ud));
+}
+int32_t pvio_hip_image_create_undistorted(pvio_hip_ctx *ctx, const pvio_hip_undistort *ud, const uint8_t *pixels, int32_t width, int32_t height,
+                                          int32_t stride, int32_t apply_clahe, pvio_hip_image **out) {
+    if (!ctx || !ud || !pixels || !out) return PVIO_ERR_INVALID_ARGUMENT;
+    return ctx->klt->create_image(pixels, width, height, stride, apply_clahe != 0, reinterpret_cast<pvklt::Image **>(out),
+                                  reinterpret_cast<const pvklt::Undistort *>(ud));
+}
 void pvio_hip_image_release(pvio_hip_ctx *ctx, pvio_hip_image *img) {
     if (ctx && img) ctx->klt->release_image(reinterpret_cast<pvklt::Image *>(img));
 }

@@ -9,13 +9,17 @@
 
 namespace pvklt {
 
-struct Image; // device pyramid (klt.hip)
+struct Image;     // device pyramid (klt.hip)
+struct Undistort; // device-resident fixed-point remap tables (klt.hip)
 
 class Klt {
   public:
     explicit Klt(int device);
     ~Klt();
-    int create_image(const uint8_t *pixels, int w, int h, int stride, bool clahe, Image **out);
+    // `ud` != nullptr: the pixels are first undistorted on the device (cv::remap semantics), the pyramid has the map's size
+    int create_image(const uint8_t *pixels, int w, int h, int stride, bool clahe, Image **out, const Undistort *ud = nullptr);
+    int create_undistort(const int16_t *map_xy, const uint16_t *map_frac, int w, int h, Undistort **out);
+    void release_undistort(Undistort *u);
     void release_image(Image *img);
     int download_level(const Image *img, int level, uint8_t *pixels, int16_t *deriv, int32_t *w, int32_t *h);
     int track(const Image *prev, const Image *next, int n, const float *prev_xy, float *next_xy, uint8_t *status);
@@ -33,6 +37,8 @@ class Klt {
     std::string err_;
     void *d_pts_ = nullptr;
     size_t pts_cap_ = 0;
+    void *d_src_ = nullptr; // distorted source pixels of the image being built
+    size_t src_cap_ = 0;
     void *d_det_ = nullptr; // detection scratch: cov planes, response map, candidates
     size_t det_cap_ = 0;
     // released pyramid slabs, reused by the next image of the same size: a camera stream allocates once (hipMalloc +

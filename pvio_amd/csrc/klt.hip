@@ -129,6 +129,33 @@ __global__ void k_copy_level0(const uint8_t *src, int w, int h, LevelDesc out) {
     if (x < w && y < h) out.img[(size_t)(y + kPad) * out.pitch + x + kPad] = src[(size_t)y * w + x];
 }
 
+// ---- undistortion: cv::remap(INTER_LINEAR, BORDER_CONSTANT) with fixed-point maps --------------------------------------
+// Replaces cv::undistort (pvio-pc/src/euroc_dataset_reader.cpp:72-75) and ImageUndistorter::undistort_image
+// (pvio-extra/include/pvio/extra/image_undistorter.h:44-46).  Maps are OpenCV's CV_16SC2 + CV_16UC1 pair: integer source
+// position and a 5+5-bit fraction index (INTER_BITS = 5); weights are the INTER_LINEAR table entries at 15 bits
+// ((32-fx)(32-fy)*32, ...; the fraction (0,0) entry is {32767, 0, 0, 1}: saturate_cast<short>(32768) and the +1 that makes the
+// table row sum to 1 << 15 again -- the result is the same pixel), result = (sum + (1 << 14)) >> 15; taps outside the
+// source image are the constant border 0.  Streaming: 5 bytes of map + 1 byte out per pixel, the 2x2 source taps hit in L2.
+struct Undistort {
+    int w, h;          // destination (= map) size
+    int16_t *xy;       // [h][w][2]
+    uint16_t *frac;    // [h][w]
+};
+__global__ void __launch_bounds__(256) k_remap(const uint8_t *src, int sw, int sh, const int16_t *__restrict__ mxy, const uint16_t *__restrict__ mfr,
+                                               int w, int h, uint8_t *__restrict__ dst) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    const size_t i = (size_t)y * w + x;
+    const int sx = mxy[2 * i], sy = mxy[2 * i + 1];
+    const int f = mfr[i] & 1023, fx = f & 31, fy = f >> 5;
+    int w00 = (32 - fx) * (32 - fy) * 32, w01 = fx * (32 - fy) * 32, w10 = (32 - fx) * fy * 32, w11 = fx * fy * 32;
+    if (f == 0) w00 = 32767, w11 = 1;
+    const bool x0 = sx >= 0 && sx < sw, x1 = sx + 1 >= 0 && sx + 1 < sw, y0 = sy >= 0 && sy < sh, y1 = sy + 1 >= 0 && sy + 1 < sh;
+    const int p00 = (x0 && y0) ? src[(size_t)sy * sw + sx] : 0, p01 = (x1 && y0) ? src[(size_t)sy * sw + sx + 1] : 0;
+    const int p10 = (x0 && y1) ? src[(size_t)(sy + 1) * sw + sx] : 0, p11 = (x1 && y1) ? src[(size_t)(sy + 1) * sw + sx + 1] : 0;
+    dst[i] = (uint8_t)((p00 * w00 + p01 * w01 + p10 * w10 + p11 * w11 + (1 << 14)) >> 15);
+}
+
 // BORDER_REFLECT_101 ring of kPad pixels around the interior
 __global__ void k_border(LevelDesc lv) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x - kPad, y = (int)blockIdx.y - kPad;
@@ -407,6 +434,7 @@ Klt::Klt(int device) : device_(device) {
 Klt::~Klt() {
     if (d_pts_) (void)hipFree(d_pts_);
     if (d_det_) (void)hipFree(d_det_);
+    if (d_src_) (void)hipFree(d_src_);
     for (auto &s : slab_pool_) (void)hipFree(s.second);
     if (staging_) (void)hipHostFree(staging_);
     if (ev0_) (void)hipEventDestroy(ev0_);
@@ -414,8 +442,42 @@ Klt::~Klt() {
     if (stream_) (void)hipStreamDestroy(stream_);
 }
 
-int Klt::create_image(const uint8_t *pixels, int w, int h, int stride, bool clahe, Image **out) {
-    if (w < 2 * kWin || h < 2 * kWin || stride < w) {
+int Klt::create_undistort(const int16_t *map_xy, const uint16_t *map_frac, int w, int h, Undistort **out) {
+    if (!map_xy || !map_frac || w < 1 || h < 1) {
+        err_ = "bad undistortion map";
+        return PVIO_ERR_INVALID_ARGUMENT;
+    }
+    (void)hipSetDevice(device_);
+    Undistort *u = new Undistort();
+    u->w = w, u->h = h, u->xy = nullptr, u->frac = nullptr;
+    const size_t n = (size_t)w * h;
+    void *slab = nullptr;
+    if (hipMalloc(&slab, n * 6) != hipSuccess) {
+        delete u;
+        err_ = "hipMalloc failed";
+        return PVIO_ERR_OUT_OF_MEMORY;
+    }
+    u->xy = static_cast<int16_t *>(slab);
+    u->frac = reinterpret_cast<uint16_t *>(static_cast<char *>(slab) + n * 4);
+    if (hipMemcpy(u->xy, map_xy, n * 4, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(u->frac, map_frac, n * 2, hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(slab);
+        delete u;
+        err_ = "H2D failed";
+        return PVIO_ERR_HIP;
+    }
+    *out = u;
+    return PVIO_OK;
+}
+void Klt::release_undistort(Undistort *u) {
+    if (!u) return;
+    if (u->xy) (void)hipFree(u->xy);
+    delete u;
+}
+
+int Klt::create_image(const uint8_t *pixels, int sw, int sh, int stride, bool clahe, Image **out, const Undistort *ud) {
+    // with an undistortion map the pyramid has the MAP's size and the uploaded pixels are only the source of the remap
+    const int w = ud ? ud->w : sw, h = ud ? ud->h : sh;
+    if (w < 2 * kWin || h < 2 * kWin || sw < 1 || sh < 1 || stride < sw) {
         err_ = "image too small / bad stride";
         return PVIO_ERR_INVALID_ARGUMENT;
     }
@@ -460,24 +522,39 @@ int Klt::create_image(const uint8_t *pixels, int w, int h, int stride, bool clah
     // derivative borders are BORDER_CONSTANT zeros; image borders are written by k_border
     (void)hipMemsetAsync(im->slab, 0, off, stream_);
     // pixels go through a pinned staging buffer (packed rows): the copy is a real asynchronous DMA then
-    if ((size_t)w * h > staging_cap_) {
+    if ((size_t)sw * sh > staging_cap_) {
         if (staging_) (void)hipHostFree(staging_);
         staging_ = nullptr, staging_cap_ = 0;
-        if (hipHostMalloc(&staging_, (size_t)w * h) != hipSuccess) {
+        if (hipHostMalloc(&staging_, (size_t)sw * sh) != hipSuccess) {
             release_image(im);
             err_ = "hipHostMalloc failed";
             return PVIO_ERR_OUT_OF_MEMORY;
         }
-        staging_cap_ = (size_t)w * h;
+        staging_cap_ = (size_t)sw * sh;
     }
-    for (int y = 0; y < h; ++y) std::memcpy(static_cast<uint8_t *>(staging_) + (size_t)y * w, pixels + (size_t)y * stride, w);
+    for (int y = 0; y < sh; ++y) std::memcpy(static_cast<uint8_t *>(staging_) + (size_t)y * sw, pixels + (size_t)y * stride, sw);
     const uint8_t *src = static_cast<const uint8_t *>(staging_);
-    if (hipMemcpyAsync(im->raw, src, (size_t)w * h, hipMemcpyHostToDevice, stream_) != hipSuccess) {
+    uint8_t *d_src = im->raw; // distorted pixels land in a scratch buffer, the remap writes im->raw
+    if (ud) {
+        if ((size_t)sw * sh > src_cap_) {
+            if (d_src_) (void)hipFree(d_src_);
+            d_src_ = nullptr, src_cap_ = 0;
+            if (hipMalloc(&d_src_, (size_t)sw * sh) != hipSuccess) {
+                release_image(im);
+                err_ = "hipMalloc failed";
+                return PVIO_ERR_OUT_OF_MEMORY;
+            }
+            src_cap_ = (size_t)sw * sh;
+        }
+        d_src = static_cast<uint8_t *>(d_src_);
+    }
+    if (hipMemcpyAsync(d_src, src, (size_t)sw * sh, hipMemcpyHostToDevice, stream_) != hipSuccess) {
         release_image(im);
         err_ = "H2D failed";
         return PVIO_ERR_HIP;
     }
     const dim3 blk(256);
+    if (ud) hipLaunchKernelGGL(k_remap, dim3((w + 255) / 256, h), blk, 0, stream_, (const uint8_t *)d_src, sw, sh, (const int16_t *)ud->xy, (const uint16_t *)ud->frac, w, h, im->raw);
     if (clahe) {
         const int tiles = 8;
         int ew = w, eh = h;

@@ -78,11 +78,13 @@ class HipImage : public Image {
     void enable_ransac(bool on) { ransac_ = on; } // default on, like the reference; a custom filter takes precedence
     const pvio_hip_image *device_image() const { return img_; }
 
-  private:
+  protected: // UndistortedHipImage (dataset_reader.h) builds the pyramid through another C-ABI entry point
     pvio_hip_ctx *ctx_;
     std::vector<uint8_t> pixels_;
     int w_, h_;
     pvio_hip_image *img_ = nullptr;
+
+  private:
     OutlierFilter filter_;
     bool ransac_ = true;
 };

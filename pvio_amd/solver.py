@@ -96,14 +96,39 @@ class HipContext:
         return S, s, IM, iv
 
 
-class HipImage:
-    """Device-resident CLAHE'd pyramid (pvio_hip_image_create); mirrors OpenCvImage::preprocess."""
+class HipUndistort:
+    """Device-resident fixed-point remap tables (pvio_hip_undistort_create): map_xy int16 [h][w][2], map_frac uint16 [h][w]."""
 
-    def __init__(self, ctx, pixels, clahe=True):
+    def __init__(self, ctx, map_xy, map_frac):
+        self.ctx = ctx
+        xy = np.ascontiguousarray(map_xy, dtype=np.int16)
+        fr = np.ascontiguousarray(map_frac, dtype=np.uint16)
+        self.h, self.w = fr.shape
+        assert xy.shape == (self.h, self.w, 2)
+        self.handle = C.c_void_p()
+        ctx._check(ctx.lib.pvio_hip_undistort_create(ctx.ctx, xy.ctypes.data_as(capi.c_int16_p), fr.ctypes.data_as(C.POINTER(C.c_uint16)),
+                                                     self.w, self.h, C.byref(self.handle)), "pvio_hip_undistort_create")
+
+    def release(self):
+        if self.handle:
+            self.ctx.lib.pvio_hip_undistort_release(self.ctx.ctx, self.handle)
+            self.handle = C.c_void_p()
+
+
+class HipImage:
+    """Device-resident CLAHE'd pyramid (pvio_hip_image_create); mirrors OpenCvImage::preprocess.  With `undistort` the
+    pixels are the distorted camera image and are remapped on the device first (the dataset readers' cv::undistort / remap)."""
+
+    def __init__(self, ctx, pixels, clahe=True, undistort=None):
         self.ctx = ctx
         px = np.ascontiguousarray(pixels, dtype=np.uint8)
         self.h, self.w = px.shape
         self.handle = C.c_void_p()
+        if undistort is not None:
+            ctx._check(ctx.lib.pvio_hip_image_create_undistorted(ctx.ctx, undistort.handle, px.ctypes.data_as(capi.c_uint8_p), self.w, self.h, self.w,
+                                                                 int(clahe), C.byref(self.handle)), "pvio_hip_image_create_undistorted")
+            self.h, self.w = undistort.h, undistort.w
+            return
         ctx._check(ctx.lib.pvio_hip_image_create(ctx.ctx, px.ctypes.data_as(capi.c_uint8_p), self.w, self.h, self.w, int(clahe), C.byref(self.handle)),
                    "pvio_hip_image_create")
 

@@ -340,3 +340,18 @@ def make_image_pair(width=752, height=480, n_points=1500, seed=SEED, max_motion=
     assert np.abs(truth - pts).max() <= max_motion
     init = truth + (rng.uniform(2 * n_points).reshape(n_points, 2) - 0.5) * 4.0
     return img0, img1, pts.astype(np.float32), truth.astype(np.float32), init.astype(np.float32)
+
+
+def make_undistort_maps(width=512, height=512, k1=-0.28, k2=0.07):
+    """Fixed-point remap tables (the layout pvio_hip_undistort_create takes) of a plain radial model around the image centre,
+    for bench.py's ingest timing -- the real camera maps come from pvio_amd/host/undistort_maps.cpp."""
+    f = 0.6 * width
+    v, u = np.meshgrid(np.arange(height, dtype=np.float64), np.arange(width, dtype=np.float64), indexing="ij")
+    x, y = (u - 0.5 * width) / f, (v - 0.5 * height) / f
+    r2 = x * x + y * y
+    kr = 1 + (k2 * r2 + k1) * r2
+    iu = np.rint((f * x * kr + 0.5 * width) * 32).astype(np.int64)
+    iv = np.rint((f * y * kr + 0.5 * height) * 32).astype(np.int64)
+    xy = np.stack([iu >> 5, iv >> 5], axis=-1).astype(np.int16)
+    frac = ((iv & 31) * 32 + (iu & 31)).astype(np.uint16)
+    return xy, frac
