@@ -58,6 +58,7 @@ BASolver::BASolver(int device, int rank, int world, bool use_graph) : device_(de
 BASolver::~BASolver() {
     invalidate_graph();
     if (h_ctrl_) (void)hipHostFree(h_ctrl_);
+    if (h_stage_) (void)hipHostFree(h_stage_);
     if (ev0_) (void)hipEventDestroy(ev0_);
     if (ev1_) (void)hipEventDestroy(ev1_);
     if (stream_) (void)hipStreamDestroy(stream_);
@@ -78,14 +79,23 @@ void BASolver::invalidate_graph() {
     graph_slots_ = 0;
 }
 
-template <typename T>
-static bool up(DevicePool &pool, const char *name, const T *src, size_t n, const T **dst, hipStream_t st, bool *grew) {
-    T *p = static_cast<T *>(pool.get(name, n * sizeof(T), grew));
-    if (!p) return false;
-    if (n && src && hipMemcpyAsync(p, src, n * sizeof(T), hipMemcpyHostToDevice, st) != hipSuccess) return false;
-    *dst = p;
-    return true;
-}
+// Host inputs of one upload: gathered in ONE pinned staging buffer and sent with ONE DMA into one device slab (a window is
+// ~35 small arrays; a pageable hipMemcpyAsync each cost more than the solve's first iterations).  Offsets are 256-byte
+// aligned; an array that is not given (null) keeps its place uninitialized, like the separate allocations it replaces.
+struct StagedUpload {
+    struct Item {
+        const void *src;
+        size_t bytes, off;
+        const void **dst;
+    };
+    std::vector<Item> items; // offsets are assigned when the upload is flushed
+    template <typename T>
+    void add(const T *src, size_t n, const T **dst) {
+        const size_t bytes = n * sizeof(T);
+        items.push_back({(n && src) ? static_cast<const void *>(src) : nullptr, bytes, 0, reinterpret_cast<const void **>(dst)});
+    }
+};
+
 template <typename T>
 static bool dev(DevicePool &pool, const char *name, size_t n, T **dst, bool *grew) {
     T *p = static_cast<T *>(pool.get(name, n * sizeof(T), grew));
@@ -154,9 +164,12 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st) {
         motion_active[i] = (dm.d == 15) && motion_used[i];
     }
 
-    hipDeviceProp_t prop;
-    if (check(hipGetDeviceProperties(&prop, device_), "hipGetDeviceProperties")) return PVIO_ERR_HIP;
-    const int cus = std::max(1, prop.multiProcessorCount);
+    if (cus_ <= 0) { // asked once: the query is slow
+        hipDeviceProp_t prop;
+        if (check(hipGetDeviceProperties(&prop, device_), "hipGetDeviceProperties")) return PVIO_ERR_HIP;
+        cus_ = std::max(1, prop.multiProcessorCount);
+    }
+    const int cus = cus_;
     // ---- landmark chunks: <= lm_slots landmarks and <= 256 factors each (one thread per factor).  A small window is
     // latency-bound per workgroup, so chunks are sized to put one chunk on every CU (256 on MI355X) rather than to fill
     // the LDS; a large window falls back to LDS-filling chunks that each workgroup walks in a grid-stride loop. ----
@@ -215,42 +228,43 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st) {
     v.dm = dm;
     const size_t Ns = N, Ms = std::max(M, 1), Fs = std::max(F, 1);
     bool ok = true;
-    ok &= up(pool_, "frame_fixed", pb->frame_fixed, Ns, &v.frame_fixed, stream_, &grew);
-    ok &= up(pool_, "pose_active", pose_active.data(), Ns, &v.pose_active, stream_, &grew);
-    ok &= up(pool_, "motion_active", motion_active.data(), Ns, &v.motion_active, stream_, &grew);
-    ok &= up(pool_, "cam_ext", pb->cam_extrinsic, Ns * 7, &v.cam_ext, stream_, &grew);
-    ok &= up(pool_, "imu_ext", pb->imu_extrinsic, Ns * 7, &v.imu_ext, stream_, &grew);
-    ok &= up(pool_, "sic", pb->sqrt_inv_cov, Ns * 4, &v.sic, stream_, &grew);
-    ok &= up(pool_, "intr", pb->intrinsics, Ns * 4, &v.intr, stream_, &grew);
-    ok &= up(pool_, "lm_anchor", pb->lm_anchor_frame, (size_t)M, &v.lm_anchor, stream_, &grew);
-    ok &= up(pool_, "lm_ptr", pb->lm_obs_ptr, (size_t)M + 1, &v.lm_ptr, stream_, &grew);
-    ok &= up(pool_, "lm_zref", pb->lm_anchor_z, (size_t)M * 2, &v.lm_zref, stream_, &grew);
-    ok &= up(pool_, "obs_frame", pb->obs_frame, (size_t)F, &v.obs_frame, stream_, &grew);
-    ok &= up(pool_, "obs_z", pb->obs_z, (size_t)F * 2, &v.obs_z, stream_, &grew);
-    ok &= up(pool_, "obs_lm", obs_lm.data(), (size_t)F, &v.obs_lm, stream_, &grew);
-    ok &= up(pool_, "chunk_lm", chunk_lm.data(), chunk_lm.size(), &v.chunk_lm, stream_, &grew);
-    ok &= up(pool_, "task_desc", task_desc.data(), task_desc.size(), &v.task_desc, stream_, &grew);
-    ok &= up(pool_, "pre_valid", pre_valid.data(), Ns, &v.pre_valid, stream_, &grew);
-    ok &= up(pool_, "pre_delta", dm.use_inertial ? pb->preint_delta : nullptr, Ns * 11, &v.pre_delta, stream_, &grew);
-    ok &= up(pool_, "pre_U", dm.use_inertial ? pb->preint_sqrt_inv_cov : nullptr, Ns * 225, &v.pre_U, stream_, &grew);
-    ok &= up(pool_, "pre_jac", dm.use_inertial ? pb->preint_jacobian : nullptr, Ns * 45, &v.pre_jac, stream_, &grew);
+    StagedUpload stage;
+    stage.add(pb->frame_fixed, Ns, &v.frame_fixed);
+    stage.add(pose_active.data(), Ns, &v.pose_active);
+    stage.add(motion_active.data(), Ns, &v.motion_active);
+    stage.add(pb->cam_extrinsic, Ns * 7, &v.cam_ext);
+    stage.add(pb->imu_extrinsic, Ns * 7, &v.imu_ext);
+    stage.add(pb->sqrt_inv_cov, Ns * 4, &v.sic);
+    stage.add(pb->intrinsics, Ns * 4, &v.intr);
+    stage.add(pb->lm_anchor_frame, (size_t)M, &v.lm_anchor);
+    stage.add(pb->lm_obs_ptr, (size_t)M + 1, &v.lm_ptr);
+    stage.add(pb->lm_anchor_z, (size_t)M * 2, &v.lm_zref);
+    stage.add(pb->obs_frame, (size_t)F, &v.obs_frame);
+    stage.add(pb->obs_z, (size_t)F * 2, &v.obs_z);
+    stage.add(obs_lm.data(), (size_t)F, &v.obs_lm);
+    stage.add(chunk_lm.data(), chunk_lm.size(), &v.chunk_lm);
+    stage.add(task_desc.data(), task_desc.size(), &v.task_desc);
+    stage.add(pre_valid.data(), Ns, &v.pre_valid);
+    stage.add(dm.use_inertial ? pb->preint_delta : nullptr, Ns * 11, &v.pre_delta);
+    stage.add(dm.use_inertial ? pb->preint_sqrt_inv_cov : nullptr, Ns * 225, &v.pre_U);
+    stage.add(dm.use_inertial ? pb->preint_jacobian : nullptr, Ns * 45, &v.pre_jac);
     const size_t Dp = 15 * (size_t)dm.prior_n;
-    ok &= up(pool_, "prior_frames", pb->prior_frames, (size_t)dm.prior_n, &v.prior_frames, stream_, &grew);
-    ok &= up(pool_, "prior_S", pb->prior_S, Dp * Dp, &v.prior_S, stream_, &grew);
-    ok &= up(pool_, "prior_s", pb->prior_s, Dp, &v.prior_s, stream_, &grew);
-    ok &= up(pool_, "prior_lin", pb->prior_lin_state, (size_t)dm.prior_n * 16, &v.prior_lin, stream_, &grew);
+    stage.add(pb->prior_frames, (size_t)dm.prior_n, &v.prior_frames);
+    stage.add(pb->prior_S, Dp * Dp, &v.prior_S);
+    stage.add(pb->prior_s, Dp, &v.prior_s);
+    stage.add(pb->prior_lin_state, (size_t)dm.prior_n * 16, &v.prior_lin);
     double *Lambda = nullptr, *eta = nullptr, *ST = nullptr;
     ok &= dev(pool_, "prior_Lambda", Dp * Dp, &Lambda, &grew);
     ok &= dev(pool_, "prior_eta", Dp, &eta, &grew);
     ok &= dev(pool_, "prior_ST", Dp * Dp, &ST, &grew);
     v.prior_Lambda = Lambda, v.prior_eta = eta, v.prior_ST = ST;
     const size_t npo = dm.n_plane ? (size_t)pb->plane_obs_ptr[dm.n_plane] : 0;
-    ok &= up(pool_, "plane_ptr", pb->plane_obs_ptr, (size_t)dm.n_plane + 1, &v.plane_ptr, stream_, &grew);
-    ok &= up(pool_, "plane_frame", pb->plane_obs_frame, npo, &v.plane_frame, stream_, &grew);
-    ok &= up(pool_, "plane_chunk", plane_chunk.data(), plane_chunk.size(), &v.plane_chunk, stream_, &grew);
-    ok &= up(pool_, "plane_z", pb->plane_obs_z, npo * 2, &v.plane_z, stream_, &grew);
-    ok &= up(pool_, "plane_normal", pb->plane_normal, (size_t)dm.n_plane * 3, &v.plane_normal, stream_, &grew);
-    ok &= up(pool_, "plane_dist", pb->plane_distance, (size_t)dm.n_plane, &v.plane_dist, stream_, &grew);
+    stage.add(pb->plane_obs_ptr, (size_t)dm.n_plane + 1, &v.plane_ptr);
+    stage.add(pb->plane_obs_frame, npo, &v.plane_frame);
+    stage.add(plane_chunk.data(), plane_chunk.size(), &v.plane_chunk);
+    stage.add(pb->plane_obs_z, npo * 2, &v.plane_z);
+    stage.add(pb->plane_normal, (size_t)dm.n_plane * 3, &v.plane_normal);
+    stage.add(pb->plane_distance, (size_t)dm.n_plane, &v.plane_dist);
     v.plane_sic = pb->plane_sqrt_inv_cov;
     // state + work
     ok &= dev(pool_, "ctrl", 1, &v.ctrl, &grew);
@@ -310,18 +324,44 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st) {
     // initial state: kept on the host (tiny for frames) and on the device in buffer 0
     h_init_fs_.assign(st->frame_state, st->frame_state + Ns * 16);
     h_init_rho_.assign(st->lm_inv_depth, st->lm_inv_depth + M);
-    double *fs_init = nullptr, *rho_init = nullptr;
-    ok &= dev(pool_, "fs_init", Ns * 16, &fs_init, &grew);
-    ok &= dev(pool_, "rho_init", Ms, &rho_init, &grew);
-    if (!ok) return fail(PVIO_ERR_OUT_OF_MEMORY, "device allocation failed");
-    if (check(hipMemcpyAsync(fs_init, h_init_fs_.data(), Ns * 16 * sizeof(double), hipMemcpyHostToDevice, stream_), "H2D state")) return PVIO_ERR_HIP;
-    if (M && check(hipMemcpyAsync(rho_init, h_init_rho_.data(), (size_t)M * sizeof(double), hipMemcpyHostToDevice, stream_), "H2D state")) return PVIO_ERR_HIP;
+    stage.add(h_init_fs_.data(), Ns * 16, &fs_init_);
+    stage.add(h_init_rho_.data(), (size_t)M, &rho_init_);
+    // ---- one staging pass, one DMA ----
+    {
+        // small arrays ride in the staging buffer (front of the slab); a big one (the observation arrays of a 50 000-landmark
+        // window) is cheaper sent from where it lies than copied twice, and lives behind them
+        constexpr size_t kDirect = 1 << 20;
+        size_t staged = 0, total = 0;
+        for (auto &it : stage.items)
+            if (it.bytes < kDirect) it.off = staged, staged += (std::max<size_t>(it.bytes, 8) + 255) & ~(size_t)255;
+        total = staged;
+        for (auto &it : stage.items)
+            if (it.bytes >= kDirect) it.off = total, total += (it.bytes + 255) & ~(size_t)255;
+        char *slab = static_cast<char *>(pool_.get("inputs", total, &grew));
+        if (!slab) return fail(PVIO_ERR_OUT_OF_MEMORY, "device allocation failed");
+        if (staged > h_stage_cap_) {
+            if (h_stage_) (void)hipHostFree(h_stage_);
+            h_stage_ = nullptr, h_stage_cap_ = 0;
+            const size_t cap = staged + staged / 4;
+            if (hipHostMalloc(&h_stage_, cap) != hipSuccess) return fail(PVIO_ERR_OUT_OF_MEMORY, "hipHostMalloc failed");
+            h_stage_cap_ = cap;
+        }
+        for (const auto &it : stage.items) {
+            if (it.src && it.bytes < kDirect) std::memcpy(static_cast<char *>(h_stage_) + it.off, it.src, it.bytes);
+            *it.dst = slab + it.off;
+        }
+        if (check(hipMemcpyAsync(slab, h_stage_, staged, hipMemcpyHostToDevice, stream_), "H2D inputs")) return PVIO_ERR_HIP;
+        for (const auto &it : stage.items)
+            if (it.src && it.bytes >= kDirect && check(hipMemcpyAsync(slab + it.off, it.src, it.bytes, hipMemcpyHostToDevice, stream_), "H2D inputs"))
+                return PVIO_ERR_HIP;
+    }
     if (dm.prior_n > 0 && check(launch_prior_prep(v.prior_S, v.prior_s, (int)Dp, Lambda, eta, ST, stream_), "k_prior_prep")) return PVIO_ERR_HIP;
 
     const bool dims_changed = std::memcmp(&v.dm, &v_.dm, sizeof(Dims)) != 0;
     if (grew || dims_changed || std::memcmp(&v, &v_, sizeof(View)) != 0) invalidate_graph();
     v_ = v;
     uploaded_ = true;
+    solves_since_upload_ = 0;
     return check(hipStreamSynchronize(stream_), "upload sync");
 }
 
@@ -355,8 +395,12 @@ int BASolver::enqueue_slot(hipEvent_t *ev) {
 }
 
 int BASolver::run_slots(int n_slots) {
-    if (use_graph_ && world_ == 1) {
-        if (!graph_exec_ || graph_slots_ != n_slots) {
+    // A window that has just been uploaded with a new shape is solved with plain launches (they pipeline on the stream: the
+    // state machine is on the device); capturing + instantiating a graph costs more than it saves on a single solve and
+    // is left to the second solve of the same resident window.
+    const bool have_graph = graph_exec_ && graph_slots_ == n_slots;
+    if (use_graph_ && world_ == 1 && (have_graph || solves_since_upload_ > 0)) {
+        if (!have_graph) {
             invalidate_graph();
             if (check(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal), "begin capture")) return PVIO_ERR_HIP;
             int rc = PVIO_OK;
@@ -396,8 +440,7 @@ int BASolver::solve(pvio_ba_summary *sum, pvio_ba_kernel_times *prof) {
         }
     }
     // reset: state buffer 0 <- initial state, user state, control block
-    double *fs_init = static_cast<double *>(pool_.get("fs_init", Ns * 16 * sizeof(double)));
-    double *rho_init = static_cast<double *>(pool_.get("rho_init", Ms * sizeof(double)));
+    const double *fs_init = fs_init_, *rho_init = rho_init_;
     if (check(hipMemcpyAsync(v_.fs, fs_init, Ns * 16 * sizeof(double), hipMemcpyDeviceToDevice, stream_), "reset fs")) return PVIO_ERR_HIP;
     if (check(hipMemcpyAsync(v_.fs_user, fs_init, Ns * 16 * sizeof(double), hipMemcpyDeviceToDevice, stream_), "reset user")) return PVIO_ERR_HIP;
     if (dm.M && check(hipMemcpyAsync(v_.rho, rho_init, (size_t)dm.M * sizeof(double), hipMemcpyDeviceToDevice, stream_), "reset rho")) return PVIO_ERR_HIP;
@@ -454,6 +497,7 @@ int BASolver::solve(pvio_ba_summary *sum, pvio_ba_kernel_times *prof) {
         (void)hipMemcpy(prof->phase_ticks, v_.dbg, 4 * 32 * sizeof(long long), hipMemcpyDeviceToHost);
         v_.dbg = dbg_saved;
     }
+    ++solves_since_upload_;
     if (!h_ctrl_->done) return fail(PVIO_ERR_HIP, "device state machine did not terminate");
     float ms = 0;
     (void)hipEventElapsedTime(&ms, ev0_, ev1_);
@@ -512,8 +556,7 @@ int BASolver::reprojection_error(double *out) {
     if (check(hipMemsetAsync(acc, 0, 2 * sizeof(double), stream_), "memset")) return PVIO_ERR_HIP;
     // evaluates the uploaded initial state (buffer 0 after a reset)
     const size_t Ns = v_.dm.N, Ms = std::max(v_.dm.M, 1);
-    double *fs_init = static_cast<double *>(pool_.get("fs_init", Ns * 16 * sizeof(double)));
-    double *rho_init = static_cast<double *>(pool_.get("rho_init", Ms * sizeof(double)));
+    const double *fs_init = fs_init_, *rho_init = rho_init_;
     if (check(hipMemcpyAsync(v_.fs, fs_init, Ns * 16 * sizeof(double), hipMemcpyDeviceToDevice, stream_), "reset fs")) return PVIO_ERR_HIP;
     if (v_.dm.M && check(hipMemcpyAsync(v_.rho, rho_init, (size_t)v_.dm.M * sizeof(double), hipMemcpyDeviceToDevice, stream_), "reset rho")) return PVIO_ERR_HIP;
     if (check(launch_quality(v_, stream_, 0, acc), "k_quality")) return PVIO_ERR_HIP;
@@ -580,8 +623,7 @@ int BASolver::marginalize(const pvio_ba_problem *pb, const pvio_ba_state *st, in
     if (rc != PVIO_OK) return rc;
     const Dims &dm = v_.dm;
     const size_t Ns = N;
-    double *fs_init = static_cast<double *>(pool_.get("fs_init", Ns * 16 * sizeof(double)));
-    double *rho_init = static_cast<double *>(pool_.get("rho_init", std::max(dm.M, 1) * sizeof(double)));
+    const double *fs_init = fs_init_, *rho_init = rho_init_;
     if (check(hipMemcpyAsync(v_.fs, fs_init, Ns * 16 * sizeof(double), hipMemcpyDeviceToDevice, stream_), "reset fs")) return PVIO_ERR_HIP;
     if (check(hipMemcpyAsync(v_.fs_user, fs_init, Ns * 16 * sizeof(double), hipMemcpyDeviceToDevice, stream_), "reset user")) return PVIO_ERR_HIP;
     if (dm.M && check(hipMemcpyAsync(v_.rho, rho_init, (size_t)dm.M * sizeof(double), hipMemcpyDeviceToDevice, stream_), "reset rho")) return PVIO_ERR_HIP;

@@ -65,6 +65,11 @@ class BASolver {
     View v_{};
     Ctrl *h_ctrl_ = nullptr; // pinned
     bool uploaded_ = false;
+    int solves_since_upload_ = 0;
+    int cus_ = 0;
+    void *h_stage_ = nullptr; // pinned staging of one upload's inputs
+    size_t h_stage_cap_ = 0;
+    const double *fs_init_ = nullptr, *rho_init_ = nullptr; // initial state inside the inputs slab
     int trace_cap_ = 0;
     bool want_trace_states_ = false;
     hipGraph_t graph_ = nullptr;
