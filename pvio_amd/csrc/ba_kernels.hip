@@ -1088,6 +1088,11 @@ __global__ void __launch_bounds__(kRedElems *kRedGroups) k_reduce(View v, int nb
         double r = quarter[0][el];
         for (int q = 1; q < 4; ++q) r = is_max ? fmax(r, quarter[q][el]) : r + quarter[q][el];
         v.red[e] = r;
+        if (is_max && v.dm.world > 1) {
+            // landmark-sharded: the maximum cannot ride in a summing all-reduce, so every rank owns one slot behind the
+            // scalars (zero in the others' slots); after the sum the slots hold every rank's maximum (k_dense takes the max)
+            for (int w = 0; w < v.dm.world; ++w) v.red[total + w] = (w == v.dm.rank) ? r : 0.0;
+        }
         if (v.dm.use_img && e < nS) {
             const int n_tasks = v.dm.n_tasks, ee = (int)e, q = ee / n_tasks, t = ee - q * n_tasks, d = v.dm.d;
             int fi, fj, si, sj;
@@ -1374,7 +1379,15 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(View v) {
         constexpr int nw = (int)(sizeof(Ctrl) / sizeof(double));
         const double *src = reinterpret_cast<const double *>(cg);
         if (tid < nw) reinterpret_cast<double *>(c)[tid] = src[tid];
-        else if (tid < 64 + kNumLinScal && tid >= 64) redS[tid - 64] = v.red[nS + (size_t)kNumPoseVec * P6 + (tid - 64)];
+        else if (tid < 64 + kNumLinScal && tid >= 64) {
+            const size_t base = nS + (size_t)kNumPoseVec * P6;
+            double val = v.red[base + (tid - 64)];
+            if (tid - 64 == 4 && v.dm.world > 1) { // max |b_l|: one slot per rank behind the scalars (see k_reduce); all >= 0
+                val = 0.0;
+                for (int w = 0; w < v.dm.world; ++w) val = fmax(val, v.red[base + kNumLinScal + w]);
+            }
+            redS[tid - 64] = val;
+        }
         else if (tid >= 128 && tid < 128 + N) aux_costs[tid - 128] = (tid - 128 >= 1 && v.dm.G_pre && v.pre_valid[tid - 128]) ? v.pre_cost[tid - 128] : 0.0;
         else if (tid >= 192 && tid < 192 + v.dm.prior_n) aux_costs[N + tid - 192] = v.prior_cost[tid - 192];
     }

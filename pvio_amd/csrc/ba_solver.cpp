@@ -284,7 +284,7 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st) {
     ok &= dev(pool_, "part_S", G * nS, &v.part_S, &grew);
     ok &= dev(pool_, "part_vec", G * nV, &v.part_vec, &grew);
     ok &= dev(pool_, "part_scal", G * kNumLinScal, &v.part_scal, &grew);
-    ok &= dev(pool_, "red", nS + nV + kNumLinScal, &v.red, &grew);
+    ok &= dev(pool_, "red", nS + nV + kNumLinScal + (size_t)world_, &v.red, &grew); // + one max slot per rank
     ok &= dev(pool_, "back_part", (size_t)std::max(dm.G_back, 1) * kNumBackScal, &v.back_part, &grew);
     ok &= dev(pool_, "back_red", kNumBackScal, &v.back_red, &grew);
     ok &= dev(pool_, "pre_H", Ns * 900, &v.pre_H, &grew);
@@ -376,10 +376,9 @@ int BASolver::enqueue_slot(hipEvent_t *ev) {
     if (ev) (void)hipEventRecord(ev[2], stream_);
     if (world_ > 1) {
         const size_t n = (size_t)v_.dm.n_tasks * 9 + (size_t)kNumPoseVec * v_.dm.P6 + kNumLinScal;
-        // scalar 4 (max |b_l|) must not be summed: reduce it separately with max
-        if (comm_allreduce(comm_, v_.red + n - kNumLinScal + 4, 1, 1, stream_)) return fail(PVIO_ERR_COMM, "all-reduce(max) failed");
-        if (comm_allreduce(comm_, v_.red, n - kNumLinScal + 4, 0, stream_)) return fail(PVIO_ERR_COMM, "all-reduce failed");
-        if (comm_allreduce(comm_, v_.red + n - kNumLinScal + 5, 3, 0, stream_)) return fail(PVIO_ERR_COMM, "all-reduce failed");
+        // ONE summing all-reduce per linearization: scalar 4 (max |b_l|) travels as one slot per rank behind the scalars
+        // (k_reduce fills this rank's slot, zeros the others; k_dense takes the maximum), its summed copy is not used
+        if (comm_allreduce(comm_, v_.red, n + (size_t)world_, 0, stream_)) return fail(PVIO_ERR_COMM, "all-reduce failed");
     }
     if (ev) (void)hipEventRecord(ev[3], stream_);
     if ((e = launch_dense(v_, stream_)) != hipSuccess) return check(e, "k_dense");

@@ -18,6 +18,8 @@
 
 #include <cmath>
 #include <cstdio>
+#include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <unordered_map>
@@ -226,7 +228,10 @@ bool BundleAdjustor::solve(Map *map, Config *config, bool use_inertial) {
     if (!ctx) return false;
     DefaultConfig dc;
     Flat F;
+    static const bool timing = std::getenv("PVIO_HIP_TIMING") != nullptr; // diagnostics: host share of a keyframe solve
+    const auto t0 = std::chrono::steady_clock::now();
     flatten(map, config ? config : &dc, use_inertial, false, F);
+    const auto t1 = std::chrono::steady_clock::now();
     std::vector<double> quality(F.lm_track.size(), 0.0);
     std::vector<uint8_t> valid(F.lm_track.size(), 1);
     pvio_ba_state st{F.fstate.data(), F.rho.data(), quality.data(), valid.data()};
@@ -236,6 +241,7 @@ bool BundleAdjustor::solve(Map *map, Config *config, bool use_inertial) {
         std::fprintf(stderr, "[pvio-hip] ba_solve failed: %s\n", pvio_hip_last_error(ctx));
         return false;
     }
+    const auto t2 = std::chrono::steady_clock::now();
     // write the states back in place, like Ceres does through the parameter-block pointers
     for (size_t i = 0; i < map->frame_num(); ++i) {
         Frame *f = map->get_frame(i);
@@ -256,6 +262,12 @@ bool BundleAdjustor::solve(Map *map, Config *config, bool use_inertial) {
         } else {
             t->landmark.quality = quality[l];
         }
+    }
+    if (timing) {
+        const auto t3 = std::chrono::steady_clock::now();
+        auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+        std::fprintf(stderr, "[pvio-hip] solve: %d frames, %d landmarks, %d factors: flatten %.1f us, upload+solve+download %.1f us (device %.1f us, %d iterations), write-back %.1f us\n",
+                     F.pb.n_frames, F.pb.n_landmarks, F.pb.n_obs, us(t0, t1), us(t1, t2), 1e6 * sum.device_seconds, sum.num_iterations, us(t2, t3));
     }
     return sum.is_usable != 0;
 }

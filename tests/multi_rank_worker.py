@@ -44,7 +44,7 @@ def main():
     l0, l1 = shard.meta["lm_range"] if world > 1 else (0, pb.n_landmarks)
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), frame_state=st.frame_state, rho=st.lm_inv_depth, l0=l0, l1=l1,
              iters=sm.num_iterations, term=sm.termination, costs=np.array([t["cost"] for t in sm.trace()]),
-             succ=np.array([t["step_is_successful"] for t in sm.trace()]))
+             succ=np.array([t["step_is_successful"] for t in sm.trace()]), gmax=np.array([t["gradient_max_norm"] for t in sm.trace()]))
     dist.barrier()
     dist.destroy_process_group()
 

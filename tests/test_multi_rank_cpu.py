@@ -33,6 +33,8 @@ def test_sharded_solve_matches_oracle(oracle, case, world, mode):
             assert int(z["iters"]) == sm0.num_iterations and int(z["term"]) == sm0.termination
             assert (z["succ"] == np.array([t["step_is_successful"] for t in sm0.trace()])).all()
             np.testing.assert_allclose(z["costs"], [t["cost"] for t in sm0.trace()], rtol=1e-7)
+            # the landmark part of the gradient maximum crosses the ranks as one slot per rank inside the summing all-reduce
+            np.testing.assert_allclose(z["gmax"], [t["gradient_max_norm"] for t in sm0.trace()], rtol=1e-5, atol=1e-7)
             np.testing.assert_allclose(z["frame_state"], st0.frame_state, rtol=0, atol=1e-6)  # identical on every rank
             rho[int(z["l0"]):int(z["l1"])] = z["rho"]
         np.testing.assert_allclose(rho, st0.lm_inv_depth, rtol=0, atol=1e-6)
