@@ -149,6 +149,9 @@ typedef double lds_d2 __attribute__((ext_vector_type(2)));
 // multiply-accumulate, no operand negation); finished L entries are stored as they are.
 __device__ __forceinline__ int tile_base(int bi, int bk) { return (((bi * (bi + 1)) >> 1) + bk) << 8; }
 __device__ __forceinline__ int tile_off(int r, int c) { return ((((r & 3) << 4) + c) << 2) + (r >> 2); }
+// generic (matrix in HBM) path of k_dense: columns per LDS-resident panel -- 32 when [header | 8 vectors | LDV x 34] fits the
+// 160 KB of LDS, else 16
+__host__ __device__ __forceinline__ int dense_panel_width(int LDV) { return (352 + 8 * LDV + LDV * 34) * 8 <= 160 * 1024 ? 32 : 16; }
 __device__ __forceinline__ int mat_at(int i, int k) { return tile_base(i >> 4, k >> 4) + tile_off(i & 15, k & 15); } // k <= i
 
 // ------------------------------------------------------------------------------------------------------
@@ -1341,6 +1344,72 @@ __device__ __forceinline__ void dense_build_image(const View &v, double *A, cons
     __syncthreads();
 }
 
+// Trailing sweep of the generic (matrix in HBM) factorization: (-C)(16x16) += L_i (16 x W) L_k^T for every tile of the
+// trailing block triangle (tile rows / columns >= b0), W / 4 v_mfma_f64_16x16x4_f64 per tile (operand layout: lane l supplies
+// A[l & 15][l >> 4] and B[l >> 4][l & 15], receives D[(l >> 4) + 4 r][l & 15]).  Tiles are dealt round-robin to the four waves
+// in batches of kBatch; the C tiles of the NEXT batch are requested before the current batch's operands are read from the LDS
+// panel and multiplied (two batches ahead), so a batch costs max(L2 round trip, W / 4 * kBatch MFMAs), not their sum.
+template <int W>
+__device__ __forceinline__ void dense_trailing_sweep(double *A, const double *Pn, int WS, int b0, int nbk, int wv, int lane) {
+    constexpr int kBatch = 4, NM = W / 4;
+    const int lr = lane & 15, lk = lane >> 4;
+    int bi = b0, q = wv;
+    while (bi < nbk && q > bi - b0) q -= bi - b0 + 1, ++bi;
+    struct Batch { // one batch of C tiles on its way from L2
+        double *C[kBatch];
+        int bi[kBatch], bk[kBatch];
+        bool valid[kBatch];
+        lds_d2 c01[kBatch], c23[kBatch];
+    };
+    auto fetch = [&](Batch &B) {
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            B.valid[u] = bi < nbk;
+            B.bi[u] = B.valid[u] ? bi : nbk - 1, B.bk[u] = B.valid[u] ? b0 + q : nbk - 1;
+            B.C[u] = A + tile_base(B.bi[u], B.bk[u]) + 4 * lane;
+            B.c01[u] = *reinterpret_cast<const lds_d2 *>(B.C[u]);
+            B.c23[u] = *reinterpret_cast<const lds_d2 *>(B.C[u] + 2);
+            q += 4;
+            while (bi < nbk && q > bi - b0) q -= bi - b0 + 1, ++bi;
+        }
+    };
+    auto multiply = [&](const Batch &B) {
+        mfma_d4 acc[kBatch];
+        double oa[kBatch][NM], ob[kBatch][NM];
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            const double *pa = Pn + (16 * B.bi[u] + lr) * WS + lk, *pb = Pn + (16 * B.bk[u] + lr) * WS + lk;
+#pragma unroll
+            for (int m = 0; m < NM; ++m) oa[u][m] = pa[4 * m], ob[u][m] = pb[4 * m];
+        }
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) acc[u][0] = B.c01[u][0], acc[u][1] = B.c01[u][1], acc[u][2] = B.c23[u][0], acc[u][3] = B.c23[u][1];
+#pragma unroll
+        for (int m = 0; m < NM; ++m)
+#pragma unroll
+            for (int u = 0; u < kBatch; ++u) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(oa[u][m], ob[u][m], acc[u], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u)
+            if (B.valid[u]) {
+                lds_d2 w0, w1;
+                w0[0] = acc[u][0], w0[1] = acc[u][1], w1[0] = acc[u][2], w1[1] = acc[u][3];
+                *reinterpret_cast<lds_d2 *>(B.C[u]) = w0;
+                *reinterpret_cast<lds_d2 *>(B.C[u] + 2) = w1;
+            }
+    };
+    // two batches ahead: a round trip to L2 is longer than one batch of MFMAs (a wave per SIMD: nobody else hides it)
+    Batch B0, B1, B2;
+    fetch(B0), fetch(B1);
+    for (;;) {
+        if (!B0.valid[0]) break;
+        fetch(B2), multiply(B0);
+        if (!B1.valid[0]) break;
+        fetch(B0), multiply(B1);
+        if (!B2.valid[0]) break;
+        fetch(B1), multiply(B2);
+    }
+}
+
 template <bool LDSMAT> // compile-time storage choice: a runtime LDS-or-global pointer select degrades every access to FLAT
 __global__ void __launch_bounds__(kDenseThreads) k_dense(View v) {
     // 256 threads = one wave per SIMD: the redundant 8 x 8 block factorization then costs each SIMD exactly once
@@ -2008,159 +2077,149 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(View v) {
             }
         }
     } else {
-        // generic path (systems too large for LDS): tiles in HBM, read-modify-written per panel
-        for (int j0 = 0; j0 < Pp; j0 += kPanel) {
-            const int jb = j0 >> 4, o = j0 & 15, k0 = j0 + kPanel;
-            if (j0 == 0) PV_STAMP(2, 8);
-            double Ld[kPanel][kPanel], inv[kPanel];
+        // generic path (systems too large for LDS): tiles in HBM.  The factorization walks panels of W = 32 (16) columns:
+        // a panel is pulled into LDS once, factored there in four (two) steps of 8 columns -- redundant 8 x 8 block
+        // factorization, row owners turn their 8 entries into L, the rest of the PANEL is updated on the VALU -- written
+        // back as finished L, and only then the trailing matrix is swept once with a rank-W update on the matrix cores
+        // (W / 4 MFMAs per tile and read-modify-write).  One workgroup pulls ~70 GB/s from L2: with 8-column panels the
+        // 57 sweeps of a 450-row system were 80 % of this kernel; a sweep per 32 columns moves a quarter of the bytes.
+        const int W = dense_panel_width(LDV), WS = W + 2; // row stride W + 2 doubles: rows of a tile fall on different banks
+        double *Pn = Lp;
+        for (int J0 = 0; J0 < Pp; J0 += W) {
+            const int Wc = Pp - J0 < W ? Pp - J0 : W, jb = J0 >> 4, ntr = nbk - jb, ntc = (Wc + 15) >> 4;
+            if (J0 == 0) PV_STAMP(2, 8);
+            // ---- panel -> LDS, un-negated: a wave takes whole tiles (32 bytes per lane = the four entries rows lk + 4 r,
+            // column lr it would own in an MFMA), four tiles in flight ----
             {
-                const lds_d2 *G = reinterpret_cast<const lds_d2 *>(Dg);
-                double flat[36];
+                const int nt = ntr * ntc;
+                for (int t0 = 4 * wv; t0 < nt; t0 += 16) {
+                    lds_d2 g01[4], g23[4];
     #pragma unroll
-                for (int e = 0; e < 18; ++e) {
-                    const lds_d2 g = G[e];
-                    flat[2 * e] = g[0], flat[2 * e + 1] = g[1];
+                    for (int u = 0; u < 4; ++u) {
+                        const int t = t0 + u < nt ? t0 + u : nt - 1, tr = t / ntc, tc = t - tr * ntc;
+                        const bool have = jb + tc <= jb + tr;
+                        const double *T = A + tile_base(jb + tr, have ? jb + tc : jb) + 4 * lane;
+                        g01[u] = *reinterpret_cast<const lds_d2 *>(T), g23[u] = *reinterpret_cast<const lds_d2 *>(T + 2);
+                        if (!have) g01[u][0] = 0.0, g01[u][1] = 0.0, g23[u][0] = 0.0, g23[u][1] = 0.0; // tile above the diagonal
+                    }
+    #pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int t = t0 + u;
+                        if (t < nt) {
+                            const int tr = t / ntc, tc = t - tr * ntc, col = 16 * tc + lr;
+                            if (col < Wc) {
+                                double *dst = Pn + (16 * (jb + tr) + lk) * WS + col;
+                                dst[0] = -g01[u][0], dst[4 * WS] = -g01[u][1], dst[8 * WS] = -g23[u][0], dst[12 * WS] = -g23[u][1];
+                            }
+                        }
+                    }
                 }
+            }
+            __syncthreads();
+            if (J0 == 0) PV_STAMP(2, 9);
+            for (int s8 = 0; s8 < Wc; s8 += kPanel) {
+                const int j0 = J0 + s8;
+                double Ld[kPanel][kPanel], inv[kPanel];
     #pragma unroll
                 for (int r = 0; r < kPanel; ++r)
     #pragma unroll
-                    for (int cc = 0; cc <= r; ++cc) Ld[r][cc] = flat[((r * (r + 1)) >> 1) + cc];
-            }
-            // the owner's row: issue the loads before the factorization chain (LDV <= 256 whenever the matrix is in LDS;
-            // larger systems loop over the remaining rows below).  Unfactored entries are stored negated.
-            const int irow = j0 + tid;
-            double x[kPanel];
-            double *Trow = A + tile_base(irow >> 4, jb) + tile_off(irow & 15, o);
-            if (irow < LDV) {
-    #pragma unroll
-                for (int cc = 0; cc < kPanel; ++cc) x[cc] = -Trow[4 * cc];
-            }
-            // right-looking: after pivot cc the remaining block entries are updated at once (short dependent chain)
-    #pragma unroll
-            for (int cc = 0; cc < kPanel; ++cc) {
-                const double dd = Ld[cc][cc];
-                fail |= (!(dd > 0.0) || !isfinite(dd)) ? 1 : 0;
-                inv[cc] = fast_rsqrt(dd);
-    #pragma unroll
-                for (int r = cc + 1; r < kPanel; ++r) Ld[r][cc] *= inv[cc];
-    #pragma unroll
-                for (int r = cc + 1; r < kPanel; ++r)
-    #pragma unroll
-                    for (int c2 = cc + 1; c2 <= r; ++c2) Ld[r][c2] -= Ld[r][cc] * Ld[c2][cc];
-            }
-            if (j0 == 0) PV_STAMP(2, 9);
-            if (fail) break; // uniform: every thread factored the same block
-            if (tid < kPanel) {
-                double iv = inv[0];
-    #pragma unroll
-                for (int cc = 1; cc < kPanel; ++cc) iv = (tid == cc) ? inv[cc] : iv;
-                tmp[j0 + tid] = iv; // 1 / L_jj for the back substitution
-            }
-            if (irow < LDV) {
+                    for (int cc = 0; cc <= r; ++cc) Ld[r][cc] = Pn[(j0 + r) * WS + s8 + cc]; // broadcast reads
     #pragma unroll
                 for (int cc = 0; cc < kPanel; ++cc) {
-                    x[cc] = (j0 + cc <= irow) ? x[cc] * inv[cc] : 0.0; // the panel's own rows: strictly upper entries are not L
+                    const double dd = Ld[cc][cc];
+                    fail |= (!(dd > 0.0) || !isfinite(dd)) ? 1 : 0;
+                    inv[cc] = fast_rsqrt(dd);
     #pragma unroll
-                    for (int c2 = cc + 1; c2 < kPanel; ++c2) x[c2] -= x[cc] * Ld[c2][cc];
+                    for (int r = cc + 1; r < kPanel; ++r) Ld[r][cc] *= inv[cc];
+    #pragma unroll
+                    for (int r = cc + 1; r < kPanel; ++r)
+    #pragma unroll
+                        for (int c2 = cc + 1; c2 <= r; ++c2) Ld[r][c2] -= Ld[r][cc] * Ld[c2][cc];
                 }
-                lds_d2 *Lrow = reinterpret_cast<lds_d2 *>(Lp + 8 * irow);
+                if (fail) break; // uniform: every thread factored the same block
+                __syncthreads(); // everybody has read the block before its owners overwrite it
+                if (tid < kPanel) {
+                    double iv = inv[0];
     #pragma unroll
-                for (int h = 0; h < 4; ++h) {
-                    lds_d2 pr;
-                    pr[0] = x[h], pr[1] = x[h + 4]; // operand pair (k, k + 4) of the two MFMAs
-                    Lrow[h] = pr;
+                    for (int cc = 1; cc < kPanel; ++cc) iv = (tid == cc) ? inv[cc] : iv;
+                    tmp[j0 + tid] = iv; // 1 / L_jj for the back substitution
                 }
-                // rows below the panel can be written now; the panel's own rows are still being read by their owners'
-                // neighbours (the diagonal tile), so they go back only after the barrier
-                if (irow >= k0) {
+                for (int ir = j0 + tid; ir < LDV; ir += nthr) { // row owners: 8 entries -> L (strictly upper entries of the block are not L)
+                    lds_d2 *rowp = reinterpret_cast<lds_d2 *>(Pn + ir * WS + s8);
+                    double x[kPanel];
     #pragma unroll
-                    for (int cc = 0; cc < kPanel; ++cc) Trow[4 * cc] = x[cc];
-                }
-            }
-            if (!LDSMAT) {
-                // systems too large for LDS (more rows than threads): the remaining row owners
-                for (int ir = irow + nthr; ir < LDV; ir += nthr) {
-                    double *T = A + tile_base(ir >> 4, jb) + tile_off(ir & 15, o);
-                    double xx[kPanel];
-    #pragma unroll
-                    for (int cc = 0; cc < kPanel; ++cc) xx[cc] = -T[4 * cc];
+                    for (int h = 0; h < 4; ++h) {
+                        const lds_d2 g = rowp[h];
+                        x[2 * h] = g[0], x[2 * h + 1] = g[1];
+                    }
     #pragma unroll
                     for (int cc = 0; cc < kPanel; ++cc) {
-                        xx[cc] *= inv[cc];
+                        x[cc] = (j0 + cc <= ir) ? x[cc] * inv[cc] : 0.0;
     #pragma unroll
-                        for (int c2 = cc + 1; c2 < kPanel; ++c2) xx[c2] -= xx[cc] * Ld[c2][cc];
+                        for (int c2 = cc + 1; c2 < kPanel; ++c2) x[c2] -= x[cc] * Ld[c2][cc];
                     }
     #pragma unroll
-                    for (int cc = 0; cc < kPanel; ++cc) Lp[8 * ir + 2 * (cc & 3) + (cc >> 2)] = xx[cc], T[4 * cc] = xx[cc];
+                    for (int h = 0; h < 4; ++h) {
+                        lds_d2 g;
+                        g[0] = x[2 * h], g[1] = x[2 * h + 1];
+                        rowp[h] = g;
+                    }
+                }
+                __syncthreads();
+                // the rest of the panel: column J0 + c of row ir loses L(ir, j0..j0+7) . L(J0 + c, j0..j0+7); the second factor is
+                // a row of the panel's own square (finished entries, broadcast reads)
+                const int c_lo = s8 + kPanel;
+                if (c_lo < Wc) {
+                    for (int ir = j0 + kPanel + tid; ir < LDV; ir += nthr) {
+                        double *rowp = Pn + ir * WS;
+                        double x[kPanel];
+    #pragma unroll
+                        for (int h = 0; h < 4; ++h) {
+                            const lds_d2 g = *reinterpret_cast<const lds_d2 *>(rowp + s8 + 2 * h);
+                            x[2 * h] = g[0], x[2 * h + 1] = g[1];
+                        }
+                        for (int c = c_lo; c < Wc; c += 2) { // two columns per step (16-byte accesses)
+                            const double *l0 = Pn + (J0 + c) * WS + s8, *l1 = l0 + WS;
+                            lds_d2 acc = *reinterpret_cast<const lds_d2 *>(rowp + c);
+    #pragma unroll
+                            for (int h = 0; h < 4; ++h) {
+                                const lds_d2 a0 = *reinterpret_cast<const lds_d2 *>(l0 + 2 * h), a1 = *reinterpret_cast<const lds_d2 *>(l1 + 2 * h);
+                                acc[0] -= x[2 * h] * a0[0] + x[2 * h + 1] * a0[1];
+                                acc[1] -= x[2 * h] * a1[0] + x[2 * h + 1] * a1[1];
+                            }
+                            *reinterpret_cast<lds_d2 *>(rowp + c) = acc;
+                        }
+                    }
+                    __syncthreads();
                 }
             }
-            __syncthreads();
-            if (j0 == 0) PV_STAMP(2, 10);
-            if (irow < k0) {
-    #pragma unroll
-                for (int cc = 0; cc < kPanel; ++cc)
-                    if (j0 + cc <= irow) Trow[4 * cc] = x[cc];
-            }
-            // rank-8 update of the trailing tiles: (-C)(16x16) += Lp_i (16 x 8) Lp_k^T, two v_mfma_f64_16x16x4_f64 per tile.
-            // Operand layout (cdna_hip_programming.md section 3, f64): lane l supplies A[l & 15][l >> 4] and B[l >> 4][l & 15];
-            // it receives D[(l >> 4) + 4 r][l & 15], r = 0..3 = the four consecutive doubles it owns in the tile.  Everything
-            // is loaded unconditionally (padding rows are zero, columns left of k0 hold finished L entries and are simply not
-            // stored back).  Tiles of the trailing block triangle are dealt round-robin to the four waves in batches of
-            // kBatch: all loads of a batch are in flight before its first MFMA.
+            if (fail) break;
+            if (J0 == 0) PV_STAMP(2, 10);
+            // ---- finished L of the panel -> HBM (the back substitution reads it there); same tile ownership as the load ----
             {
-                constexpr int kBatch = 4;
-                const int b0 = k0 >> 4;
-                const int o2 = k0 & 15; // the next diagonal block sits at (o2, o2) of tile (b0, b0) = the first tile of wave 0
-                int bi = b0, q = wv;
-                bool first = wv == 0;
-                while (bi < nbk && q > bi - b0) q -= bi - b0 + 1, ++bi;
-                while (bi < nbk) {
-                    double *C[kBatch];
-                    lds_d2 av[kBatch], pv[kBatch], c01[kBatch], c23[kBatch];
-                    bool st[kBatch];
-    #pragma unroll
-                    for (int u = 0; u < kBatch; ++u) {
-                        const bool valid = bi < nbk;
-                        const int bic = valid ? bi : nbk - 1, bkc = valid ? b0 + q : nbk - 1;
-                        C[u] = A + tile_base(bic, bkc) + 4 * lane;
-                        av[u] = *reinterpret_cast<const lds_d2 *>(Lp + 8 * (16 * bic + lr) + 2 * lk);
-                        pv[u] = *reinterpret_cast<const lds_d2 *>(Lp + 8 * (16 * bkc + lr) + 2 * lk);
-                        c01[u] = *reinterpret_cast<const lds_d2 *>(C[u]);
-                        c23[u] = *reinterpret_cast<const lds_d2 *>(C[u] + 2);
-                        st[u] = valid && (16 * bkc + lr >= k0);
-                        q += 4;
-                        while (bi < nbk && q > bi - b0) q -= bi - b0 + 1, ++bi;
-                    }
-                    mfma_d4 acc[kBatch];
-    #pragma unroll
-                    for (int u = 0; u < kBatch; ++u) {
-                        acc[u][0] = c01[u][0], acc[u][1] = c01[u][1], acc[u][2] = c23[u][0], acc[u][3] = c23[u][1];
-                        acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][0], pv[u][0], acc[u], 0, 0, 0);
-                    }
-    #pragma unroll
-                    for (int u = 0; u < kBatch; ++u) acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][1], pv[u][1], acc[u], 0, 0, 0);
-    #pragma unroll
-                    for (int u = 0; u < kBatch; ++u)
-                        if (st[u]) {
-                            lds_d2 w0, w1;
-                            w0[0] = acc[u][0], w0[1] = acc[u][1], w1[0] = acc[u][2], w1[1] = acc[u][3];
-                            *reinterpret_cast<lds_d2 *>(C[u]) = w0;
-                            *reinterpret_cast<lds_d2 *>(C[u] + 2) = w1;
-                        }
-                    if (first) { // hand the next diagonal block over, packed and un-negated
-                        first = false;
-                        const int cD = lr - o2;
-    #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int rD = lk + 4 * r - o2;
-                            if (rD >= 0 && rD < kPanel && cD >= 0 && cD <= rD) Dg[((rD * (rD + 1)) >> 1) + cD] = -acc[0][r];
-                        }
-                    }
+                const int nt = ntr * ntc;
+                for (int t = wv; t < nt; t += 4) {
+                    const int tr = t / ntc, tc = t - tr * ntc, col = 16 * tc + lr;
+                    if (tc > tr || col >= Wc) continue; // above the diagonal / right of a narrow last panel
+                    const double *src = Pn + (16 * (jb + tr) + lk) * WS + col;
+                    const int row = 16 * (jb + tr) + lk, ca = J0 + col;
+                    lds_d2 w0, w1;
+                    w0[0] = ca <= row ? src[0] : 0.0, w0[1] = ca <= row + 4 ? src[4 * WS] : 0.0;
+                    w1[0] = ca <= row + 8 ? src[8 * WS] : 0.0, w1[1] = ca <= row + 12 ? src[12 * WS] : 0.0;
+                    double *T = A + tile_base(jb + tr, jb + tc) + 4 * lane;
+                    *reinterpret_cast<lds_d2 *>(T) = w0, *reinterpret_cast<lds_d2 *>(T + 2) = w1;
                 }
             }
-            if (j0 == 0) PV_STAMP(2, 11);
-            __syncthreads();
-            if (j0 == 0) PV_STAMP(2, 12);
+            // ---- rank-W update of the trailing matrix on the matrix cores (nothing behind the last panel; every panel before
+            // the last one is W wide and ends on a tile boundary) ----
+            if (J0 + Wc < Pp) {
+                __syncthreads(); // (the write-back above read the panel; the sweep only reads it too, but keeps the waves together)
+                if (W == 32) dense_trailing_sweep<32>(A, Pn, WS, (J0 + Wc) >> 4, nbk, wv, lane);
+                else dense_trailing_sweep<16>(A, Pn, WS, (J0 + Wc) >> 4, nbk, wv, lane);
+            }
+            if (J0 == 0) PV_STAMP(2, 11);
+            __syncthreads(); // the panel buffer is free again, the trailing tiles are in place (same-workgroup visibility)
+            if (J0 == 0) PV_STAMP(2, 12);
         }
         PV_STAMP(2, 5);
         // ---------------- back substitution L^T y = z, 8 columns per step ----------------
@@ -2588,18 +2647,24 @@ size_t dense_lds_bytes(const Dims &dm, int *lds_matrix) {
     const size_t lfull = 8 * (npan * LDV - 4 * npan * (npan - 1)); // finished panels of L (overlays the tile image)
     const size_t mat = std::max(dense_tile_doubles(dm), lfull) * sizeof(double);
     *lds_matrix = (mat + vec <= 160 * 1024 && LDV <= 176) ? 1 : 0;
-    return *lds_matrix ? mat + vec : vec;
+    if (*lds_matrix) return mat + vec;
+    return (352 + 8 * LDV + LDV * (size_t)(dense_panel_width((int)LDV) + 2)) * sizeof(double); // header, 8 vectors, LDS panel
 }
 
 hipError_t launch_dense(const View &v, hipStream_t st) {
     int lm;
     const size_t lds = dense_lds_bytes(v.dm, &lm);
 #ifndef PV_HIPEMU
-    static size_t configured = 0;
+    static size_t configured = 0, configured_g = 0;
     if (lm && lds > configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dense<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         configured = lds;
+    }
+    if (!lm && lds > configured_g) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dense<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        configured_g = lds;
     }
 #endif
     if (lm) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_dense<true>), dim3(1), dim3(kDenseThreads), lds, st, v);

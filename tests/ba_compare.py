@@ -18,6 +18,10 @@ CASES = {
     "config1_10x200": dict(n_frames=10, n_landmarks=200),
     "vio_11_frames_lds_limit": dict(n_frames=11, n_landmarks=80, use_inertial=True, visibility=6),   # reduced system 165: largest that stays in LDS
     "vio_13_frames_global_matrix": dict(n_frames=13, n_landmarks=80, use_inertial=True, visibility=6),  # 195: matrix in HBM
+    # matrix in HBM, factored in LDS-resident panels: 300 rows = nine 32-column panels + one of 16; 480 rows = 16-column panels
+    # (a 32-column panel of 496 rows does not fit the LDS); the 13-frame window above ends in an 8-column panel
+    "vio_20_frames_panels": dict(n_frames=20, n_landmarks=120, use_inertial=True, visibility=7),
+    "vio_32_frames_narrow_panels": dict(n_frames=32, n_landmarks=160, use_inertial=True, visibility=8),
 }
 BIG_CASES = {
     # the configuration the metric is quoted on (10 KF x 1000 landmarks), vision-only and full VIO

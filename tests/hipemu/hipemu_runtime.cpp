@@ -28,6 +28,7 @@ std::vector<Fiber> fibers;
 std::vector<WaveState> waves;
 ucontext_t sched_ctx;
 int n_threads = 0, bar_arrived = 0, bar_generation = 0, n_done = 0;
+long g_sync_events = 0; // completed barriers + wave exchanges (progress for the deadlock detector)
 long launch_counter = 0;
 int g_order = [] { const char *e = std::getenv("HIPEMU_ORDER"); return !e ? 0 : (e[0] == 'r' ? 1 : (e[0] == 'i' ? 2 : 0)); }();
 std::function<void()> *cur_body = nullptr;
@@ -55,6 +56,7 @@ void syncthreads() {
     if (++bar_arrived == n_threads) {
         bar_arrived = 0;
         ++bar_generation;
+        ++g_sync_events;
     } else {
         while (bar_generation == gen) yield();
     }
@@ -72,6 +74,7 @@ void wave_exchange(const void *in, void *out_all, size_t elem) {
         w.arrived = 0;
         w.readers = n_in_wave;
         ++w.generation;
+        ++g_sync_events;
     } else {
         while (w.generation == gen) yield();
     }
@@ -121,7 +124,7 @@ void launch(dim3 grid, dim3 block, size_t shmem, Stream *s, std::function<void()
                         makecontext(&f.ctx, trampoline, 0);
                     }
                     int remaining = nt;
-                    long spins = 0;
+                    long spins = 0, seen_events = g_sync_events;
                     while (remaining > 0) {
                         int progressed = 0;
                         for (int tt = 0; tt < nt; ++tt) {
@@ -138,6 +141,9 @@ void launch(dim3 grid, dim3 block, size_t shmem, Stream *s, std::function<void()
                                 ++progressed;
                             }
                         }
+                        // a completed barrier / wave exchange is progress too: a long kernel may pass tens of thousands of them
+                        // before its first thread retires
+                        if (g_sync_events != seen_events) seen_events = g_sync_events, spins = 0;
                         if (!progressed && ++spins > 20000) {
                             std::fprintf(stderr, "hipemu: kernel %s (%d threads) block (%u,%u,%u) deadlocked: bar_arrived=%d n_done=%d (divergent barrier / shuffle?)\n", g_kernel_name, nt, bx, by, bz, bar_arrived, n_done);
                             for (size_t w = 0; w < waves.size(); ++w) std::fprintf(stderr, "  wave %zu: arrived=%d alive=%d readers=%d\n", w, waves[w].arrived, waves[w].alive, waves[w].readers);
