@@ -22,12 +22,16 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_pro
 python $R/profiles/summarize_pmc.py $OUT/${TAG}_prof_large_fetch $OUT/${TAG}_prof_large_write $OUT/${TAG}_pmc_hbm_30x50000_vio.json > /dev/null
 find $OUT/${TAG}_prof_large_stats -name '*kernel_stats.csv' -exec cp {} $OUT/${TAG}_kernel_stats_bench_30x50000_vio.csv \;
 rm -rf $OUT/${TAG}_prof_large_fetch/*/*kernel_trace.csv $OUT/${TAG}_prof_large_write/*/*kernel_trace.csv $OUT/${TAG}_prof_large_stats/*/*kernel_trace.csv 2>/dev/null
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_stats -- python $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline > $OUT/${TAG}_prof_stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_stats -- python $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-scaling-window > $OUT/${TAG}_prof_stats.log 2>&1
 # counters in their own passes, kernel trace only (no sys / runtime traces)
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_prof_fetch -- python $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline > $OUT/${TAG}_prof_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_prof_write -- python $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline > $OUT/${TAG}_prof_write.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_prof_fetch -- python $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-scaling-window > $OUT/${TAG}_prof_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_prof_write -- python $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-scaling-window > $OUT/${TAG}_prof_write.log 2>&1
 python $R/profiles/summarize_pmc.py $OUT/${TAG}_prof_fetch $OUT/${TAG}_prof_write $OUT/${TAG}_pmc_hbm.json > /dev/null
 find $OUT/${TAG}_prof_stats -name '*kernel_stats.csv' -exec cp {} $OUT/${TAG}_kernel_stats_bench_vio.csv \;
+# complete keyframe solves (upload + solve + download), LK launch time against the batch size, dense kernel of large windows
+(cd $R && python tests/prof_upload.py) > $OUT/${TAG}_prof_upload.txt 2>&1
+(cd $R && python tests/prof_klt.py) > $OUT/${TAG}_prof_klt.txt 2>&1
+(cd $R && python tests/prof_dense_large.py) > $OUT/${TAG}_prof_dense_large.txt 2>&1
 # the raw traces are large: keep the summaries only
 rm -rf $OUT/${TAG}_prof_fetch/*/*kernel_trace.csv $OUT/${TAG}_prof_write/*/*kernel_trace.csv 2>/dev/null
 ls -la $OUT | head -40

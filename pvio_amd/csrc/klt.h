@@ -37,6 +37,7 @@ class Klt {
     std::string err_;
     void *d_pts_ = nullptr;
     size_t pts_cap_ = 0;
+    void *h_pts_ = nullptr; // pinned mirror of d_pts_
     void *d_src_ = nullptr; // distorted source pixels of the image being built
     size_t src_cap_ = 0;
     void *d_det_ = nullptr; // detection scratch: cov planes, response map, candidates

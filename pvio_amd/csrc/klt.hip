@@ -435,6 +435,7 @@ Klt::~Klt() {
     if (d_pts_) (void)hipFree(d_pts_);
     if (d_det_) (void)hipFree(d_det_);
     if (d_src_) (void)hipFree(d_src_);
+    if (h_pts_) (void)hipHostFree(h_pts_);
     for (auto &s : slab_pool_) (void)hipFree(s.second);
     if (staging_) (void)hipHostFree(staging_);
     if (ev0_) (void)hipEventDestroy(ev0_);
@@ -631,6 +632,12 @@ int Klt::track(const Image *prev, const Image *next, int n, const float *prev_xy
             return PVIO_ERR_OUT_OF_MEMORY;
         }
         pts_cap_ = need * 2;
+        if (h_pts_) (void)hipHostFree(h_pts_);
+        h_pts_ = nullptr;
+        if (hipHostMalloc(&h_pts_, pts_cap_) != hipSuccess) {
+            err_ = "hipHostMalloc failed";
+            return PVIO_ERR_OUT_OF_MEMORY;
+        }
     }
     float *d_prev = static_cast<float *>(d_pts_), *d_next = d_prev + 2 * (size_t)n;
     uint8_t *d_st = reinterpret_cast<uint8_t *>(d_next + 2 * (size_t)n);
@@ -638,18 +645,21 @@ int Klt::track(const Image *prev, const Image *next, int n, const float *prev_xy
     a.n = n, a.n_levels = std::min(prev->n_levels, next->n_levels);
     for (int l = 0; l < a.n_levels; ++l) a.prev[l] = prev->lv[l], a.next[l] = next->lv[l];
     a.prev_xy = d_prev, a.next_xy = d_next, a.status = d_st;
-    bool ok = hipMemcpyAsync(d_prev, prev_xy, (size_t)n * 8, hipMemcpyHostToDevice, stream_) == hipSuccess;
-    ok = ok && hipMemcpyAsync(d_next, next_xy, (size_t)n * 8, hipMemcpyHostToDevice, stream_) == hipSuccess;
+    // one DMA in ([previous | initial next] points), one out ([next points | status bytes]) through a pinned buffer laid out
+    // like the device one: four pageable copies cost more than the kernel
+    char *hp = static_cast<char *>(h_pts_);
+    std::memcpy(hp, prev_xy, (size_t)n * 8), std::memcpy(hp + (size_t)n * 8, next_xy, (size_t)n * 8);
+    bool ok = hipMemcpyAsync(d_prev, hp, (size_t)n * 16, hipMemcpyHostToDevice, stream_) == hipSuccess;
     (void)hipEventRecord(ev0_, stream_);
     hipLaunchKernelGGL(k_lk_track, dim3((n + 3) / 4), dim3(256), 0, stream_, a);
     (void)hipEventRecord(ev1_, stream_);
-    ok = ok && hipMemcpyAsync(next_xy, d_next, (size_t)n * 8, hipMemcpyDeviceToHost, stream_) == hipSuccess;
-    ok = ok && hipMemcpyAsync(status, d_st, (size_t)n, hipMemcpyDeviceToHost, stream_) == hipSuccess;
+    ok = ok && hipMemcpyAsync(hp + (size_t)n * 8, d_next, (size_t)n * 9, hipMemcpyDeviceToHost, stream_) == hipSuccess;
     ok = ok && hipStreamSynchronize(stream_) == hipSuccess && hipGetLastError() == hipSuccess;
     if (!ok) {
         err_ = "klt track failed";
         return PVIO_ERR_HIP;
     }
+    std::memcpy(next_xy, hp + (size_t)n * 8, (size_t)n * 8), std::memcpy(status, hp + (size_t)n * 16, (size_t)n);
     float ms = 0;
     (void)hipEventElapsedTime(&ms, ev0_, ev1_);
     last_ms_ = ms;
