@@ -229,6 +229,8 @@ __device__ __forceinline__ float wave_sum_f(float v) {
 // Lane l < 63 owns 7 consecutive pixels of one row of the 21 x 21 window (row l / 3, columns 7 (l % 3) ..): the bilinear
 // taps of neighbouring pixels overlap, so a lane fetches 2 x 8 bytes per iteration instead of 7 x 4, and its share of the
 // template (intensity + both derivatives, 14-bit fixed point like OpenCV) stays in registers -- no LDS in the loop.
+// A bilinear sample is two v_dot2c_i32_i16 on (tap, right neighbour) x (left weight, right weight) pairs (measured: 1024
+// tracks 22.4 -> 20.8 us, 6000 tracks 63.6 -> 58.9 us against four 24-bit multiplies and three adds).
 // The lane's 8 taps of a row are 8 consecutive bytes at an arbitrary address, its 8 derivative pairs 32 consecutive bytes
 // at a 4-byte aligned one: one 8-byte and two 16-byte loads instead of 8 + 16 scalar ones (gfx950 global loads need no
 // natural alignment).
@@ -236,22 +238,44 @@ typedef uint64_t lk_u64_any __attribute__((aligned(1)));
 struct __attribute__((aligned(4))) lk_i16x8 {
     int16_t v[8];
 };
-__device__ __forceinline__ void lk_unpack_taps(uint64_t w, int *r) {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) r[k] = (int)((w >> (8 * k)) & 255u);
-}
-__device__ __forceinline__ void lk_load_taps(const uint8_t *s, int *r) { lk_unpack_taps(*reinterpret_cast<const lk_u64_any *>(s), r); }
 struct lk_drv_raw {
     lk_i16x8 lo, hi;
 };
+// a.lo * b.lo + a.hi * b.hi + c on signed 16-bit halves: v_dot2c_i32_i16.  The bilinear sample of OpenCV's fixed-point LK,
+// (p00 w00 + p01 w01 + p10 w10 + p11 w11 + round) >> shift, is two of these on (pixel, right neighbour) pairs and
+// (left weight, right weight) pairs -- exact integer arithmetic (pixels <= 255 or int16 derivatives, weights <= 2^14).
+__device__ __forceinline__ int lk_dot2(int a, int b, int c) {
+#ifdef PV_HIPEMU
+    return (int)(int16_t)(a & 0xffff) * (int)(int16_t)(b & 0xffff) + (a >> 16) * (b >> 16) + c;
+#else
+    typedef short lk_s2 __attribute__((ext_vector_type(2)));
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(lk_s2, a), __builtin_bit_cast(lk_s2, b), c, false);
+#endif
+}
+// (tap k, tap k + 1) pairs of one row of 8 taps, k = 0..6
+__device__ __forceinline__ void lk_tap_pairs(uint64_t w, int *pr) {
+#pragma unroll
+    for (int k = 0; k < 7; ++k) pr[k] = (int)(((w >> (8 * k)) & 255u) | (((w >> (8 * k + 8)) & 255u) << 16));
+}
+__device__ __forceinline__ void lk_load_tap_pairs(const uint8_t *s, int *pr) { lk_tap_pairs(*reinterpret_cast<const lk_u64_any *>(s), pr); }
+// derivative rows come as (x, y) int16 pairs per pixel: (x_k, x_k+1) and (y_k, y_k+1) pairs, k = 0..6
+__device__ __forceinline__ void lk_deriv_pairs(const lk_drv_raw &r, int *px, int *py) {
+    int d[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        d[k] = (int)((uint32_t)(uint16_t)r.lo.v[2 * k] | ((uint32_t)(uint16_t)r.lo.v[2 * k + 1] << 16));
+        d[4 + k] = (int)((uint32_t)(uint16_t)r.hi.v[2 * k] | ((uint32_t)(uint16_t)r.hi.v[2 * k + 1] << 16));
+    }
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        px[k] = (int)(((uint32_t)d[k] & 0xffffu) | ((uint32_t)d[k + 1] << 16));
+        py[k] = (int)(((uint32_t)d[k] >> 16) | ((uint32_t)d[k + 1] & 0xffff0000u));
+    }
+}
 __device__ __forceinline__ lk_drv_raw lk_load_derivs_raw(const int16_t *d) {
     lk_drv_raw r;
     r.lo = *reinterpret_cast<const lk_i16x8 *>(d), r.hi = *reinterpret_cast<const lk_i16x8 *>(d + 8);
     return r;
-}
-__device__ __forceinline__ void lk_unpack_derivs(const lk_drv_raw &r, int *x, int *y) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) x[k] = r.lo.v[2 * k], y[k] = r.lo.v[2 * k + 1], x[4 + k] = r.hi.v[2 * k], y[4 + k] = r.hi.v[2 * k + 1];
 }
 
 constexpr int kRun = 7; // pixels per lane; kWin = 3 * kRun
@@ -285,10 +309,10 @@ __device__ __forceinline__ int lk_template_load(const LevelDesc &I, int level, f
     t.d0 = lk_load_derivs_raw(d0), t.d1 = lk_load_derivs_raw(d1);
     return 0;
 }
-// Template of the level in packed form (intensities are 13-bit: pixel << 5; derivatives fit int16) + the gradient matrix.
+// Template of the level (this lane's 7 pixels: intensity << 5, both derivatives) + the gradient matrix.
 // Returns 1 when the level is skipped (degenerate gradient matrix).
 struct LkTpl {
-    int xy[kRun], ip[(kRun + 1) / 2];
+    int ti[kRun], tx[kRun], ty[kRun];
     float A11, A12, A22, Dinv;
 };
 __device__ __forceinline__ int lk_template_form(const LkTplRaw &t, bool live, LkTpl &T) {
@@ -297,21 +321,17 @@ __device__ __forceinline__ int lk_template_form(const LkTplRaw &t, bool live, Lk
 #endif
     const float FLT_SCALE = 1.f / (1 << 20);
     constexpr int W_BITS = LK_W_BITS;
-    const int iw00 = t.w00, iw01 = t.w01, iw10 = t.w10, iw11 = t.w11;
-    int q0[kRun + 1], q1[kRun + 1], x0[kRun + 1], x1[kRun + 1], y0[kRun + 1], y1[kRun + 1];
-    lk_unpack_taps(t.i0, q0), lk_unpack_taps(t.i1, q1);
-    lk_unpack_derivs(t.d0, x0, y0), lk_unpack_derivs(t.d1, x1, y1);
+    const int wA = t.w00 | (t.w01 << 16), wB = t.w10 | (t.w11 << 16); // (left, right) weight pairs of the two rows
+    int q0[kRun], q1[kRun], x0[kRun], x1[kRun], y0[kRun], y1[kRun];
+    lk_tap_pairs(t.i0, q0), lk_tap_pairs(t.i1, q1);
+    lk_deriv_pairs(t.d0, x0, y0), lk_deriv_pairs(t.d1, x1, y1);
     float sA11 = 0, sA12 = 0, sA22 = 0;
 #pragma unroll
-    for (int k = 0; k < (kRun + 1) / 2; ++k) T.ip[k] = 0;
-#pragma unroll
     for (int k = 0; k < kRun; ++k) {
-        const int ti = (__mul24(q0[k], iw00) + __mul24(q0[k + 1], iw01) + __mul24(q1[k], iw10) + __mul24(q1[k + 1], iw11) + (1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
-        const int tx = (__mul24(x0[k], iw00) + __mul24(x0[k + 1], iw01) + __mul24(x1[k], iw10) + __mul24(x1[k + 1], iw11) + (1 << (W_BITS - 1))) >> W_BITS;
-        const int ty = (__mul24(y0[k], iw00) + __mul24(y0[k + 1], iw01) + __mul24(y1[k], iw10) + __mul24(y1[k + 1], iw11) + (1 << (W_BITS - 1))) >> W_BITS;
-        T.ip[k >> 1] |= ti << (16 * (k & 1));
-        T.xy[k] = (tx & 0xffff) | (int)((unsigned)ty << 16);
-        if (live) sA11 += (float)(tx * tx), sA12 += (float)(tx * ty), sA22 += (float)(ty * ty);
+        T.ti[k] = lk_dot2(q1[k], wB, lk_dot2(q0[k], wA, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
+        T.tx[k] = lk_dot2(x1[k], wB, lk_dot2(x0[k], wA, 1 << (W_BITS - 1))) >> W_BITS;
+        T.ty[k] = lk_dot2(y1[k], wB, lk_dot2(y0[k], wA, 1 << (W_BITS - 1))) >> W_BITS;
+        if (live) sA11 += (float)(T.tx[k] * T.tx[k]), sA12 += (float)(T.tx[k] * T.ty[k]), sA22 += (float)(T.ty[k] * T.ty[k]);
     }
     const float a11 = wave_sum_f(sA11) * FLT_SCALE, a12 = wave_sum_f(sA12) * FLT_SCALE, a22 = wave_sum_f(sA22) * FLT_SCALE;
     const float D = a11 * a22 - a12 * a12;
@@ -341,7 +361,7 @@ __global__ void __launch_bounds__(256) k_lk_track(TrackArgs a) {
     float outx = a.next_xy[2 * p], outy = a.next_xy[2 * p + 1];
     int st = 1;
     LkTpl T;
-    int r0[kRun + 1], r1[kRun + 1], cinx, ciny; // the lane's taps of the search window, kept while its integer origin stays
+    int r0[kRun], r1[kRun], cinx, ciny; // the lane's (tap, right neighbour) pairs of the search window, kept while its integer origin stays
 #pragma unroll
     for (int li = 0; li < kLevels; ++li) {
         const int level = kLevels - 1 - li;
@@ -377,15 +397,15 @@ __global__ void __launch_bounds__(256) k_lk_track(TrackArgs a) {
             const int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
             if (inx != cinx || iny != ciny) { // uniform: the window only moves to other pixels every few iterations
                 const uint8_t *s0 = J.img + (size_t)(iny + wy + kPad) * J.pitch + (inx + wx + kPad), *s1 = s0 + J.pitch;
-                lk_load_taps(s0, r0), lk_load_taps(s1, r1);
+                lk_load_tap_pairs(s0, r0), lk_load_tap_pairs(s1, r1);
                 cinx = inx, ciny = iny;
             }
+            const int wA = iw00 | (iw01 << 16), wB = iw10 | (iw11 << 16);
             float sb1 = 0, sb2 = 0;
 #pragma unroll
             for (int k = 0; k < kRun; ++k) {
-                const int ti = (Tl.ip[k >> 1] >> (16 * (k & 1))) & 0xffff, tx = (int)(int16_t)Tl.xy[k], ty = Tl.xy[k] >> 16;
-                const int diff = ((__mul24(r0[k], iw00) + __mul24(r0[k + 1], iw01) + __mul24(r1[k], iw10) + __mul24(r1[k + 1], iw11) + (1 << (W_BITS - 5 - 1))) >> (W_BITS - 5)) - ti;
-                sb1 += (float)__mul24(diff, tx), sb2 += (float)__mul24(diff, ty);
+                const int diff = (lk_dot2(r1[k], wB, lk_dot2(r0[k], wA, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5)) - Tl.ti[k];
+                sb1 += (float)__mul24(diff, Tl.tx[k]), sb2 += (float)__mul24(diff, Tl.ty[k]);
             }
             if (!live) sb1 = 0.f, sb2 = 0.f;
             const float b1 = wave_sum_f(sb1) * FLT_SCALE, b2 = wave_sum_f(sb2) * FLT_SCALE;
