@@ -1177,9 +1177,10 @@ __device__ __forceinline__ void backsub_landmarks(const View &v, int lin, double
 #define PV_KEEP(x) asm volatile("" : "+v"(x)) // the value is needed HERE: keeps its load unconditional and where it was written
 #endif
 // flags[j] = IMU factor j is present, pframe[q] = frame of prior slot q (both in LDS)
+template <int NT> // threads of the workgroup
 __device__ __forceinline__ void dense_build(const View &v, double *A, const double *cm, const double *rhs_s, const int *flags, const int *pframe, int P, int Pp, int nbk) {
     const int tid = threadIdx.x, N = v.dm.N, d = v.dm.d, n_tasks = v.dm.n_tasks;
-    constexpr int nthr = kDenseThreads;
+    constexpr int nthr = NT;
     // (one wave per SIMD: the VALU instruction count of these passes is what they cost, so index arithmetic is hoisted)
     { // pass 0: zero fill, 16 bytes per store (the tile image is contiguous)
         const int nd2 = (nbk * (nbk + 1)) << 6; // tiles * 256 / 2
@@ -1308,9 +1309,10 @@ __device__ __forceinline__ void dense_build(const View &v, double *A, const doub
 // The same system from the tile image k_reduce assembled (single GPU): the image already holds landmark / plane tiles +
 // IMU blocks + prior, unscaled, in the layout of A, so the build is one coalesced sweep (32 bytes per lane and step)
 // instead of four passes whose read-modify-writes each wait on a global round trip when A lives in HBM.
+template <int NT>
 __device__ __forceinline__ void dense_build_image(const View &v, double *A, const double *cm, const double *rhs_s, int P, int Pp, int nbk) {
     const int tid = threadIdx.x;
-    constexpr int nthr = kDenseThreads;
+    constexpr int nthr = NT;
     const int ntile = (nbk * (nbk + 1)) >> 1;
     const int ln = tid & 63, lr = ln & 15, lk = ln >> 4;
     int ti = tid >> 6, bi = 0, bk = ti;
@@ -1349,7 +1351,7 @@ __device__ __forceinline__ void dense_build_image(const View &v, double *A, cons
 // A[l & 15][l >> 4] and B[l >> 4][l & 15], receives D[(l >> 4) + 4 r][l & 15]).  Tiles are dealt round-robin to the four waves
 // in batches of kBatch; the C tiles of the NEXT batch are requested before the current batch's operands are read from the LDS
 // panel and multiplied (two batches ahead), so a batch costs max(L2 round trip, W / 4 * kBatch MFMAs), not their sum.
-template <int W>
+template <int W, int NWV>
 __device__ __forceinline__ void dense_trailing_sweep(double *A, const double *Pn, int WS, int b0, int nbk, int wv, int lane) {
     constexpr int kBatch = 4, NM = W / 4;
     const int lr = lane & 15, lk = lane >> 4;
@@ -1369,7 +1371,7 @@ __device__ __forceinline__ void dense_trailing_sweep(double *A, const double *Pn
             B.C[u] = A + tile_base(B.bi[u], B.bk[u]) + 4 * lane;
             B.c01[u] = *reinterpret_cast<const lds_d2 *>(B.C[u]);
             B.c23[u] = *reinterpret_cast<const lds_d2 *>(B.C[u] + 2);
-            q += 4;
+            q += NWV;
             while (bi < nbk && q > bi - b0) q -= bi - b0 + 1, ++bi;
         }
     };
@@ -1410,13 +1412,16 @@ __device__ __forceinline__ void dense_trailing_sweep(double *A, const double *Pn
     }
 }
 
-template <bool LDSMAT> // compile-time storage choice: a runtime LDS-or-global pointer select degrades every access to FLAT
-__global__ void __launch_bounds__(kDenseThreads) k_dense(View v) {
+// compile-time storage choice: a runtime LDS-or-global pointer select degrades every access to FLAT.  The register-resident
+// form runs one wave per SIMD (its tiles live in the accumulators of exactly four waves); the HBM form runs two: its sweeps
+// and passes over the matrix wait on L2 round trips that a second wave fills.
+template <bool LDSMAT>
+__global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_dense(View v) {
     // 256 threads = one wave per SIMD: the redundant 8 x 8 block factorization then costs each SIMD exactly once
     HIP_DYNAMIC_SHARED(double, lds)
     Ctrl *const cg = v.ctrl;
     const int N = v.dm.N, d = v.dm.d, P = v.dm.P, P6 = v.dm.P6, tid = threadIdx.x;
-    constexpr int nthr = kDenseThreads;
+    constexpr int nthr = LDSMAT ? kDenseThreads : 2 * kDenseThreads, NW = nthr / 64;
     const size_t nS = (size_t)v.dm.n_tasks * 9;
     const double *redV = v.red + nS;
     // dynamic LDS: [header 352][8 vectors of LDV][Lp: panel, LDV x 8][A: tiles]   (no static LDS: keeps the dynamic base
@@ -1752,15 +1757,15 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(View v) {
         for (int e = tid; e < 8 * LDV; e += nthr) Lp[e] = 0.0;
         __syncthreads();
         PV_STAMP(2, 21);
-        if (!LDSMAT && v.dm.use_img) dense_build_image(v, A, cpl, yv, P, Pp, nbk);
-        else dense_build(v, A, cpl, yv, pvalid, pframe, P, Pp, nbk);
+        if (!LDSMAT && v.dm.use_img) dense_build_image<nthr>(v, A, cpl, yv, P, Pp, nbk);
+        else dense_build<nthr>(v, A, cpl, yv, pvalid, pframe, P, Pp, nbk);
         PV_STAMP(2, 22);
         // pose quadratic form with the Schur-reduced scaled matrix (mu D^2 not yet added): v^T S v = sum S_ik v_i v_k
         // (thread = one (row, column) of every tile; the vector S v itself is not needed: v^T S y' follows from the solve)
         {
-            const int r = tid >> 4, cc = tid & 15, off = tile_off(r, cc);
+            const int r = (tid & 255) >> 4, cc = tid & 15, off = tile_off(r, cc);
             double q = 0;
-            for (int bi = 0; bi < nbk; ++bi) {
+            for (int bi = tid >> 8; bi < nbk; bi += nthr / 256) { // 256 threads cover a tile; a second half takes every other tile row
                 const int i = 16 * bi + r;
                 const double vi = vv[i];
                 double qr = 0;
@@ -2092,7 +2097,7 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(View v) {
             // column lr it would own in an MFMA), four tiles in flight ----
             {
                 const int nt = ntr * ntc;
-                for (int t0 = 4 * wv; t0 < nt; t0 += 16) {
+                for (int t0 = 4 * wv; t0 < nt; t0 += 4 * NW) {
                     lds_d2 g01[4], g23[4];
     #pragma unroll
                     for (int u = 0; u < 4; ++u) {
@@ -2198,7 +2203,7 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(View v) {
             // ---- finished L of the panel -> HBM (the back substitution reads it there); same tile ownership as the load ----
             {
                 const int nt = ntr * ntc;
-                for (int t = wv; t < nt; t += 4) {
+                for (int t = wv; t < nt; t += NW) {
                     const int tr = t / ntc, tc = t - tr * ntc, col = 16 * tc + lr;
                     if (tc > tr || col >= Wc) continue; // above the diagonal / right of a narrow last panel
                     const double *src = Pn + (16 * (jb + tr) + lk) * WS + col;
@@ -2214,8 +2219,8 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(View v) {
             // the last one is W wide and ends on a tile boundary) ----
             if (J0 + Wc < Pp) {
                 __syncthreads(); // (the write-back above read the panel; the sweep only reads it too, but keeps the waves together)
-                if (W == 32) dense_trailing_sweep<32>(A, Pn, WS, (J0 + Wc) >> 4, nbk, wv, lane);
-                else dense_trailing_sweep<16>(A, Pn, WS, (J0 + Wc) >> 4, nbk, wv, lane);
+                if (W == 32) dense_trailing_sweep<32, NW>(A, Pn, WS, (J0 + Wc) >> 4, nbk, wv, lane);
+                else dense_trailing_sweep<16, NW>(A, Pn, WS, (J0 + Wc) >> 4, nbk, wv, lane);
             }
             if (J0 == 0) PV_STAMP(2, 11);
             __syncthreads(); // the panel buffer is free again, the trailing tiles are in place (same-workgroup visibility)
@@ -2256,16 +2261,23 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(View v) {
             if (tid == 0) c->pose_qyy = s1[0]; // y^T (S + mu D^2) y = |z|^2 ; the mu term is removed below
             __syncthreads();
             // every thread forms y_b = L_bb^-T z_b redundantly (broadcast loads), then the rows above the block are updated
-            // in parallel.  One barrier per block.
-            for (int p = npan - 1; p >= 0; --p) {
-                const int jb0 = p * kPanel, o = jb0 & 15;
-                double lrow[kPanel]; // L(jb0 + cc, a) for this thread's row a (independent of y: issued first)
-                const int a = tid;
-                if (LDSMAT && a < jb0) {
-                    const double *T = A + tile_base(jb0 >> 4, a >> 4);
+            // in parallel (one row per thread: LDV <= 496 < 512 threads).  The L entries a step needs do not depend on y:
+            // those of the NEXT step are requested before this step's barrier, so a step does not wait for a round trip
+            // to L2.  One barrier per block.
+            static_assert(LDSMAT || (kMaxFrames * 15 + 16 <= 2 * kDenseThreads), "one row of the HBM-resident system per thread");
+            auto load_lrow = [&](int jb0, double *lrow) { // L(jb0 + cc, tid), cc = 0..7
+                if (tid < jb0) {
+                    const double *T = A + tile_base(jb0 >> 4, tid >> 4);
+                    const int o = jb0 & 15;
     #pragma unroll
-                    for (int cc = 0; cc < kPanel; ++cc) lrow[cc] = T[tile_off(o + cc, a & 15)];
+                    for (int cc = 0; cc < kPanel; ++cc) lrow[cc] = T[tile_off(o + cc, tid & 15)];
                 }
+            };
+            double lrow[kPanel], lnext[kPanel];
+            load_lrow((npan - 1) * kPanel, lrow);
+            for (int p = npan - 1; p >= 0; --p) {
+                const int jb0 = p * kPanel;
+                if (p > 0) load_lrow(jb0 - kPanel, lnext);
                 double zb[kPanel], yb[kPanel];
                 {
                     const lds_d2 *Z = reinterpret_cast<const lds_d2 *>(yv + jb0);
@@ -2292,22 +2304,14 @@ __global__ void __launch_bounds__(kDenseThreads) k_dense(View v) {
                     for (int cc = 1; cc < kPanel; ++cc) yo = (tid == cc) ? yb[cc] : yo;
                     ysol[jb0 + tid] = yo;
                 }
-                if (LDSMAT) {
-                    if (a < jb0) {
-                        double acc2 = 0;
+                if (tid < jb0) {
+                    double acc2 = 0;
     #pragma unroll
-                        for (int cc = 0; cc < kPanel; ++cc) acc2 += lrow[cc] * yb[cc];
-                        yv[a] -= acc2;
-                    }
-                } else {
-                    for (int aa = tid; aa < jb0; aa += nthr) {
-                        const double *T = A + tile_base(jb0 >> 4, aa >> 4);
-                        double acc2 = 0;
-    #pragma unroll
-                        for (int cc = 0; cc < kPanel; ++cc) acc2 += T[tile_off(o + cc, aa & 15)] * yb[cc];
-                        yv[aa] -= acc2;
-                    }
+                    for (int cc = 0; cc < kPanel; ++cc) acc2 += lrow[cc] * yb[cc];
+                    yv[tid] -= acc2;
                 }
+    #pragma unroll
+                for (int cc = 0; cc < kPanel; ++cc) lrow[cc] = lnext[cc];
                 __syncthreads();
             }
         }
@@ -2668,7 +2672,7 @@ hipError_t launch_dense(const View &v, hipStream_t st) {
     }
 #endif
     if (lm) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_dense<true>), dim3(1), dim3(kDenseThreads), lds, st, v);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_dense<false>), dim3(1), dim3(kDenseThreads), lds, st, v);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_dense<false>), dim3(1), dim3(2 * kDenseThreads), lds, st, v);
     return hipGetLastError();
 }
 
