@@ -173,6 +173,16 @@ int host_roundtrip_marginalize(const pvio_ba_problem *pb, const pvio_ba_state *s
 // solves it before put_frame) and refined against the rest ------------------------------------------------------------
 #include "../../pvio_amd/host/pnp.h"
 
+namespace pvio {
+double flatten_seconds(Map *map, bool use_inertial, int reps);
+}
+extern "C" double host_flatten_seconds(const pvio_ba_problem *pb, const pvio_ba_state *st, int32_t use_inertial, int32_t reps) {
+    Map map;
+    std::vector<Track *> lm_tracks;
+    build_map(pb, st, map, lm_tracks);
+    return pvio::flatten_seconds(&map, use_inertial != 0, reps);
+}
+
 extern "C" int host_roundtrip_pnp(const pvio_ba_problem *pb, pvio_ba_state *st, int32_t use_inertial, int32_t max_iter, double *state_out) {
     Map map;
     std::vector<Track *> lm_tracks;
