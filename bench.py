@@ -277,6 +277,13 @@ def main():
         "kernel_us": {k: (v[0] / max(v[1], 1)) * 1e3 for k, v in prof.items()},
         "note": "working set < 1 MB: L2/Infinity-Cache resident, the iteration is launch/dependency-latency bound",
     }
+    # the roofline above is for the kernel that moves the window's data (SURVEY 8d's per-iteration bytes); by DURATION the
+    # longest launch of a small window is the one-workgroup dense solve, a serial FP64 chain with no bandwidth or matrix-core
+    # roofline worth quoting (P^3/3 flops in its time is < 0.1 % of the FP64 peak)
+    roofline["longest_kernel"] = max(roofline["kernel_us"], key=roofline["kernel_us"].get)
+    if n_lm >= 10000:
+        roofline["note"] = ("large window: k_linearize is FP64-issue bound (factor evaluation on the VALU + Schur complement on the f64 matrix "
+                            "cores), not HBM bound; see DESIGN.md section 5")
 
     # ---- scaling window: the window north_star's multi-GPU sentence names (10 KF x 50 000 landmarks, full factor set),
     # sharded exactly like the headline window, same context and communicator; a few solves, barrier-bracketed ----
