@@ -202,7 +202,16 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-klt", action="store_true")
     ap.add_argument("--no-scaling-window", action="store_true", help="skip the 10 KF x 50 000 landmark leg")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="diagnostics: run the multi-GPU code path (process group, RCCL communicator, eager launches, all-reduces) with "
+                         "however many ranks there are, also one")
     args = ap.parse_args()
+
+    # stdout carries exactly ONE line (the JSON): libraries that write to file descriptor 1 (RCCL prints its version banner
+    # there at communicator creation) are sent to stderr for the duration of the run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -215,9 +224,13 @@ def main():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    sharded = world > 1 or args.force_sharded
+    if sharded:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     from pvio_amd import BAState, BASummary, capi, synth
@@ -226,8 +239,8 @@ def main():
     lib = capi.load()
     pb_full, (n_frames, n_lm, vio) = build_window(args, preintegrate)
     pb = pb_full.shard(rank, world)
-    ctx = HipContext(device=local_rank, rank=rank, world_size=world, use_graph=not args.no_graph)
-    if world > 1:
+    ctx = HipContext(device=local_rank, rank=rank, world_size=world, use_graph=not args.no_graph, force_sharded=args.force_sharded)
+    if sharded:
         import ctypes as C
         uid = (C.c_uint8 * 128)()
         if rank == 0:
@@ -330,8 +343,8 @@ def main():
             "config": {"workload": "%d KF x %d landmarks, %s, %d reprojection factors, <=%d trust-region iterations per solve"
                                    % (n_frames, n_lm, "full VIO factor set (IMU pre-integration + gauge prior)" if vio else "reprojection only",
                                       pb_full.n_obs, pb_full.max_iterations),
-                       "parallelism": "landmark shards x%d, RCCL all-reduce of the reduced pose system" % world if world > 1 else "single GPU",
-                       "graph": (not args.no_graph) and world == 1},
+                       "parallelism": "landmark shards x%d, RCCL all-reduce of the reduced pose system" % world if sharded else "single GPU",
+                       "graph": (not args.no_graph) and not sharded},
             "iterations_per_solve": iters / args.steps,
             "device_ms_per_step": 1e3 * dev_s / args.steps,
             "roofline": roofline,
@@ -342,7 +355,8 @@ def main():
         }
         if cpu:
             out["speedup_vs_cpu_baseline"] = value / cpu["value"]
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
 

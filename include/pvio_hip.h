@@ -70,7 +70,10 @@ typedef struct pvio_hip_opts {
      * FP64 VALU while every workgroup has a single landmark chunk, 16x16 f64 MFMA tiles once workgroups walk many),
      * 1 = always the VALU tiles, 2 = always the MFMA tiles */
     int32_t linearize_mode;
-    int32_t reserved;
+    /* tests only: run the landmark-sharded code path (eager launches, the all-reduces through the communicator given to
+     * pvio_hip_comm_init, the reduced system assembled from the all-reduced buffer) even with world_size == 1 -- a one-rank
+     * RCCL communicator exercises the collectives on a single-GPU box.  0 in production. */
+    int32_t debug_force_sharded;
 } pvio_hip_opts;
 
 /* ------------------------------------------------------------------------------------------------

@@ -22,7 +22,7 @@ c_int16_p = C.POINTER(C.c_int16)
 
 class HipOpts(C.Structure):
     _fields_ = [("device", C.c_int32), ("rank", C.c_int32), ("world_size", C.c_int32), ("use_graph", C.c_int32),
-                ("debug_fail_factorizations", C.c_int32), ("debug_invalid_steps", C.c_int32), ("linearize_mode", C.c_int32), ("reserved", C.c_int32)]
+                ("debug_fail_factorizations", C.c_int32), ("debug_invalid_steps", C.c_int32), ("linearize_mode", C.c_int32), ("debug_force_sharded", C.c_int32)]
 
 
 class BAProblemC(C.Structure):

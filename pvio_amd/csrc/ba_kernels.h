@@ -10,7 +10,7 @@ size_t dense_lds_bytes(const Dims &dm, int *lds_matrix);
 size_t dense_tile_doubles(const Dims &dm);
 int tiles_per_thread(const Dims &dm);
 hipError_t launch_linearize(const View &v, hipStream_t st);
-hipError_t launch_reduce(const View &v, hipStream_t st);
+hipError_t launch_reduce(const View &v, hipStream_t st, int phase = 0); // phase: see k_reduce
 hipError_t launch_dense(const View &v, hipStream_t st);
 hipError_t launch_backsub(const View &v, hipStream_t st);
 hipError_t launch_back_reduce(const View &v, double *back_local, hipStream_t st);

@@ -1029,7 +1029,10 @@ __device__ __forceinline__ double reduced_entry_terms(const View &v, double val,
 // that finishes tile element red[e] adds the IMU factor blocks and the prior and stores the entry; the entries that have
 // no landmark / plane part (a velocity or bias coordinate) come from the blocks behind nb_red, which read no partials.
 // Entries outside the real lower triangle are never written (the image is zeroed at upload).
-__global__ void __launch_bounds__(kRedElems *kRedGroups) k_reduce(View v, int nb_red) {
+// phase 0: single GPU -- partials -> `red` + tile image.  Landmark-sharded runs split it around the all-reduce:
+// phase 1: partials -> `red` (+ this rank's max slot), no image;  phase 2 (after the all-reduce): `red` -> tile image, so that
+// the dense kernel takes the same fast path (tiles loaded straight into its accumulators) as on one GPU.
+__global__ void __launch_bounds__(kRedElems *kRedGroups) k_reduce(View v, int nb_red, int phase) {
     // the control word is only needed before anything is written: its load travels together with the partials
     const int ctl_done = v.ctrl->done, ctl_result = v.ctrl->lin_result;
     const size_t nS = (size_t)v.dm.n_tasks * 9, nV = (size_t)kNumPoseVec * v.dm.P6;
@@ -1058,7 +1061,9 @@ __global__ void __launch_bounds__(kRedElems *kRedGroups) k_reduce(View v, int nb
     const size_t e = (size_t)blockIdx.x * kRedElems + el;
     // stage 1: group gg sums partials g = gg, gg + 16, ... (coalesced across el), four independent accumulators
     double s = 0;
-    if (e < nS + nV) {
+    if (phase == 2) {
+        if (gg == 0 && e < total) s = v.red[e]; // the all-reduced value (everything it is combined with below is zero)
+    } else if (e < nS + nV) {
         const double *src = e < nS ? v.part_S + e : v.part_vec + (e - nS);
         const size_t stride = e < nS ? nS : nV;
         // <= 4 values per thread per round (one round up to 256 partial rows), all loads issued before the first add
@@ -1090,13 +1095,13 @@ __global__ void __launch_bounds__(kRedElems *kRedGroups) k_reduce(View v, int nb
     if (gg == 0 && e < total) {
         double r = quarter[0][el];
         for (int q = 1; q < 4; ++q) r = is_max ? fmax(r, quarter[q][el]) : r + quarter[q][el];
-        v.red[e] = r;
-        if (is_max && v.dm.world > 1) {
+        if (phase != 2) v.red[e] = r;
+        if (phase != 2 && is_max && v.dm.world > 1) {
             // landmark-sharded: the maximum cannot ride in a summing all-reduce, so every rank owns one slot behind the
             // scalars (zero in the others' slots); after the sum the slots hold every rank's maximum (k_dense takes the max)
             for (int w = 0; w < v.dm.world; ++w) v.red[total + w] = (w == v.dm.rank) ? r : 0.0;
         }
-        if (v.dm.use_img && e < nS) {
+        if (v.dm.use_img && phase != 1 && e < nS) {
             const int n_tasks = v.dm.n_tasks, ee = (int)e, q = ee / n_tasks, t = ee - q * n_tasks, d = v.dm.d;
             int fi, fj, si, sj;
             unpack_task(v.task_desc[t], fi, fj, si, sj);
@@ -2632,11 +2637,11 @@ hipError_t launch_linearize(const View &v, hipStream_t st) {
     return launch_lin_T<9>(v, st);
 }
 
-hipError_t launch_reduce(const View &v, hipStream_t st) {
+hipError_t launch_reduce(const View &v, hipStream_t st, int phase) {
     const size_t total = (size_t)v.dm.n_tasks * 9 + (size_t)kNumPoseVec * v.dm.P6 + kNumLinScal;
     const int nb_red = (int)((total + kRedElems - 1) / kRedElems);
-    const int nb_img = v.dm.use_img ? (v.dm.img_sz + kRedElems * kRedGroups - 1) / (kRedElems * kRedGroups) : 0;
-    hipLaunchKernelGGL(k_reduce, dim3(nb_red + nb_img), dim3(kRedElems * kRedGroups), 0, st, v, nb_red);
+    const int nb_img = (v.dm.use_img && phase != 1) ? (v.dm.img_sz + kRedElems * kRedGroups - 1) / (kRedElems * kRedGroups) : 0;
+    hipLaunchKernelGGL(k_reduce, dim3(nb_red + nb_img), dim3(kRedElems * kRedGroups), 0, st, v, nb_red, phase);
     return hipGetLastError();
 }
 

@@ -48,7 +48,7 @@ void *DevicePool::get(const char *name, size_t bytes, bool *grew) {
     return s.ptr;
 }
 
-BASolver::BASolver(int device, int rank, int world, bool use_graph) : device_(device), rank_(rank), world_(world), use_graph_(use_graph) {
+BASolver::BASolver(int device, int rank, int world, bool use_graph) : device_(device), rank_(rank), world_(world), sharded_(world > 1), use_graph_(use_graph) {
     (void)hipSetDevice(device_);
     (void)hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking);
     (void)hipEventCreate(&ev0_);
@@ -213,8 +213,8 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st) {
     // 16 landmarks per workgroup pass (16 lanes each); <= 64 partial rows (one per lane of the wave that sums them) until a
     // large window needs the whole chip
     dm.G_back = M <= 4096 ? std::max(1, std::min(64, (M + 15) / 16)) : std::min(cus, (M + 63) / 64);
-    dm.fuse_backsub = (world_ == 1 && M <= 256) ? 1 : 0; // beyond one landmark per thread the separate launch is faster
-    dm.n_back_rows = (world_ > 1 || dm.fuse_backsub) ? 1 : dm.G_back;
+    dm.fuse_backsub = (!sharded_ && M <= 256) ? 1 : 0; // beyond one landmark per thread the separate launch is faster
+    dm.n_back_rows = (sharded_ || dm.fuse_backsub) ? 1 : dm.G_back;
 
     // 3x3 tile tasks over the upper block triangle
     std::vector<int32_t> task_desc;
@@ -301,7 +301,7 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st) {
         int lds_matrix = 0;
         dense_lds_bytes(dm, &lds_matrix);
         const size_t img_sz = dense_tile_doubles(dm);
-        v.dm.use_img = world_ == 1 ? 1 : 0; // (landmark-sharded runs all-reduce `red`, the dense kernel then builds from it)
+        v.dm.use_img = 1; // (landmark-sharded runs build it from the all-reduced `red`: k_reduce phase 2)
         v.dm.img_sz = (int)img_sz;
         dm.use_img = v.dm.use_img, dm.img_sz = v.dm.img_sz;
         ok &= dev(pool_, "img", img_sz, &v.img, &grew);
@@ -319,7 +319,6 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st) {
     ok &= dev(pool_, "trace", (size_t)trace_cap_, &v.trace, &grew);
     v.trace_states = nullptr;
     if (!ok) return fail(PVIO_ERR_OUT_OF_MEMORY, "device allocation / upload failed");
-    if (world_ > 1) v.back_part = v.back_part; // rows are reduced into back_red and all-reduced (see enqueue_slot)
 
     // initial state: kept on the host (tiny for frames) and on the device in buffer 0
     h_init_fs_.assign(st->frame_state, st->frame_state + Ns * 16);
@@ -368,24 +367,26 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st) {
 int BASolver::enqueue_slot(hipEvent_t *ev) {
     hipError_t e;
     View vl = v_;
-    if (world_ > 1) vl.back_part = v_.back_red; // k_linearize reads the all-reduced row
+    if (sharded_) vl.back_part = v_.back_red; // k_linearize reads the all-reduced row
     if (ev) (void)hipEventRecord(ev[0], stream_);
     if ((e = launch_linearize(vl, stream_)) != hipSuccess) return check(e, "k_linearize");
     if (ev) (void)hipEventRecord(ev[1], stream_);
-    if ((e = launch_reduce(v_, stream_)) != hipSuccess) return check(e, "k_reduce");
+    if ((e = launch_reduce(v_, stream_, sharded_ ? 1 : 0)) != hipSuccess) return check(e, "k_reduce");
     if (ev) (void)hipEventRecord(ev[2], stream_);
-    if (world_ > 1) {
+    if (sharded_) {
         const size_t n = (size_t)v_.dm.n_tasks * 9 + (size_t)kNumPoseVec * v_.dm.P6 + kNumLinScal;
         // ONE summing all-reduce per linearization: scalar 4 (max |b_l|) travels as one slot per rank behind the scalars
         // (k_reduce fills this rank's slot, zeros the others; k_dense takes the maximum), its summed copy is not used
         if (comm_allreduce(comm_, v_.red, n + (size_t)world_, 0, stream_)) return fail(PVIO_ERR_COMM, "all-reduce failed");
+        // the all-reduced system -> tile image (every rank the same): the dense kernel then runs as on one GPU
+        if ((e = launch_reduce(v_, stream_, 2)) != hipSuccess) return check(e, "k_reduce (image)");
     }
     if (ev) (void)hipEventRecord(ev[3], stream_);
     if ((e = launch_dense(v_, stream_)) != hipSuccess) return check(e, "k_dense");
     if (ev) (void)hipEventRecord(ev[4], stream_);
     if (!v_.dm.fuse_backsub && (e = launch_backsub(v_, stream_)) != hipSuccess) return check(e, "k_backsub");
     if (ev) (void)hipEventRecord(ev[5], stream_);
-    if (world_ > 1) {
+    if (sharded_) {
         double *back_local = static_cast<double *>(pool_.get("back_local", kNumBackScal * sizeof(double)));
         if ((e = launch_back_reduce(v_, back_local, stream_)) != hipSuccess) return check(e, "k_back_reduce");
         if (comm_allreduce(comm_, v_.back_red, kNumBackScal, 0, stream_)) return fail(PVIO_ERR_COMM, "all-reduce failed");
@@ -398,7 +399,7 @@ int BASolver::run_slots(int n_slots) {
     // state machine is on the device); capturing + instantiating a graph costs more than it saves on a single solve and
     // is left to the second solve of the same resident window.
     const bool have_graph = graph_exec_ && graph_slots_ == n_slots;
-    if (use_graph_ && world_ == 1 && (have_graph || solves_since_upload_ > 0)) {
+    if (use_graph_ && !sharded_ && (have_graph || solves_since_upload_ > 0)) {
         if (!have_graph) {
             invalidate_graph();
             if (check(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal), "begin capture")) return PVIO_ERR_HIP;

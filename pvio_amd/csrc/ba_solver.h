@@ -36,6 +36,7 @@ class DevicePool { // grow-only device allocations keyed by name
 class BASolver {
   public:
     BASolver(int device, int rank, int world, bool use_graph);
+    void set_force_sharded(bool on) { sharded_ = world_ > 1 || on; }
     void set_fault_injection(int fail_factorizations, int invalid_steps) { dbg_fail_ = fail_factorizations, dbg_invalid_ = invalid_steps; }
     void set_linearize_mode(int m) { lin_mode_ = m; }
     ~BASolver();
@@ -56,6 +57,7 @@ class BASolver {
     void invalidate_graph();
 
     int device_, rank_, world_;
+    bool sharded_; // world_ > 1, or forced for tests: eager launches + all-reduces + assembly from the reduced buffer
     bool use_graph_;
     int lin_mode_ = 0; // pvio_hip_opts::linearize_mode
     int dbg_fail_ = 0, dbg_invalid_ = 0; // tests only: forced factorization failures / invalid steps per solve

@@ -16,12 +16,13 @@ class HipError(RuntimeError):
 
 class HipContext:
     def __init__(self, device=0, rank=0, world_size=1, use_graph=True, lib=None, debug_fail_factorizations=0, debug_invalid_steps=0,
-                 linearize_mode=0):
+                 linearize_mode=0, force_sharded=False):
         self.lib = lib or capi.load()
         opts = capi.HipOpts()
         opts.device, opts.rank, opts.world_size, opts.use_graph = device, rank, world_size, int(use_graph)
         opts.debug_fail_factorizations, opts.debug_invalid_steps = debug_fail_factorizations, debug_invalid_steps  # tests only
         opts.linearize_mode = linearize_mode
+        opts.debug_force_sharded = int(force_sharded)
         self.ctx = C.c_void_p()
         rc = self.lib.pvio_hip_create(C.byref(opts), C.byref(self.ctx))
         if rc != 0:

@@ -141,3 +141,25 @@ def test_emulated_mfma_tile_linearization_matches_oracle(emu_ctx_mm, oracle, nam
 def test_emulated_mfma_tile_marginalization_matches_oracle(emu_ctx_mm, oracle, victim):
     import marg_compare
     marg_compare.check_marginalize(emu_ctx_mm, oracle, victim, n_frames=6, n_landmarks=40, use_inertial=True, visibility=4)
+
+
+def test_emulated_one_rank_sharded_path(oracle):
+    """debug_force_sharded with world_size 1: the sharded code path (eager launches, all-reduces through the communicator,
+    assembly from the reduced buffer) with an identity all-reduce; tests/test_gpu_ba.py runs the same through RCCL."""
+    import ctypes as C
+    subprocess.check_call(["make", "-s", "-C", EMU_DIR, "libpvio_hipemu.so"])
+    lib = capi.load(os.path.join(EMU_DIR, "libpvio_hipemu.so"))
+
+    @C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_long, C.c_int)
+    def identity(buf, n, op_max):
+        return 0
+    lib.hipemu_set_allreduce(identity)
+    ctx = HipContext(lib=lib, force_sharded=True)
+    try:
+        uid = (C.c_uint8 * 128)()
+        assert lib.pvio_hip_comm_unique_id(uid) == 0 and lib.pvio_hip_comm_init(ctx.ctx, uid, 0, 1) == 0
+        for name in ("vio_partial", "vio_plane"):
+            ba_compare.check_against_oracle(ctx, oracle, ba_compare.make(oracle, **ba_compare.CASES[name]))
+    finally:
+        ctx.close()
+        lib.hipemu_set_allreduce(C.cast(None, C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_long, C.c_int)))

@@ -178,3 +178,33 @@ def test_gpu_full_size_window_properties(oracle):
     np.testing.assert_allclose(sm1.final_cost, sm.final_cost, rtol=1e-9)
     np.testing.assert_allclose(st1.frame_state, st.frame_state, rtol=0, atol=1e-7)
     np.testing.assert_allclose(st1.lm_inv_depth, st.lm_inv_depth, rtol=0, atol=1e-7)
+
+
+@pytest.mark.parametrize("name", ["vio_partial", "vio_plane", "metric_10x1000_vio", "vio_13_frames_global_matrix"])
+def test_gpu_one_rank_communicator_runs_the_sharded_path(oracle, name):
+    """The landmark-sharded code path on the one GPU there is: a ONE-rank RCCL communicator (ncclCommInitRank with nranks = 1)
+    carries the real all-reduces on the solver's stream, launches are eager, the reduced system is assembled from the
+    all-reduced buffer -- everything the multi-GPU run does except a second rank.  Results must equal the oracle's."""
+    import ctypes as C
+    from pvio_amd import capi
+    from pvio_amd.solver import HipContext
+    lib = capi.load()
+    ctx = HipContext(device=0, rank=0, world_size=1, force_sharded=True)
+    try:
+        uid = (C.c_uint8 * 128)()
+        assert lib.pvio_hip_comm_unique_id(uid) == 0
+        assert lib.pvio_hip_comm_init(ctx.ctx, uid, 0, 1) == 0
+        pb = ba_compare.make(oracle, **{**ba_compare.CASES, **ba_compare.BIG_CASES}[name])
+        print(name, ba_compare.check_against_oracle(ctx, oracle, pb))
+    finally:
+        ctx.close()
+
+
+def test_gpu_sharded_path_without_communicator_fails_loudly(oracle):
+    from pvio_amd.solver import HipContext, HipError
+    ctx = HipContext(device=0, force_sharded=True)
+    try:
+        with pytest.raises(HipError):
+            ctx.solve(ba_compare.make(oracle, **ba_compare.CASES["vision_small"]))
+    finally:
+        ctx.close()
