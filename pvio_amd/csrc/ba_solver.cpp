@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 
 #include "ba_kernels.h"
@@ -399,7 +400,10 @@ int BASolver::run_slots(int n_slots) {
     // state machine is on the device); capturing + instantiating a graph costs more than it saves on a single solve and
     // is left to the second solve of the same resident window.
     const bool have_graph = graph_exec_ && graph_slots_ == n_slots;
-    if (use_graph_ && !sharded_ && (have_graph || solves_since_upload_ > 0)) {
+    // Landmark-sharded runs launch eagerly by default.  Their collectives can be captured too (RCCL supports stream capture):
+    // opt-in with PVIO_HIP_SHARDED_GRAPH=1 -- measured with a one-rank communicator only, so not the default.
+    static const bool sharded_graph = std::getenv("PVIO_HIP_SHARDED_GRAPH") != nullptr && std::atoi(std::getenv("PVIO_HIP_SHARDED_GRAPH")) != 0;
+    if (use_graph_ && (!sharded_ || sharded_graph) && (have_graph || solves_since_upload_ > 0)) {
         if (!have_graph) {
             invalidate_graph();
             if (check(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal), "begin capture")) return PVIO_ERR_HIP;
