@@ -10,7 +10,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $OUT/${TAG}_bench_vio.json 2> $OUT/${TAG}_bench_vio.err
 python $R/bench.py --workload vision > $OUT/${TAG}_bench_vision.json 2> $OUT/${TAG}_bench_vision.err
-(cd $R && python -m pytest tests -m gpu -q 2>&1 | tail -5) > $OUT/${TAG}_pytest_gpu.txt
+(cd $R && python -m pytest tests -m gpu -q 2>&1 | grep -v "^RCCL version\|^HIP version\|^ROCm version\|^Hostname\|^Librccl path" | tail -5) > $OUT/${TAG}_pytest_gpu.txt
 # large windows (k_linearize in its matrix-core form): bench lines + kernel stats + HBM counters of the 30 KF x 50k VIO window
 for W in 30x50000_vio 30x50000_vision 10x50000_vio; do
   python $R/bench.py --workload $W --steps 10 --warmup 2 --no-klt --no-cpu-baseline > $OUT/${TAG}_bench_$W.json 2> $OUT/${TAG}_bench_$W.err
