@@ -42,6 +42,9 @@ class Klt {
     size_t src_cap_ = 0;
     void *d_det_ = nullptr; // detection scratch: cov planes, response map, candidates
     size_t det_cap_ = 0;
+    std::vector<uint64_t> det_keys_;   // (response bits, address) keys of the candidates, reused
+    std::vector<int> det_grid_cnt_;    // minimum-distance grid of the selection, reused
+    std::vector<float> det_grid_xy_;
     // released pyramid slabs, reused by the next image of the same size: a camera stream allocates once (hipMalloc +
     // hipFree per frame cost more than the whole pyramid build)
     std::vector<std::pair<size_t, void *>> slab_pool_;
