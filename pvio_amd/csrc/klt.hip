@@ -744,12 +744,14 @@ __global__ void __launch_bounds__(256) k_harris_response(int w, int h, const flo
     }
 }
 
+// keymap != nullptr: every pixel also gets its candidate response (0 = not a candidate) for the dominance filter below
 __global__ void __launch_bounds__(256) k_harris_collect(int w, int h, const float *resp, const int *max_bits, float quality, int cap, int *count, float *cand_val,
-                                                        int *cand_pos) {
+                                                        int *cand_pos, float *keymap) {
 #if defined(__clang__)
 #pragma clang fp contract(off)
 #endif
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (keymap && x < w) keymap[(size_t)y * w + x] = 0.0f;
     if (x < 1 || x >= w - 1 || y < 1 || y >= h - 1) return;
     const float mx = __int_as_float(*max_bits);
     const float thr = (float)((double)mx * (double)quality);
@@ -765,8 +767,61 @@ __global__ void __launch_bounds__(256) k_harris_collect(int w, int h, const floa
             m = fmaxf(m, q > thr ? q : 0.0f);
         }
     if (v == m) {
+        if (keymap) keymap[(size_t)y * w + x] = v;
         const int slot = atomicAdd(count, 1);
         if (slot < cap) cand_val[slot] = v, cand_pos[slot] = y * w + x;
+    }
+}
+
+// ---- exact pre-filter of the greedy minimum-distance selection ---------------------------------------------------------
+// goodFeaturesToTrack walks the candidates in descending (response, address) order and accepts one iff no ACCEPTED corner
+// lies closer than min_distance.  A candidate that is the strongest within min_distance of itself ("dominant") is always
+// accepted, hence every other candidate within min_distance of a dominant one is always rejected -- and a rejected
+// candidate influences nothing.  Dropping those on the device leaves the host with the contested candidates only (a
+// quarter of them on textured images) and changes no result.  Keys are unique (the address breaks ties), the distance test
+// is the host's: dx^2 + dy^2 < min_distance^2 (integer offsets, compared in double).
+__device__ __forceinline__ bool lk_key_greater(float va, int pa, float vb, int pb) { return va > vb || (va == vb && pa > pb); }
+// One WAVE per candidate of the compacted list: the lanes share the (2R + 1)^2 positions of its disc (independent loads; a
+// thread per pixel walking the disc alone paid one dependent L2 round trip per position: 1.2 ms).
+__global__ void __launch_bounds__(256) k_corner_dominant(int w, int h, const float *keymap, const int *count, const float *cand_val, const int *cand_pos, int cap,
+                                                         int R, double md2, uint8_t *dominant_map, uint8_t *dominant_flag) {
+    const int lane = threadIdx.x & 63, idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n = *count < cap ? *count : cap;
+    if (idx >= n) return; // whole wave
+    const float v = cand_val[idx];
+    const int o = cand_pos[idx], y = o / w, x = o - y * w, side = 2 * R + 1;
+    bool beaten = false;
+    for (int e = lane; e < side * side; e += 64) {
+        const int j = e / side - R, i = e - (j + R) * side - R, xx = x + i, yy = y + j;
+        if (xx < 0 || xx >= w || yy < 0 || yy >= h || (double)(i * i + j * j) >= md2) continue;
+        const float q = keymap[(size_t)yy * w + xx];
+        beaten |= q > 0.0f && lk_key_greater(q, yy * w + xx, v, o);
+    }
+    const bool dom = __ballot(beaten ? 1 : 0) == 0;
+    if (lane == 0) {
+        dominant_flag[idx] = dom ? 1 : 0;
+        if (dom) dominant_map[o] = 1; // the map was cleared before the launch
+    }
+}
+__global__ void __launch_bounds__(256) k_corner_survivors(int w, int h, const uint8_t *dominant_map, const uint8_t *dominant_flag, const int *count,
+                                                          const float *cand_val, const int *cand_pos, int cap, int R, double md2, int *count_out, float *out_val,
+                                                          int *out_pos) {
+    const int lane = threadIdx.x & 63, idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n = *count < cap ? *count : cap;
+    if (idx >= n) return;
+    const int o = cand_pos[idx], y = o / w, x = o - y * w, side = 2 * R + 1;
+    bool killed = false;
+    if (!dominant_flag[idx]) { // wave-uniform
+        for (int e = lane; e < side * side; e += 64) {
+            const int j = e / side - R, i = e - (j + R) * side - R, xx = x + i, yy = y + j;
+            if (xx < 0 || xx >= w || yy < 0 || yy >= h || (double)(i * i + j * j) >= md2) continue;
+            killed |= dominant_map[(size_t)yy * w + xx] != 0; // a dominant candidate in reach is necessarily stronger than this one
+        }
+    }
+    const bool keep = __ballot(killed ? 1 : 0) == 0;
+    if (lane == 0 && keep) {
+        const int slot = atomicAdd(count_out, 1);
+        if (slot < cap) out_val[slot] = cand_val[idx], out_pos[slot] = o;
     }
 }
 
@@ -789,21 +844,50 @@ int Klt::detect(const Image *img, int max_corners, double quality, double min_di
     }
     float *cxx = static_cast<float *>(d_det_), *cxy = cxx + px, *cyy = cxy + px, *resp = cyy + px, *cand_val = resp + px;
     int *cand_pos = reinterpret_cast<int *>(cand_val + cap), *scal = cand_pos + cap; // scal[0] = max bits, scal[1] = count
-    (void)hipMemsetAsync(scal, 0, 8, stream_);
+    (void)hipMemsetAsync(scal, 0, 12, stream_); // [0] max bits, [1] candidates, [2] contested candidates
     const dim3 grid((w + 255) / 256, h), blk(256);
     hipLaunchKernelGGL(k_harris_cov, grid, blk, 0, stream_, img->lv[0], cxx, cxy, cyy);
     hipLaunchKernelGGL(k_harris_response, grid, blk, 0, stream_, w, h, (const float *)cxx, (const float *)cxy, (const float *)cyy, resp, scal);
-    hipLaunchKernelGGL(k_harris_collect, grid, blk, 0, stream_, w, h, (const float *)resp, (const int *)scal, (float)quality, cap, scal + 1, cand_val, cand_pos);
+    const float *list_val = cand_val;
+    const int *list_pos = cand_pos;
+    int count_slot = 1;
+    if (min_distance >= 1) {
+        // all candidates -> list + key map (the xx plane is dead by now) -> dominant flags / map (the xy plane) -> contested
+        // candidates, compacted into the yy plane
+        float *keymap = cxx;
+        uint8_t *dominant_map = reinterpret_cast<uint8_t *>(cxy), *dominant_flag = dominant_map + px;
+        float *out_val = cyy;
+        int *out_pos = reinterpret_cast<int *>(cyy + cap);
+        static_assert(sizeof(float) == 4, "plane arithmetic");
+        const int R = (int)std::ceil(min_distance);
+        const double md2 = min_distance * min_distance; // compared in double like the host selection
+        hipLaunchKernelGGL(k_harris_collect, grid, blk, 0, stream_, w, h, (const float *)resp, (const int *)scal, (float)quality, cap, scal + 1, cand_val, cand_pos,
+                           keymap);
+        (void)hipMemsetAsync(dominant_map, 0, px, stream_);
+        const dim3 lgrid((cap + 3) / 4);
+        hipLaunchKernelGGL(k_corner_dominant, lgrid, blk, 0, stream_, w, h, (const float *)keymap, (const int *)(scal + 1), (const float *)cand_val,
+                           (const int *)cand_pos, cap, R, md2, dominant_map, dominant_flag);
+        hipLaunchKernelGGL(k_corner_survivors, lgrid, blk, 0, stream_, w, h, (const uint8_t *)dominant_map, (const uint8_t *)dominant_flag, (const int *)(scal + 1),
+                           (const float *)cand_val, (const int *)cand_pos, cap, R, md2, scal + 2, out_val, out_pos);
+        list_val = out_val, list_pos = out_pos, count_slot = 2;
+    } else {
+        hipLaunchKernelGGL(k_harris_collect, grid, blk, 0, stream_, w, h, (const float *)resp, (const int *)scal, (float)quality, cap, scal + 1, cand_val, cand_pos,
+                           (float *)nullptr);
+    }
     static const bool timing = getenv("PVIO_KLT_TIMING") != nullptr; // diagnostics: where a detect() call spends its time
     const auto tt0 = std::chrono::steady_clock::now();
-    int hs[2] = {0, 0};
-    bool ok = hipMemcpyAsync(hs, scal, 8, hipMemcpyDeviceToHost, stream_) == hipSuccess && hipStreamSynchronize(stream_) == hipSuccess && hipGetLastError() == hipSuccess;
-    const int nc = std::min(hs[1], cap);
+    int hs[3] = {0, 0, 0};
+    bool ok = hipMemcpyAsync(hs, scal, 12, hipMemcpyDeviceToHost, stream_) == hipSuccess && hipStreamSynchronize(stream_) == hipSuccess && hipGetLastError() == hipSuccess;
+    if (ok && hs[1] > cap) {
+        err_ = "too many corner candidates"; // a quarter of the pixels: the 3 x 3 non-maximum suppression cannot produce more
+        return PVIO_ERR_UNSUPPORTED;
+    }
+    const int nc = std::min(hs[count_slot], cap);
     std::vector<float> val((size_t)nc);
     std::vector<int> pos((size_t)nc);
     if (ok && nc > 0) {
-        ok = hipMemcpyAsync(val.data(), cand_val, (size_t)nc * 4, hipMemcpyDeviceToHost, stream_) == hipSuccess;
-        ok = ok && hipMemcpyAsync(pos.data(), cand_pos, (size_t)nc * 4, hipMemcpyDeviceToHost, stream_) == hipSuccess && hipStreamSynchronize(stream_) == hipSuccess;
+        ok = hipMemcpyAsync(val.data(), list_val, (size_t)nc * 4, hipMemcpyDeviceToHost, stream_) == hipSuccess;
+        ok = ok && hipMemcpyAsync(pos.data(), list_pos, (size_t)nc * 4, hipMemcpyDeviceToHost, stream_) == hipSuccess && hipStreamSynchronize(stream_) == hipSuccess;
     }
     if (!ok) {
         err_ = "corner detection failed";
@@ -874,7 +958,7 @@ int Klt::detect(const Image *img, int max_corners, double quality, double min_di
     *n_out = n;
     if (timing) {
         auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
-        fprintf(stderr, "[pvio-hip] detect: %d candidates -> %d corners: kernels + copies %.1f us, ordering %.1f us, selection %.1f us\n", nc, n, us(tt0, tt1),
+        fprintf(stderr, "[pvio-hip] detect: %d candidates (%d contested) -> %d corners: kernels + copies %.1f us, ordering %.1f us, selection %.1f us\n", hs[1], nc, n, us(tt0, tt1),
                 us(tt1, tt2), us(tt2, std::chrono::steady_clock::now()));
     }
     return PVIO_OK;

@@ -51,3 +51,10 @@ def test_emulated_detection_matches_oracle(emu_ctx, oracle):
 
 def test_emulated_detection_odd_size_small_distance(emu_ctx, oracle):
     gftt_compare.check_detect(emu_ctx, oracle, 151, 117, max_corners=50, min_distance=7.0)
+
+
+@pytest.mark.parametrize("md,cap", [(7.5, 1000), (1.0, 1000), (0.0, 200), (33.0, 1000)])
+def test_emulated_detection_distance_filter_is_exact(emu_ctx, oracle, md, cap):
+    """The device drops candidates that the greedy minimum-distance walk is certain to reject (dominated ones); whatever the
+    distance -- fractional, 1, none (no filter), larger than the tile -- the corners must be the oracle's, in its order."""
+    gftt_compare.check_detect(emu_ctx, oracle, 128, 96, max_corners=cap, min_distance=md)

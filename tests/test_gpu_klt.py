@@ -45,3 +45,9 @@ def test_gpu_corner_detection_matches_oracle(gpu_ctx, oracle):
     print(gftt_compare.check_detect(gpu_ctx, oracle, 752, 480))   # EuRoC size
     print(gftt_compare.check_detect(gpu_ctx, oracle, 512, 512, max_corners=300, min_distance=11.0))  # TUM-VI size
     print(gftt_compare.check_detect(gpu_ctx, oracle, 333, 241, quality=0.05))
+
+
+@pytest.mark.parametrize("md,cap", [(7.5, 1000), (1.0, 1000), (0.0, 300), (20.0, 60), (45.0, 1000)])
+def test_gpu_corner_distance_filter_is_exact(gpu_ctx, oracle, md, cap):
+    import gftt_compare
+    print(md, cap, gftt_compare.check_detect(gpu_ctx, oracle, 512, 384, max_corners=cap, min_distance=md))
