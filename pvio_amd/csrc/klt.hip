@@ -785,43 +785,45 @@ __device__ __forceinline__ bool lk_key_greater(float va, int pa, float vb, int p
 // thread per pixel walking the disc alone paid one dependent L2 round trip per position: 1.2 ms).
 __global__ void __launch_bounds__(256) k_corner_dominant(int w, int h, const float *keymap, const int *count, const float *cand_val, const int *cand_pos, int cap,
                                                          int R, double md2, uint8_t *dominant_map, uint8_t *dominant_flag) {
-    const int lane = threadIdx.x & 63, idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     const int n = *count < cap ? *count : cap;
-    if (idx >= n) return; // whole wave
-    const float v = cand_val[idx];
-    const int o = cand_pos[idx], y = o / w, x = o - y * w, side = 2 * R + 1;
-    bool beaten = false;
-    for (int e = lane; e < side * side; e += 64) {
-        const int j = e / side - R, i = e - (j + R) * side - R, xx = x + i, yy = y + j;
-        if (xx < 0 || xx >= w || yy < 0 || yy >= h || (double)(i * i + j * j) >= md2) continue;
-        const float q = keymap[(size_t)yy * w + xx];
-        beaten |= q > 0.0f && lk_key_greater(q, yy * w + xx, v, o);
-    }
-    const bool dom = __ballot(beaten ? 1 : 0) == 0;
-    if (lane == 0) {
-        dominant_flag[idx] = dom ? 1 : 0;
-        if (dom) dominant_map[o] = 1; // the map was cleared before the launch
+    for (int idx = blockIdx.x * 4 + (threadIdx.x >> 6); idx < n; idx += gridDim.x * 4) { // whole waves; the count is only known here
+        const float v = cand_val[idx];
+        const int o = cand_pos[idx], y = o / w, x = o - y * w, side = 2 * R + 1;
+        bool beaten = false;
+        for (int e = lane; e < side * side; e += 64) {
+            const int j = e / side - R, i = e - (j + R) * side - R, xx = x + i, yy = y + j;
+            if (xx < 0 || xx >= w || yy < 0 || yy >= h || (double)(i * i + j * j) >= md2) continue;
+            const float q = keymap[(size_t)yy * w + xx];
+            beaten |= q > 0.0f && lk_key_greater(q, yy * w + xx, v, o);
+        }
+        const bool dom = __ballot(beaten ? 1 : 0) == 0;
+        if (lane == 0) {
+            dominant_flag[idx] = dom ? 1 : 0;
+            if (dom) dominant_map[o] = 1; // the map was cleared before the launch
+        }
     }
 }
 __global__ void __launch_bounds__(256) k_corner_survivors(int w, int h, const uint8_t *dominant_map, const uint8_t *dominant_flag, const int *count,
                                                           const float *cand_val, const int *cand_pos, int cap, int R, double md2, int *count_out, float *out_val,
                                                           int *out_pos) {
-    const int lane = threadIdx.x & 63, idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     const int n = *count < cap ? *count : cap;
-    if (idx >= n) return;
-    const int o = cand_pos[idx], y = o / w, x = o - y * w, side = 2 * R + 1;
-    bool killed = false;
-    if (!dominant_flag[idx]) { // wave-uniform
-        for (int e = lane; e < side * side; e += 64) {
-            const int j = e / side - R, i = e - (j + R) * side - R, xx = x + i, yy = y + j;
-            if (xx < 0 || xx >= w || yy < 0 || yy >= h || (double)(i * i + j * j) >= md2) continue;
-            killed |= dominant_map[(size_t)yy * w + xx] != 0; // a dominant candidate in reach is necessarily stronger than this one
+    for (int idx = blockIdx.x * 4 + (threadIdx.x >> 6); idx < n; idx += gridDim.x * 4) {
+        const int o = cand_pos[idx], y = o / w, x = o - y * w, side = 2 * R + 1;
+        bool killed = false;
+        if (!dominant_flag[idx]) { // wave-uniform
+            for (int e = lane; e < side * side; e += 64) {
+                const int j = e / side - R, i = e - (j + R) * side - R, xx = x + i, yy = y + j;
+                if (xx < 0 || xx >= w || yy < 0 || yy >= h || (double)(i * i + j * j) >= md2) continue;
+                killed |= dominant_map[(size_t)yy * w + xx] != 0; // a dominant candidate in reach is necessarily stronger than this one
+            }
         }
-    }
-    const bool keep = __ballot(killed ? 1 : 0) == 0;
-    if (lane == 0 && keep) {
-        const int slot = atomicAdd(count_out, 1);
-        if (slot < cap) out_val[slot] = cand_val[idx], out_pos[slot] = o;
+        const bool keep = __ballot(killed ? 1 : 0) == 0;
+        if (lane == 0 && keep) {
+            const int slot = atomicAdd(count_out, 1);
+            if (slot < cap) out_val[slot] = cand_val[idx], out_pos[slot] = o;
+        }
     }
 }
 
@@ -864,7 +866,7 @@ int Klt::detect(const Image *img, int max_corners, double quality, double min_di
         hipLaunchKernelGGL(k_harris_collect, grid, blk, 0, stream_, w, h, (const float *)resp, (const int *)scal, (float)quality, cap, scal + 1, cand_val, cand_pos,
                            keymap);
         (void)hipMemsetAsync(dominant_map, 0, px, stream_);
-        const dim3 lgrid((cap + 3) / 4);
+        const dim3 lgrid(std::min((cap + 3) / 4, 2048)); // the kernels loop: the candidate count is only known on the device
         hipLaunchKernelGGL(k_corner_dominant, lgrid, blk, 0, stream_, w, h, (const float *)keymap, (const int *)(scal + 1), (const float *)cand_val,
                            (const int *)cand_pos, cap, R, md2, dominant_map, dominant_flag);
         hipLaunchKernelGGL(k_corner_survivors, lgrid, blk, 0, stream_, w, h, (const uint8_t *)dominant_map, (const uint8_t *)dominant_flag, (const int *)(scal + 1),
