@@ -72,9 +72,13 @@ bool last_point_collinear(const float *m, int count) { // the count-th point aga
     return false;
 }
 
-int count_inliers(int n, const float *p, const float *q, const double *F, double thr2, std::vector<uint8_t> &mask) {
+// `need`: the hypothesis only matters if it ends with MORE than `need` inliers (the best count so far); once the points that
+// are left cannot lift it above that the scoring stops (the value returned is then just some count <= need, the mask is
+// not used).  Most hypotheses of a run are poor: they are abandoned after n - need misses instead of after n points.
+int count_inliers(int n, const float *p, const float *q, const double *F, double thr2, std::vector<uint8_t> &mask, int need) {
     int good = 0;
     for (int i = 0; i < n; ++i) {
+        if (good + (n - i) <= need) return good;
         const double x1 = p[2 * i], y1 = p[2 * i + 1], x2 = q[2 * i], y2 = q[2 * i + 1];
         double a = F[0] * x1 + F[1] * y1 + F[2], b = F[3] * x1 + F[4] * y1 + F[5], c = F[6] * x1 + F[7] * y1 + F[8];
         const double s2 = 1. / (a * a + b * b), d2 = x2 * a + y2 * b + c;
@@ -208,7 +212,7 @@ int find_fundamental_ransac(int n, const float *p, const float *q, double thresh
         double F[27];
         const int nm = fundamental_7point(sp, sq, F);
         for (int m = 0; m < nm; ++m) {
-            const int good = count_inliers(n, p, q, F + 9 * m, thr2, cur);
+            const int good = count_inliers(n, p, q, F + 9 * m, thr2, cur, std::max(max_good, kModel - 1));
             if (good > std::max(max_good, kModel - 1)) {
                 std::swap(cur, best);
                 std::copy(F + 9 * m, F + 9 * m + 9, bestF);
