@@ -88,9 +88,35 @@ def write_front(name, width, height, n_points):
     print(name, "tracks kept", int((status > 0).sum()), "of", len(status), "corners", len(xy))
 
 
+def write_undistort(name):
+    """The dataset readers' undistortion (oracle/oracle_undistort.py): maps of both camera models at a small size with the
+    reference readers' constants scaled down, a random source image, the remap output and its CLAHE'd level 0."""
+    from oracle import oracle_undistort as U
+    rng = np.random.default_rng(77)
+    s = 0.25                                                     # EuRoC camera at a quarter of its resolution
+    K_e = [458.654 * s, 0, 367.215 * s, 0, 457.296 * s, 248.375 * s, 0, 0, 1]
+    D_e = [-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05]
+    we, he = 188, 120
+    xy_e, fr_e = U.cv_undistort_fixed_maps(K_e, D_e, we, he)
+    K_t = [190.97847715128717 * s, 0, 254.93170605935475 * s, 0, 190.9733070521226 * s, 256.8974428996504 * s, 0, 0, 1]
+    D_t = [0.0034003170790442797, 0.001766278153469831, -0.00266312569781606, 0.0003299517423931039]
+    wt, ht = 128, 128
+    xy_t, fr_t = U.image_undistorter_maps(wt, ht, K_t, D_t, "equidistant")
+    src_e = rng.integers(0, 256, (he, we), dtype=np.uint8)
+    src_t = rng.integers(0, 256, (ht, wt), dtype=np.uint8)
+    out_e, out_t = U.remap_bilinear(src_e, xy_e, fr_e), U.remap_bilinear(src_t, xy_t, fr_t)
+    d = dict(in_euroc_K=np.array(K_e), in_euroc_dist=np.array(D_e), in_euroc_src=src_e, out_euroc_map_xy=xy_e, out_euroc_map_frac=fr_e,
+             out_euroc_remap=out_e, out_euroc_level0=oracle.clahe(out_e),
+             in_tum_K=np.array(K_t), in_tum_dist=np.array(D_t), in_tum_src=src_t, out_tum_map_xy=xy_t, out_tum_map_frac=fr_t,
+             out_tum_remap=out_t, out_tum_level0=oracle.clahe(out_t))
+    np.savez_compressed(golden_io.path(name + ".npz"), **d)
+    print(name, "euroc corner ->", xy_e[0, 0], "tum corner ->", xy_t[0, 0])
+
+
 if __name__ == "__main__":
     for n, kw in BA_CASES.items():
         write_ba(n, kw)
     for n, (kw, v) in MARG_CASES.items():
         write_marg(n, kw, v)
     write_front("front_176x132", 176, 132, 60)
+    write_undistort("undistort_small")

@@ -84,3 +84,32 @@ def front_ctx(ctx, pos_tol=1e-3):
     assert (xy == d["out_corners_xy"]).all() and (r.view(np.int32) == d["out_corners_resp"].view(np.int32)).all()
     A.release()
     B.release()
+
+
+def undistort_oracle(oracle):
+    """The numpy restatement (and the oracle's CLAHE behind it) against the committed maps and pixels."""
+    from oracle import oracle_undistort as U
+    g = np.load(golden_io.path("undistort_small.npz"))
+    he, we = g["in_euroc_src"].shape
+    xy, fr = U.cv_undistort_fixed_maps(g["in_euroc_K"], g["in_euroc_dist"], we, he)
+    assert (xy == g["out_euroc_map_xy"]).all() and (fr == g["out_euroc_map_frac"]).all()
+    ht, wt = g["in_tum_src"].shape
+    xy, fr = U.image_undistorter_maps(wt, ht, g["in_tum_K"], g["in_tum_dist"], "equidistant")
+    assert (xy == g["out_tum_map_xy"]).all() and (fr == g["out_tum_map_frac"]).all()
+    for cam in ("euroc", "tum"):
+        out = U.remap_bilinear(g["in_%s_src" % cam], g["out_%s_map_xy" % cam], g["out_%s_map_frac" % cam])
+        assert (out == g["out_%s_remap" % cam]).all()
+        assert (oracle.clahe(out) == g["out_%s_level0" % cam]).all()
+
+
+def undistort_ctx(ctx):
+    """The device remap (+ CLAHE) on the committed maps against the committed pixels."""
+    from pvio_amd.solver import HipImage, HipUndistort
+    g = np.load(golden_io.path("undistort_small.npz"))
+    for cam in ("euroc", "tum"):
+        ud = HipUndistort(ctx, g["out_%s_map_xy" % cam], g["out_%s_map_frac" % cam])
+        plain = HipImage(ctx, g["in_%s_src" % cam], clahe=False, undistort=ud)
+        assert (plain.level(0)[0] == g["out_%s_remap" % cam]).all()
+        eq = HipImage(ctx, g["in_%s_src" % cam], clahe=True, undistort=ud)
+        assert (eq.level(0)[0] == g["out_%s_level0" % cam]).all()
+        plain.release(), eq.release(), ud.release()

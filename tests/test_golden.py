@@ -44,6 +44,19 @@ def test_oracle_reproduces_golden_front_end(oracle):
     gc.front_oracle(oracle)
 
 
+def test_oracle_reproduces_golden_undistortion(oracle):
+    gc.undistort_oracle(oracle)
+
+
+def test_emulated_kernels_reproduce_golden_undistortion(emu_ctx):
+    gc.undistort_ctx(emu_ctx)
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_golden_undistortion(gpu_ctx):
+    gc.undistort_ctx(gpu_ctx)
+
+
 @pytest.mark.parametrize("name", gc.BA_FIXTURES)
 def test_emulated_kernels_reproduce_golden_ba(emu_ctx, name):
     gc.ba_ctx(emu_ctx, name)
