@@ -1,6 +1,7 @@
 // ingest_shim.cpp -- extern "C" handles on the dataset-ingest host code (pvio_amd/host/{undistort_maps,image_io,dataset_reader}.*)
 // for the Python tests.
 #include <cstdint>
+#include <chrono>
 #include <cstring>
 #include <string>
 
@@ -108,6 +109,69 @@ int host_dataset_walk(const char *uri, int max_events, int32_t *types, double *t
                 auto [t, v] = reader->read_accelerometer();
                 times[n] = t, values[3 * n] = v[0], values[3 * n + 1] = v[1], values[3 * n + 2] = v[2];
             }
+            ++n;
+        }
+    } catch (const std::exception &e) {
+        set_err(err, err_len, e.what());
+        n = -1;
+    }
+    pvio_hip_destroy(ctx);
+    return n;
+}
+
+// A reduced FeatureTracker::work loop (core/feature_tracker.cpp:37-130) over a sequence: every image is read, undistorted and
+// preprocessed on the device, the keypoints of the previous image are tracked into it (device LK + border gate + host RANSAC),
+// survivors are kept and new corners detected where there is room.  per_frame[k] = {tracked in, survived, total after
+// detection, milliseconds}; mean_flow[k] = mean displacement of the survivors.  Returns the number of images or -1.
+int host_replay_front_end(const char *uri, int max_frames, double keypoint_distance, int32_t *per_frame /* [max_frames][3] */, double *ms /* [max_frames] */,
+                          double *mean_flow /* [max_frames][2] */, char *err, int err_len) {
+    pvio_hip_ctx *ctx = nullptr;
+    pvio_hip_opts opts;
+    std::memset(&opts, 0, sizeof(opts));
+    if (pvio_hip_create(&opts, &ctx) != 0 || !ctx) {
+        set_err(err, err_len, "pvio_hip_create failed (no GPU?)");
+        return -1;
+    }
+    int n = 0;
+    try {
+        auto reader = DatasetReader::create_reader(uri, ctx);
+        if (!reader) throw std::runtime_error("unknown dataset scheme");
+        std::shared_ptr<Image> prev;
+        std::vector<vector<2>> kps;
+        for (;;) {
+            const DatasetReader::NextDataType type = reader->next();
+            if (type == DatasetReader::END || n >= max_frames) break;
+            if (type == DatasetReader::GYROSCOPE) {
+                reader->read_gyroscope();
+                continue;
+            }
+            if (type == DatasetReader::ACCELEROMETER) {
+                reader->read_accelerometer();
+                continue;
+            }
+            const auto t0 = std::chrono::steady_clock::now();
+            std::shared_ptr<Image> cur = reader->read_image();
+            cur->preprocess();
+            int tracked_in = (int)kps.size(), survived = 0;
+            double fx = 0, fy = 0;
+            if (prev && !kps.empty()) {
+                std::vector<vector<2>> next; // no initial flow: starts from the previous positions
+                std::vector<char> status;
+                prev->track_keypoints(cur.get(), kps, next, status);
+                std::vector<vector<2>> kept;
+                for (size_t i = 0; i < kps.size(); ++i)
+                    if (status[i]) {
+                        fx += next[i][0] - kps[i][0], fy += next[i][1] - kps[i][1];
+                        kept.push_back(next[i]);
+                    }
+                survived = (int)kept.size();
+                kps.swap(kept);
+            }
+            cur->detect_keypoints(kps, 0, keypoint_distance); // appends corners that keep their distance to the existing ones
+            per_frame[3 * n] = tracked_in, per_frame[3 * n + 1] = survived, per_frame[3 * n + 2] = (int32_t)kps.size();
+            mean_flow[2 * n] = survived ? fx / survived : 0.0, mean_flow[2 * n + 1] = survived ? fy / survived : 0.0;
+            ms[n] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            prev = cur;
             ++n;
         }
     } catch (const std::exception &e) {

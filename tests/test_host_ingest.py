@@ -346,3 +346,55 @@ def test_tum_writer_format(host, tmp_path):
         want = " ".join("%.15g" % v for v in [t[k], *p[k], *q[k]])   # ostream << double with precision(15), default float format
         assert lines[k] == want
     assert host.host_tum_write(str(tmp_path / "no" / "dir" / "x.tum").encode(), C.c_int(0), _p(t, f64p), _p(p, f64p), _p(q, f64p)) == -1
+
+
+# ---- end to end: reader -> device undistortion / pyramid -> LK + RANSAC -> detection, frame after frame ---------------------
+def _moving_sequence(n_frames, w, h, shift):
+    """Frames cut out of one band-limited texture, the window moving by `shift` pixels per frame (a pure image translation)."""
+    from pvio_amd import synth
+    big, *_ = synth.make_image_pair(w + 64, h + 64, 8)
+    return [np.ascontiguousarray(big[16 + k * shift[1]:16 + k * shift[1] + h, 16 + k * shift[0]:16 + k * shift[0] + w]) for k in range(n_frames)]
+
+
+def _replay(lib, uri, max_frames, distance):
+    per = np.zeros((max_frames, 3), np.int32)
+    ms, flow = np.zeros(max_frames), np.zeros((max_frames, 2))
+    err = C.create_string_buffer(512)
+    lib.host_replay_front_end.restype = C.c_int
+    n = lib.host_replay_front_end(uri.encode(), C.c_int(max_frames), C.c_double(distance), _p(per, i32p), _p(ms, f64p), _p(flow, f64p), err, C.c_int(512))
+    assert n >= 0, err.value.decode()
+    return n, per[:n], ms[:n], flow[:n]
+
+
+def _check_replay(lib, tmp_path, w, h, n_frames, shift):
+    frames = _moving_sequence(n_frames, w, h, shift)
+    t0 = 1520530308199447626
+    root = tmp_path / "seq"
+    _write_sequence(root, False, frames, [t0 + 50000000 * k for k in range(n_frames)], [(t0 - 1000000 + 5000000 * k, 0, 0, 0, 0, 0, 9.8) for k in range(10 * n_frames)])
+    n, per, ms, flow = _replay(lib, "tum://" + str(root), n_frames, 20.0)
+    assert n == n_frames
+    assert per[0, 0] == 0 and per[0, 2] >= 10                       # the first frame only detects
+    for k in range(1, n):
+        assert per[k, 0] == per[k - 1, 2]                            # everything known goes into the tracker
+        assert per[k, 1] >= 0.6 * per[k, 0]                          # most of it survives LK, the border gate and RANSAC
+        assert per[k, 2] >= per[k, 1]                                # detection only adds
+    return per, ms, flow
+
+
+def test_emulated_front_end_replay(host, tmp_path):
+    per, ms, flow = _check_replay(host, tmp_path, 320, 320, 3, (2, 1))  # large enough to hold the TUM-VI principal point
+    assert per[-1, 1] > 0
+
+
+@pytest.mark.gpu
+def test_gpu_front_end_replay(tmp_path):
+    """A TUM-VI-sized sequence through the whole front end on the device: the window moves by (-3, -2) px per frame in image
+    coordinates of the undistorted centre region; reports the per-frame time."""
+    lib = host_compare.load("libpvio_host.so")
+    per, ms, flow = _check_replay(lib, tmp_path, 512, 512, 8, (3, 2))
+    # the scene content moves against the window by (-3, -2) px per frame of the DISTORTED image; undistorting the fisheye
+    # model magnifies the image centre (by about 1.5 for the TUM-VI constants), so the measured flow is that vector scaled:
+    # same direction, the same from frame to frame
+    assert np.all(flow[1:, 0] < -3) and np.all(flow[1:, 0] > -6) and np.all(flow[1:, 1] < -2) and np.all(flow[1:, 1] > -4), flow
+    assert np.all(np.abs(flow[1:, 0] / flow[1:, 1] - 1.5) < 0.1) and np.ptp(flow[1:, 0]) < 0.3, flow
+    print("front end replay 512x512: tracks", per[:, 2].tolist(), "ms/frame (decode + upload + undistort + pyramid + LK + RANSAC + detect)", np.round(ms, 2).tolist())
