@@ -66,18 +66,24 @@ GrayImage decode_png_gray(const uint8_t *data, size_t size) {
         uint8_t *cur = raw.data() + (size_t)y * (row + 1) + 1;
         const uint8_t *up = y ? cur - (row + 1) : zero.data();
         const int ft = cur[-1];
-        for (size_t i = 0; i < row; ++i) {
-            const int a = i >= bpp ? cur[i - bpp] : 0, b = up[i], c = i >= bpp ? up[i - bpp] : 0;
-            int pred;
-            switch (ft) {
-            case 0: pred = 0; break;
-            case 1: pred = a; break;
-            case 2: pred = b; break;
-            case 3: pred = (a + b) >> 1; break;
-            case 4: pred = paeth(a, b, c); break;
-            default: throw std::runtime_error("png: bad filter type");
-            }
-            cur[i] = (uint8_t)(cur[i] + pred);
+        // one loop per filter type (the branch is per scanline, not per byte); bytes left of the first pixel predict from 0
+        switch (ft) {
+        case 0: break;
+        case 1:
+            for (size_t i = bpp; i < row; ++i) cur[i] = (uint8_t)(cur[i] + cur[i - bpp]);
+            break;
+        case 2:
+            for (size_t i = 0; i < row; ++i) cur[i] = (uint8_t)(cur[i] + up[i]);
+            break;
+        case 3:
+            for (size_t i = 0; i < bpp && i < row; ++i) cur[i] = (uint8_t)(cur[i] + (up[i] >> 1));
+            for (size_t i = bpp; i < row; ++i) cur[i] = (uint8_t)(cur[i] + ((cur[i - bpp] + up[i]) >> 1));
+            break;
+        case 4:
+            for (size_t i = 0; i < bpp && i < row; ++i) cur[i] = (uint8_t)(cur[i] + paeth(0, up[i], 0));
+            for (size_t i = bpp; i < row; ++i) cur[i] = (uint8_t)(cur[i] + paeth(cur[i - bpp], up[i], up[i - bpp]));
+            break;
+        default: throw std::runtime_error("png: bad filter type");
         }
     }
     GrayImage img;
