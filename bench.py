@@ -18,6 +18,7 @@ Extra objects on the JSON line:
                 hipEvents on the solver's own stream (pvio_hip_ba_profile_resident), against the 8 TB/s HBM peak.
   scaling_window  the 10 KF x 50 000 landmark VIO window (the one north_star states the 8-GPU target on), sharded the
                 same way, a few solves: its iterations/s at this N next to the headline value.
+  api           the same window through pvio_hip_ba_solve (upload + iterations + download per solve): the H2D/D2H-inclusive rate.
   cpu_baseline  the CPU oracle (oracle/, a single-threaded restatement of the reference's Ceres path; the real
                 reference cannot be built here) timed on the same window on this box's host cores.
 """
@@ -276,6 +277,23 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    # ---- "API" rate: complete solves as the tracker issues them -- upload of the window (H2D), the iterations, the
+    # states read back (D2H) -- next to the resident rate above ----
+    api = None
+    if rank == 0 and world == 1 and not args.force_sharded:
+        n_api = max(10, min(args.steps, 100))
+        for _ in range(3):
+            ctx.solve(pb, trace=False)
+        t1 = time.perf_counter()
+        api_iters = 0
+        for _ in range(n_api):
+            _, sm_api = ctx.solve(pb, trace=False)
+            api_iters += sm_api.num_iterations
+        t_api = time.perf_counter() - t1
+        api = {"value": api_iters / t_api, "unit": "iterations/s", "ms_per_solve": 1e3 * t_api / n_api, "solves": n_api,
+               "what": "pvio_hip_ba_solve: upload (one staged DMA) + iterations + download of the states, same window"}
+        ctx.upload(pb)  # back to the resident state the legs below expect
+
     # ---- roofline leg: per-kernel durations from hipEvents on the solver's stream ----
     prof = ctx.profile_resident(BASummary(pb, trace=False))
     prof = ctx.profile_resident(BASummary(pb, trace=False))
@@ -347,6 +365,7 @@ def main():
                        "graph": (not args.no_graph) and not sharded},
             "iterations_per_solve": iters / args.steps,
             "device_ms_per_step": 1e3 * dev_s / args.steps,
+            "api": api,
             "roofline": roofline,
             "cpu_baseline": cpu,
             "klt": klt,
