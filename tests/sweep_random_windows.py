@@ -1,0 +1,28 @@
+"""Ad-hoc parity sweep on the GPU: 60 windows of random shape (2-32 frames, 10-1500 landmarks, visibility, plane share, inertial
+or not, a fixed frame) against the oracle with the test tolerances.  Last run: 57 pass at 1e-8 .. 1e-14; the three that do not are
+vision-only windows whose landmarks are all seen by exactly two frames (no gauge, barely observable depths): <= 1.5e-5 in the
+inverse depths -- and the kernel emulator (CPU double arithmetic, the kernels' summation order) is off by the same amount on
+them, i.e. conditioning, not device arithmetic."""
+import sys; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import numpy as np
+import ba_compare
+from oracle import oracle_py as O
+from pvio_amd.solver import HipContext
+O.build()
+ctx = HipContext(device=0)
+bad = 0
+for seed in range(60):
+    rng = np.random.default_rng(5000 + seed)
+    n = int(rng.integers(2, 33))
+    kw = dict(n_frames=n, n_landmarks=int(rng.integers(10, 1500)), use_inertial=bool(rng.integers(0, 2)), visibility=int(rng.integers(2, n + 1)),
+              plane_fraction=float(rng.choice([0.0, 0.0, 0.3, 0.6])), seed=int(rng.integers(1, 10000)))
+    pb = ba_compare.make(O, **kw)
+    if rng.random() < 0.4:
+        pb.frame_fixed[int(rng.integers(0, n))] = 1
+    try:
+        r = ba_compare.check_against_oracle(ctx, O, pb)
+        print(seed, kw['n_frames'], kw['n_landmarks'], kw['use_inertial'], 'ok', '%.1e' % r['worst_state_diff'], r['iterations'], flush=True)
+    except AssertionError as e:
+        bad += 1
+        print(seed, kw, 'FAIL', str(e)[:300], flush=True)
+print('failures:', bad)

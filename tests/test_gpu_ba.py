@@ -208,3 +208,18 @@ def test_gpu_sharded_path_without_communicator_fails_loudly(oracle):
             ctx.solve(ba_compare.make(oracle, **ba_compare.CASES["vision_small"]))
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_gpu_random_windows_match_oracle(gpu_ctx, oracle, seed):
+    """Windows of random shape (frames, landmarks, visibility, plane share, inertial or not, fixed frames) beyond the named
+    cases: same iteration-by-iteration agreement with the oracle."""
+    import numpy as np
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(3, 15))
+    kw = dict(n_frames=n, n_landmarks=int(rng.integers(20, 500)), use_inertial=bool(rng.integers(0, 2)), visibility=int(rng.integers(2, n + 1)),
+              plane_fraction=float(rng.choice([0.0, 0.0, 0.3, 0.6])), seed=int(rng.integers(1, 10000)))
+    pb = ba_compare.make(oracle, **kw)
+    if rng.random() < 0.4:
+        pb.frame_fixed[int(rng.integers(0, n))] = 1
+    print(kw, ba_compare.check_against_oracle(gpu_ctx, oracle, pb))
