@@ -42,6 +42,7 @@ class Klt {
     size_t src_cap_ = 0;
     void *d_det_ = nullptr; // detection scratch: cov planes, response map, candidates
     size_t det_cap_ = 0;
+    void *det_host_ = nullptr;         // pinned: counts + the first slice of the candidate list
     std::vector<uint64_t> det_keys_;   // (response bits, address) keys of the candidates, reused
     std::vector<int> det_grid_cnt_;    // minimum-distance grid of the selection, reused
     std::vector<float> det_grid_xy_;

@@ -459,6 +459,7 @@ Klt::~Klt() {
     if (d_det_) (void)hipFree(d_det_);
     if (d_src_) (void)hipFree(d_src_);
     if (h_pts_) (void)hipHostFree(h_pts_);
+    if (det_host_) (void)hipHostFree(det_host_);
     for (auto &s : slab_pool_) (void)hipFree(s.second);
     if (staging_) (void)hipHostFree(staging_);
     if (ev0_) (void)hipEventDestroy(ev0_);
@@ -878,18 +879,37 @@ int Klt::detect(const Image *img, int max_corners, double quality, double min_di
     }
     static const bool timing = getenv("PVIO_KLT_TIMING") != nullptr; // diagnostics: where a detect() call spends its time
     const auto tt0 = std::chrono::steady_clock::now();
-    int hs[3] = {0, 0, 0};
-    bool ok = hipMemcpyAsync(hs, scal, 12, hipMemcpyDeviceToHost, stream_) == hipSuccess && hipStreamSynchronize(stream_) == hipSuccess && hipGetLastError() == hipSuccess;
+    // counts and a first slice of the list come back together (one synchronization); a longer list costs a second round
+    constexpr int kFirst = 4096;
+    if (!det_host_) {
+        if (hipHostMalloc(&det_host_, 16 + (size_t)kFirst * 8) != hipSuccess) {
+            err_ = "hipHostMalloc failed";
+            return PVIO_ERR_OUT_OF_MEMORY;
+        }
+    }
+    int *hs = static_cast<int *>(det_host_);
+    float *h_val = reinterpret_cast<float *>(hs + 4);
+    int *h_pos = reinterpret_cast<int *>(h_val + kFirst);
+    const int first = std::min(kFirst, cap);
+    bool ok = hipMemcpyAsync(hs, scal, 12, hipMemcpyDeviceToHost, stream_) == hipSuccess;
+    ok = ok && hipMemcpyAsync(h_val, list_val, (size_t)first * 4, hipMemcpyDeviceToHost, stream_) == hipSuccess;
+    ok = ok && hipMemcpyAsync(h_pos, list_pos, (size_t)first * 4, hipMemcpyDeviceToHost, stream_) == hipSuccess;
+    ok = ok && hipStreamSynchronize(stream_) == hipSuccess && hipGetLastError() == hipSuccess;
     if (ok && hs[1] > cap) {
         err_ = "too many corner candidates"; // a quarter of the pixels: the 3 x 3 non-maximum suppression cannot produce more
         return PVIO_ERR_UNSUPPORTED;
     }
-    const int nc = std::min(hs[count_slot], cap);
+    const int nc = ok ? std::min(hs[count_slot], cap) : 0;
     std::vector<float> val((size_t)nc);
     std::vector<int> pos((size_t)nc);
     if (ok && nc > 0) {
-        ok = hipMemcpyAsync(val.data(), list_val, (size_t)nc * 4, hipMemcpyDeviceToHost, stream_) == hipSuccess;
-        ok = ok && hipMemcpyAsync(pos.data(), list_pos, (size_t)nc * 4, hipMemcpyDeviceToHost, stream_) == hipSuccess && hipStreamSynchronize(stream_) == hipSuccess;
+        const int got = std::min(nc, first);
+        std::memcpy(val.data(), h_val, (size_t)got * 4), std::memcpy(pos.data(), h_pos, (size_t)got * 4);
+        if (nc > got) {
+            ok = hipMemcpyAsync(val.data() + got, list_val + got, (size_t)(nc - got) * 4, hipMemcpyDeviceToHost, stream_) == hipSuccess;
+            ok = ok && hipMemcpyAsync(pos.data() + got, list_pos + got, (size_t)(nc - got) * 4, hipMemcpyDeviceToHost, stream_) == hipSuccess &&
+                 hipStreamSynchronize(stream_) == hipSuccess;
+        }
     }
     if (!ok) {
         err_ = "corner detection failed";
