@@ -126,6 +126,21 @@ def marginalize(problem, state, victim, want_info=True):
     return S, s, IM, iv
 
 
+def post_passes(problem, frame_state, t):
+    """bundle_adjustor.cpp:251-296 on the flat track table `t` (tests/host_compare.flat_tracks); updates valid / plane / inv_depth /
+    quality / membership in place"""
+    L = lib()
+    pbc = problem.as_c()
+    u8p, i32p, i64p = C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.POINTER(C.c_int64)
+    fs = np.ascontiguousarray(frame_state, float)
+    L.oracle_post_passes.restype = C.c_int
+    rc = L.oracle_post_passes(C.byref(pbc), _d(fs), C.c_int32(len(t["ptr"]) - 1), t["ptr"].ctypes.data_as(i32p), t["frame"].ctypes.data_as(i32p),
+                              _d(t["z"]), t["life"].ctypes.data_as(i64p), t["valid"].ctypes.data_as(u8p), t["plane"].ctypes.data_as(u8p),
+                              _d(t["inv_depth"]), _d(t["quality"]), C.c_int32(len(t["distance"])), _d(t["normal"]), _d(t["distance"]),
+                              t["membership"].ctypes.data_as(u8p))
+    assert rc == 0
+
+
 def reprojection_error(problem, state):
     pb, st = problem.as_c(), state.as_c()
     out = np.zeros(1)

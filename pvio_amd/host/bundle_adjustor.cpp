@@ -1,20 +1,20 @@
 // bundle_adjustor.cpp -- pvio::BundleAdjustor on top of the HIP C-ABI (include/pvio_hip.h).
 //
-// Drop-in for pvio/src/pvio/estimation/bundle_adjustor.cpp: same class, same three methods, same in-place semantics
-// (states are read from and written back into Frame::pose/motion and Track::landmark), same return value
-// (IsSolutionUsable(), :298), no exceptions.  What it does NOT contain any more: ceres::Problem assembly and
-// ceres::Solve -- the Map is flattened, in the reference's residual-block order, into a pvio_ba_problem and handed to
-// the GPU.  Host-side passes that are map bookkeeping stay here (plane re-validation :251-275 needs
-// PlaneExtractor/triangulation, which live outside this seam).
-#ifdef PVIO_HOST_USE_REFERENCE_TYPES
-#include <pvio/estimation/bundle_adjustor.h>
-#include <pvio/map/frame.h>
-#include <pvio/map/map.h>
-#include <pvio/map/plane.h>
-#include <pvio/map/track.h>
-#else
-#include "pvio_min.h"
-#endif
+// Drop-in for pvio/src/pvio/estimation/bundle_adjustor.cpp: same class (pimpl included, bundle_adjustor.h:29-42), same
+// three methods, same in-place semantics (states are read from and written back into Frame::pose/motion and
+// Track::landmark, flags and Plane::tracks are updated like :251-296), same return value (IsSolutionUsable(), :298), no
+// exceptions.  What it does NOT contain any more: ceres::Problem assembly and ceres::Solve -- the Map is flattened, in the
+// reference's residual-block order, into a pvio_ba_problem and handed to the GPU.
+//
+// ONE source, two builds (host_seam.h): against the reference's real headers inside the PVIO tree
+// (-DPVIO_HOST_USE_REFERENCE_TYPES; `make -C tests/host refcheck` proves that it compiles there), and against the
+// look-alike declarations of pvio_min.h for the standalone tests.  Only members that exist in the reference are used:
+// frame->image->t, get_preintegration_factor(), Track::flag(f) = v, Factor::create_marginalization_error,
+// Map::set/get_marginalization_factor, MarginalizationErrorCost::related_frames() (+ the four accessors of the Ceres-free
+// holder, dropin/.../marginalization_error_cost.h), Track::try_triangulate / set_landmark_point / get_landmark_point,
+// PlaneExtractor::enough_baseline, Frame::get_pose.  Eigen objects are touched through (i, j), [i], .data() of vectors,
+// .coeffs(), .dot() only; every matrix crosses the C ABI element by element (the ABI is row-major, Eigen column-major).
+#include "host_seam.h"
 
 #include <cmath>
 #include <cstdio>
@@ -43,6 +43,7 @@ pvio_hip_ctx *process_ctx() {
         pvio_hip_opts o;
         std::memset(&o, 0, sizeof o);
         o.world_size = 1, o.use_graph = 1;
+        if (const char *dev = std::getenv("PVIO_HIP_DEVICE")) o.device = std::atoi(dev); // one ctx per process and GPU
         if (pvio_hip_create(&o, &ctx) != PVIO_OK) {
             std::fprintf(stderr, "[pvio-hip] no usable GPU context: BundleAdjustor::solve will report failure\n");
             ctx = nullptr;
@@ -56,6 +57,8 @@ struct Flat { // owns the arrays a pvio_ba_problem points into
     std::vector<double> cam, imu, sic, intr, fstate, lm_z, obs_z, rho, pre_delta, pre_U, pre_jac, prior_S, prior_s, prior_lin, plane_z, plane_n, plane_d;
     std::vector<int32_t> lm_anchor, lm_ptr, obs_frame, prior_frames, plane_ptr, plane_frame;
     std::vector<Track *> lm_track; // landmark index -> track (write-back)
+    std::vector<double> quality;
+    std::vector<uint8_t> valid;
     pvio_ba_problem pb;
 };
 
@@ -134,9 +137,12 @@ class PtrSet {
     size_t used_ = 0;
 };
 
-void put_q(std::vector<double> &v, size_t off, quaternion &q) {
-    const double *c = q.coeffs().data();
-    for (int k = 0; k < 4; ++k) v[off + k] = c[k];
+void put_q(std::vector<double> &v, size_t off, const quaternion &q) {
+    for (int k = 0; k < 4; ++k) v[off + k] = q.coeffs()[k]; // x y z w
+}
+void put_m3(std::vector<double> &v, size_t off, const matrix<3> &m) { // -> row-major
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) v[off + 3 * r + c] = m(r, c);
 }
 
 // The reference's block order: frames in map index order (:75-88); inverse depths by first encounter scanning frames then
@@ -165,17 +171,13 @@ void flatten(Map *map, Config *config, bool use_inertial, bool for_marginalizati
     }
     // planes with >= 20 tracks constrain their best-plane tracks through the plane-distance factor; tracks of smaller
     // planes fall back to plain reprojection blocks (:165-195)
-    std::unordered_set<Track *> small_plane_tracks;
     std::vector<std::pair<Track *, Plane *>> plane_factors;
     if (!for_marginalization)
         for (size_t i = 0; i < map->plane_num(); ++i) {
             Plane *pl = map->get_plane(i);
-            if (pl->tracks.size() < 20) {
-                for (Track *t : pl->tracks) small_plane_tracks.insert(t);
-            } else {
-                for (Track *t : pl->tracks)
-                    if (t->landmark.plane_id == pl->id()) plane_factors.emplace_back(t, pl);
-            }
+            if (pl->tracks.size() < 20) continue;
+            for (Track *t : pl->tracks)
+                if (t->landmark.plane_id == pl->id()) plane_factors.emplace_back(t, pl); // only under its best plane (:183)
         }
     static thread_local PtrSet visited; // keeps its table between solves
     visited.reset(F.lm_track.size());
@@ -229,34 +231,44 @@ void flatten(Map *map, Config *config, bool use_inertial, bool for_marginalizati
     if (use_inertial || for_marginalization)
         for (int j = 1; j < N; ++j) {
             Frame *fi = map->get_frame(j - 1), *fj = map->get_frame(j);
-            bool ok = for_marginalization ? fj->has_preintegration_factor : fj->preintegration.integrate(fj->image_t, fi->motion.bg, fi->motion.ba, true, true);
+            const bool ok = for_marginalization ? fj->get_preintegration_factor() != nullptr
+                                                : fj->preintegration.integrate(fj->image->t, fi->motion.bg, fi->motion.ba, true, true);
             if (!ok) continue;
             F.pre_valid[j] = 1;
-            auto &d = fj->preintegration.delta;
+            const PreIntegrator::Delta &d = fj->preintegration.delta;
             F.pre_delta[11 * j] = d.t;
             put_q(F.pre_delta, 11 * j + 1, d.q);
             for (int k = 0; k < 3; ++k) F.pre_delta[11 * j + 5 + k] = d.p[k], F.pre_delta[11 * j + 8 + k] = d.v[k];
-            std::memcpy(&F.pre_U[225 * j], d.sqrt_inv_cov, sizeof d.sqrt_inv_cov);
-            auto &jc = fj->preintegration.jacobian;
-            std::memcpy(&F.pre_jac[45 * j], jc.dq_dbg, 72), std::memcpy(&F.pre_jac[45 * j + 9], jc.dp_dbg, 72);
-            std::memcpy(&F.pre_jac[45 * j + 18], jc.dp_dba, 72), std::memcpy(&F.pre_jac[45 * j + 27], jc.dv_dbg, 72), std::memcpy(&F.pre_jac[45 * j + 36], jc.dv_dba, 72);
+            for (int r = 0; r < 15; ++r)
+                for (int c = 0; c < 15; ++c) F.pre_U[225 * j + 15 * r + c] = d.sqrt_inv_cov(r, c);
+            const PreIntegrator::Jacobian &jc = fj->preintegration.jacobian;
+            put_m3(F.pre_jac, 45 * j, jc.dq_dbg), put_m3(F.pre_jac, 45 * j + 9, jc.dp_dbg), put_m3(F.pre_jac, 45 * j + 18, jc.dp_dba);
+            put_m3(F.pre_jac, 45 * j + 27, jc.dv_dbg), put_m3(F.pre_jac, 45 * j + 36, jc.dv_dba);
         }
-    // marginalization prior (:126-139)
+    // marginalization prior (:126-139): S, s, the related frames and the linearization states the holder captured
     F.prior_frames.clear(), F.prior_S.clear(), F.prior_s.clear(), F.prior_lin.clear();
-    if (MarginalizationPrior *pr = map->get_marginalization_factor()) {
-        for (size_t i = 0; i < pr->frames.size(); ++i) {
-            const int pf = fidx.find(pr->frames[i]);
-            if (pf < 0) throw std::out_of_range("marginalization prior refers to a frame outside the window"); // unordered_map::at threw here too
+    if (Factor *mf = map->get_marginalization_factor()) {
+        const MarginalizationErrorCost *mc = mf->get_cost_function<MarginalizationErrorCost>();
+        const std::vector<Frame *> &rel = mc->related_frames();
+        for (size_t i = 0; i < rel.size(); ++i) {
+            const int pf = fidx.find(rel[i]);
+            if (pf < 0) throw std::out_of_range("marginalization prior refers to a frame outside the window"); // unordered_map::at threw here too; caught by the callers
             F.prior_frames.push_back(pf);
             const size_t o = F.prior_lin.size();
             F.prior_lin.resize(o + 16);
-            put_q(F.prior_lin, o, pr->pose_0[i].q);
-            for (int k = 0; k < 3; ++k) {
-                F.prior_lin[o + 4 + k] = pr->pose_0[i].p[k], F.prior_lin[o + 7 + k] = pr->motion_0[i].v[k];
-                F.prior_lin[o + 10 + k] = pr->motion_0[i].bg[k], F.prior_lin[o + 13 + k] = pr->motion_0[i].ba[k];
-            }
+            const PoseState &p0 = mc->linearization_pose(i);
+            const MotionState &m0 = mc->linearization_motion(i);
+            put_q(F.prior_lin, o, p0.q);
+            for (int k = 0; k < 3; ++k) F.prior_lin[o + 4 + k] = p0.p[k], F.prior_lin[o + 7 + k] = m0.v[k], F.prior_lin[o + 10 + k] = m0.bg[k], F.prior_lin[o + 13 + k] = m0.ba[k];
         }
-        F.prior_S = pr->sqrt_infomat, F.prior_s = pr->sqrt_infovec;
+        const matrix<> &S = mc->sqrt_information();
+        const vector<> &sv = mc->information_vector();
+        const size_t D = 15 * rel.size();
+        F.prior_S.resize(D * D), F.prior_s.resize(D);
+        for (size_t r = 0; r < D; ++r) {
+            F.prior_s[r] = sv[r];
+            for (size_t c = 0; c < D; ++c) F.prior_S[r * D + c] = S(r, c);
+        }
     }
     pvio_ba_problem &pb = F.pb;
     std::memset(&pb, 0, sizeof pb);
@@ -277,30 +289,67 @@ void flatten(Map *map, Config *config, bool use_inertial, bool for_marginalizati
     pb.max_solver_time = config->solver_time_limit();
 }
 
-struct DefaultConfig : Config {};
-
-} // namespace
-
-#ifndef PVIO_HOST_USE_REFERENCE_TYPES
-bool PreIntegrator::integrate(double t, const vector<3> &bg, const vector<3> &ba, bool, bool) { // preintegrator.cpp:84-96
-    if (data.empty()) return false;
-    std::vector<double> ts(data.size()), w(3 * data.size()), a(3 * data.size());
-    for (size_t i = 0; i < data.size(); ++i) {
-        ts[i] = data[i].t;
-        for (int k = 0; k < 3; ++k) w[3 * i + k] = data[i].w[k], a[3 * i + k] = data[i].a[k];
+// ---- post-solve passes (bundle_adjustor.cpp:251-296), host side ---------------------------------------------------
+// depth gate + mean pixel error of one track from the map's current states (:279-295); false when the gate fails
+bool track_quality(const Track *track, double &quality) {
+    const vector<3> x = track->get_landmark_point();
+    double sum = 0, num = 0;
+    for (const auto &fk : track->keypoint_map()) {
+        const Frame *frame = fk.first;
+        const PoseState cam = frame->get_pose(frame->camera);
+        const vector<3> y = cam.q.conjugate() * (x - cam.p);
+        if (y.z() <= 1.0e-3 || y.z() > 50) return false;
+        const vector<2> &z = frame->get_keypoint(fk.second);
+        const double du = (y.x() / y.z() * frame->K(0, 0) + frame->K(0, 2)) - (z[0] * frame->K(0, 0) + frame->K(0, 2)); // apply_k, stereo.h:25-27
+        const double dv = (y.y() / y.z() * frame->K(1, 1) + frame->K(1, 2)) - (z[1] * frame->K(1, 1) + frame->K(1, 2));
+        sum += std::sqrt(du * du + dv * dv), num += 1.0;
     }
-    pvio_imu_noise nz;
-    std::memcpy(nz.cov_w, cov_w, 72), std::memcpy(nz.cov_a, cov_a, 72), std::memcpy(nz.cov_bg, cov_bg, 72), std::memcpy(nz.cov_ba, cov_ba, 72);
-    double d[11], jac[45];
-    if (pvio_preintegrate((int32_t)data.size(), ts.data(), w.data(), a.data(), t, bg.data(), ba.data(), &nz, d, delta.cov, delta.sqrt_inv_cov, jac) != PVIO_OK) return false;
-    delta.t = d[0];
-    std::memcpy(delta.q.c, d + 1, 32);
-    for (int k = 0; k < 3; ++k) delta.p[k] = d[5 + k], delta.v[k] = d[8 + k];
-    std::memcpy(jacobian.dq_dbg, jac, 72), std::memcpy(jacobian.dp_dbg, jac + 9, 72), std::memcpy(jacobian.dp_dba, jac + 18, 72);
-    std::memcpy(jacobian.dv_dbg, jac + 27, 72), std::memcpy(jacobian.dv_dba, jac + 36, 72);
+    quality = sum / std::max(num, 1.0);
     return true;
 }
-#endif
+
+// :251-275 -- PLANE tracks that can be triangulated on their own are checked against the planes they sit in (0.1 m): a
+// plane that does not hold the point loses the track, a track that no plane holds goes back to being an ordinary VALID
+// landmark at the triangulated point.  Returns the tracks whose inverse depth it replaced.
+std::vector<Track *> revalidate_plane_tracks(Map *map) {
+    std::vector<Track *> moved;
+    for (size_t i = 0; i < map->track_num(); ++i) {
+        Track *track = map->get_track(i);
+        if (!track->flag(TrackFlag::TF_PLANE)) continue;
+        if (track->keypoint_num() < 2) continue;
+        vector<3> p;
+        if (!(track->life > 10 && PlaneExtractor::enough_baseline(track) && track->try_triangulate(p))) continue;
+        bool held = false;
+        for (size_t j = 0; j < map->plane_num(); ++j) {
+            Plane *plane = map->get_plane(j);
+            if (plane->tracks.count(track) == 0) continue;
+            if (std::abs(plane->parameter.normal.dot(p) - plane->parameter.distance) > 0.1) plane->tracks.erase(track);
+            else held = true;
+        }
+        if (!held) {
+            track->flag(TrackFlag::TF_PLANE) = false;
+            track->flag(TrackFlag::TF_VALID) = true;
+            track->set_landmark_point(p);
+            moved.push_back(track);
+        }
+    }
+    return moved;
+}
+
+struct DefaultConfig : Config { // solver_iteration_limit / solver_time_limit / plane_distance_cov defaults (config.cpp:24-26,82-88)
+    matrix<3> camera_intrinsic() const override { return matrix<3>(); }
+    quaternion camera_to_body_rotation() const override { return quaternion(); }
+    vector<3> camera_to_body_translation() const override { return vector<3>(); }
+    quaternion imu_to_body_rotation() const override { return quaternion(); }
+    vector<3> imu_to_body_translation() const override { return vector<3>(); }
+    matrix<2> keypoint_noise_cov() const override { return matrix<2>(); }
+    matrix<3> gyroscope_noise_cov() const override { return matrix<3>(); }
+    matrix<3> accelerometer_noise_cov() const override { return matrix<3>(); }
+    matrix<3> gyroscope_bias_noise_cov() const override { return matrix<3>(); }
+    matrix<3> accelerometer_bias_noise_cov() const override { return matrix<3>(); }
+};
+
+} // namespace
 
 // diagnostics (tests/host/roundtrip.cpp): seconds per flattening of `map`, steady state (the arrays keep their capacity)
 double flatten_seconds(Map *map, bool use_inertial, int reps) {
@@ -312,93 +361,144 @@ double flatten_seconds(Map *map, bool use_inertial, int reps) {
     return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / (reps > 0 ? reps : 1);
 }
 
-BundleAdjustor::BundleAdjustor() = default;
-BundleAdjustor::~BundleAdjustor() = default;
+struct BundleAdjustor::BundleAdjustorSolver { // the pimpl of bundle_adjustor.h:30,41; the GPU context is process-wide, see process_ctx()
+    Flat F; // a BundleAdjustor temporary lives for one call: the arrays that should keep their capacity are thread_local below
 
-bool BundleAdjustor::solve(Map *map, Config *config, bool use_inertial) {
-    pvio_hip_ctx *ctx = process_ctx();
-    if (!ctx) return false;
-    DefaultConfig dc;
-    static thread_local Flat F; // keeps the capacity of its arrays from one keyframe to the next
-    static const bool timing = std::getenv("PVIO_HIP_TIMING") != nullptr; // diagnostics: host share of a keyframe solve
-    const auto t0 = std::chrono::steady_clock::now();
-    flatten(map, config ? config : &dc, use_inertial, false, F);
-    const auto t1 = std::chrono::steady_clock::now();
-    std::vector<double> quality(F.lm_track.size(), 0.0);
-    std::vector<uint8_t> valid(F.lm_track.size(), 1);
-    pvio_ba_state st{F.fstate.data(), F.rho.data(), quality.data(), valid.data()};
-    pvio_ba_summary sum;
-    std::memset(&sum, 0, sizeof sum);
-    if (pvio_hip_ba_solve(ctx, &F.pb, &st, &sum) != PVIO_OK) {
-        std::fprintf(stderr, "[pvio-hip] ba_solve failed: %s\n", pvio_hip_last_error(ctx));
-        return false;
+    static Flat &window() {
+        static thread_local Flat F; // keeps the capacity of its arrays from one keyframe to the next
+        return F;
     }
-    const auto t2 = std::chrono::steady_clock::now();
-    // write the states back in place, like Ceres does through the parameter-block pointers
-    for (size_t i = 0; i < map->frame_num(); ++i) {
-        Frame *f = map->get_frame(i);
-        double *q = f->pose.q.coeffs().data();
-        for (int k = 0; k < 4; ++k) q[k] = F.fstate[16 * i + k];
-        for (int k = 0; k < 3; ++k) {
-            f->pose.p[k] = F.fstate[16 * i + 4 + k];
-            if (use_inertial || map->get_marginalization_factor()) {
-                f->motion.v[k] = F.fstate[16 * i + 7 + k], f->motion.bg[k] = F.fstate[16 * i + 10 + k], f->motion.ba[k] = F.fstate[16 * i + 13 + k];
+
+    bool solve(Map *map, Config *config, bool use_inertial) {
+        pvio_hip_ctx *ctx = process_ctx();
+        if (!ctx) return false;
+        DefaultConfig dc;
+        Flat &F = window();
+        static const bool timing = std::getenv("PVIO_HIP_TIMING") != nullptr; // diagnostics: host share of a keyframe solve
+        const auto t0 = std::chrono::steady_clock::now();
+        flatten(map, config ? config : &dc, use_inertial, false, F);
+        const auto t1 = std::chrono::steady_clock::now();
+        F.quality.assign(F.lm_track.size(), 0.0), F.valid.assign(F.lm_track.size(), 1);
+        pvio_ba_state st{F.fstate.data(), F.rho.data(), F.quality.data(), F.valid.data()};
+        pvio_ba_summary sum;
+        std::memset(&sum, 0, sizeof sum);
+        if (pvio_hip_ba_solve(ctx, &F.pb, &st, &sum) != PVIO_OK) {
+            std::fprintf(stderr, "[pvio-hip] ba_solve failed: %s\n", pvio_hip_last_error(ctx));
+            return false;
+        }
+        const auto t2 = std::chrono::steady_clock::now();
+        // write the states back in place, like Ceres does through the parameter-block pointers
+        const bool motion_blocks = use_inertial || map->get_marginalization_factor() != nullptr;
+        for (size_t i = 0; i < map->frame_num(); ++i) {
+            Frame *f = map->get_frame(i);
+            for (int k = 0; k < 4; ++k) f->pose.q.coeffs()[k] = F.fstate[16 * i + k];
+            for (int k = 0; k < 3; ++k) {
+                f->pose.p[k] = F.fstate[16 * i + 4 + k];
+                if (motion_blocks) f->motion.v[k] = F.fstate[16 * i + 7 + k], f->motion.bg[k] = F.fstate[16 * i + 10 + k], f->motion.ba[k] = F.fstate[16 * i + 13 + k];
             }
         }
-    }
-    for (size_t l = 0; l < F.lm_track.size(); ++l) {
-        Track *t = F.lm_track[l];
-        t->landmark.inv_depth = F.rho[l];
-        if (!valid[l]) { // depth gate (:286-290)
-            t->set_flag(TrackFlag::TF_VALID, false), t->set_flag(TrackFlag::TF_PLANE, false);
-        } else {
-            t->landmark.quality = quality[l];
+        for (size_t l = 0; l < F.lm_track.size(); ++l) F.lm_track[l]->landmark.inv_depth = F.rho[l];
+        // ---- post-solve passes (:251-296).  The depth gate and the mean pixel error of the flattened landmarks come from the
+        // device (k_quality, evaluated on the final states); the plane-track re-validation and the tracks the device never
+        // saw (PLANE tracks of planes with >= 20 tracks, tracks the re-validation has just moved) are done here. ----
+        const std::vector<Track *> moved = revalidate_plane_tracks(map);
+        static thread_local PtrSet on_device;
+        on_device.reset(F.lm_track.size());
+        for (size_t l = 0; l < F.lm_track.size(); ++l) {
+            Track *t = F.lm_track[l];
+            if (std::find(moved.begin(), moved.end(), t) != moved.end()) continue; // its point changed after the solve
+            if (!t->flag(TrackFlag::TF_VALID) && !t->flag(TrackFlag::TF_PLANE)) continue; // (:279)
+            on_device.insert(t);
+            if (!F.valid[l]) t->flag(TrackFlag::TF_VALID) = false, t->flag(TrackFlag::TF_PLANE) = false; // depth gate (:286-290)
+            else if (t->flag(TrackFlag::TF_VALID)) t->landmark.quality = F.quality[l];                  // (:294-295)
         }
+        for (size_t i = 0; i < map->track_num(); ++i) {
+            Track *t = map->get_track(i);
+            if (!t->flag(TrackFlag::TF_VALID) && !t->flag(TrackFlag::TF_PLANE)) continue;
+            if (on_device.contains(t)) continue;
+            double q = 0;
+            if (!track_quality(t, q)) t->flag(TrackFlag::TF_VALID) = false, t->flag(TrackFlag::TF_PLANE) = false;
+            else if (t->flag(TrackFlag::TF_VALID)) t->landmark.quality = q;
+        }
+        if (timing) {
+            const auto t3 = std::chrono::steady_clock::now();
+            auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+            std::fprintf(stderr, "[pvio-hip] solve: %d frames, %d landmarks, %d factors: flatten %.1f us, upload+solve+download %.1f us (device %.1f us, %d iterations), write-back + post passes %.1f us\n",
+                         F.pb.n_frames, F.pb.n_landmarks, F.pb.n_obs, us(t0, t1), us(t1, t2), 1e6 * sum.device_seconds, sum.num_iterations, us(t2, t3));
+        }
+        return sum.is_usable != 0;
     }
-    if (timing) {
-        const auto t3 = std::chrono::steady_clock::now();
-        auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
-        std::fprintf(stderr, "[pvio-hip] solve: %d frames, %d landmarks, %d factors: flatten %.1f us, upload+solve+download %.1f us (device %.1f us, %d iterations), write-back %.1f us\n",
-                     F.pb.n_frames, F.pb.n_landmarks, F.pb.n_obs, us(t0, t1), us(t1, t2), 1e6 * sum.device_seconds, sum.num_iterations, us(t2, t3));
+
+    void marginalize_frame(Map *map, size_t index) {
+        pvio_hip_ctx *ctx = process_ctx();
+        if (!ctx || index >= map->frame_num() || map->frame_num() < 2) return;
+        DefaultConfig dc;
+        flatten(map, &dc, true, true, F);
+        const size_t n = map->frame_num() - 1, D = 15 * n;
+        std::vector<double> S(D * D, 0.0), s(D, 0.0); // row-major, like the C ABI
+        pvio_ba_state st{F.fstate.data(), F.rho.data(), nullptr, nullptr};
+        pvio_ba_prior out;
+        std::memset(&out, 0, sizeof out);
+        out.S = S.data(), out.s = s.data();
+        if (pvio_hip_ba_marginalize(ctx, &F.pb, &st, (int32_t)index, &out) != PVIO_OK) {
+            std::fprintf(stderr, "[pvio-hip] ba_marginalize failed: %s\n", pvio_hip_last_error(ctx));
+            return;
+        }
+        matrix<> sqrt_infomat;
+        vector<> sqrt_infovec;
+        sqrt_infomat.resize((int)D, (int)D), sqrt_infovec.resize((int)D);
+        for (size_t r = 0; r < D; ++r) {
+            sqrt_infovec[(int)r] = s[r];
+            for (size_t c = 0; c < D; ++c) sqrt_infomat((int)r, (int)c) = S[r * D + c];
+        }
+        std::vector<Frame *> remaining; // linearized at their current states by the holder's constructor (:592-598)
+        for (size_t i = 0; i < map->frame_num(); ++i)
+            if (i != index) remaining.emplace_back(map->get_frame(i));
+        map->set_marginalization_factor(Factor::create_marginalization_error(sqrt_infomat, sqrt_infovec, std::move(remaining)));
     }
-    return sum.is_usable != 0;
+
+    double compute_reprojection_error(Map *map) {
+        pvio_hip_ctx *ctx = process_ctx();
+        if (!ctx) return 0.0;
+        DefaultConfig dc;
+        flatten(map, &dc, false, true, F);
+        pvio_ba_state st{F.fstate.data(), F.rho.data(), nullptr, nullptr};
+        double err = 0;
+        if (pvio_hip_ba_reprojection_error(ctx, &F.pb, &st, &err) != PVIO_OK) return 0.0;
+        return err;
+    }
+};
+
+BundleAdjustor::BundleAdjustor() { solver = std::make_unique<BundleAdjustorSolver>(); }
+BundleAdjustor::~BundleAdjustor() = default;
+
+// The reference's methods do not throw (Ceres reports failure through the summary); neither do these: anything the
+// flattening or the standard library raises (bad_alloc, a prior that names a frame outside the window) ends the call as
+// "not usable" / "no new prior" with one line on stderr.
+bool BundleAdjustor::solve(Map *map, Config *config, bool use_inertial) {
+    try {
+        return solver->solve(map, config, use_inertial);
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "[pvio-hip] BundleAdjustor::solve: %s\n", e.what());
+        return false;
+    }
 }
 
 void BundleAdjustor::marginalize_frame(Map *map, size_t index) {
-    pvio_hip_ctx *ctx = process_ctx();
-    if (!ctx || index >= map->frame_num() || map->frame_num() < 2) return;
-    DefaultConfig dc;
-    Flat F;
-    flatten(map, &dc, true, true, F);
-    const size_t n = map->frame_num() - 1, D = 15 * n;
-    auto pr = std::make_unique<MarginalizationPrior>();
-    pr->sqrt_infomat.assign(D * D, 0.0), pr->sqrt_infovec.assign(D, 0.0);
-    pvio_ba_state st{F.fstate.data(), F.rho.data(), nullptr, nullptr};
-    pvio_ba_prior out;
-    std::memset(&out, 0, sizeof out);
-    out.S = pr->sqrt_infomat.data(), out.s = pr->sqrt_infovec.data();
-    if (pvio_hip_ba_marginalize(ctx, &F.pb, &st, (int32_t)index, &out) != PVIO_OK) {
-        std::fprintf(stderr, "[pvio-hip] ba_marginalize failed: %s\n", pvio_hip_last_error(ctx));
-        return;
+    try {
+        solver->marginalize_frame(map, index);
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "[pvio-hip] BundleAdjustor::marginalize_frame: %s\n", e.what());
     }
-    for (size_t i = 0; i < map->frame_num(); ++i) { // remaining frames, linearized at their current states (:592-598)
-        if (i == index) continue;
-        Frame *f = map->get_frame(i);
-        pr->frames.push_back(f), pr->pose_0.push_back(f->pose), pr->motion_0.push_back(f->motion);
-    }
-    map->set_marginalization_factor(std::move(pr));
 }
 
 double BundleAdjustor::compute_reprojection_error(Map *map) {
-    pvio_hip_ctx *ctx = process_ctx();
-    if (!ctx) return 0.0;
-    DefaultConfig dc;
-    Flat F;
-    flatten(map, &dc, false, true, F);
-    pvio_ba_state st{F.fstate.data(), F.rho.data(), nullptr, nullptr};
-    double err = 0;
-    if (pvio_hip_ba_reprojection_error(ctx, &F.pb, &st, &err) != PVIO_OK) return 0.0;
-    return err;
+    try {
+        return solver->compute_reprojection_error(map);
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "[pvio-hip] BundleAdjustor::compute_reprojection_error: %s\n", e.what());
+        return 0.0;
+    }
 }
 
 } // namespace pvio

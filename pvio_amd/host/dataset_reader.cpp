@@ -203,8 +203,8 @@ TumOutputWriter::TumOutputWriter(const std::string &filename) {
 }
 
 void TumOutputWriter::write_pose(const double &t, const OutputPose &pose) {
-    const double *q = pose.q.coeffs_data(); // x y z w
-    file << t << " " << pose.p[0] << " " << pose.p[1] << " " << pose.p[2] << " " << q[0] << " " << q[1] << " " << q[2] << " " << q[3] << "\n";
+    const quaternion &q = pose.q;
+    file << t << " " << pose.p[0] << " " << pose.p[1] << " " << pose.p[2] << " " << q.x() << " " << q.y() << " " << q.z() << " " << q.w() << "\n";
     file.flush();
 }
 

@@ -18,7 +18,7 @@
 
 #include "../../include/pvio_hip.h"
 #include "feature_front.h"
-#include "pvio_min.h"
+#include "host_seam.h"
 #include "undistort_maps.h"
 
 namespace pvio {
@@ -98,10 +98,6 @@ class TUMDatasetReader : public SequenceReader {
     std::unique_ptr<ImageUndistorter> image_undistorter;
 };
 
-struct OutputPose { // pvio.h: OutputPose { quaternion q; vector<3> p; }
-    quaternion q;
-    vector<3> p;
-};
 class OutputWriter {
   public:
     virtual ~OutputWriter() = default;

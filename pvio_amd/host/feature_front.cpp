@@ -88,7 +88,7 @@ Q qmul(const Q &a, const Q &b) {
              a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w, a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z};
 }
 Q qconj(const Q &a) { return Q{-a.x, -a.y, -a.z, a.w}; }
-Q load(const quaternion &q) { return Q{q.c[0], q.c[1], q.c[2], q.c[3]}; }
+Q load(const quaternion &q) { return Q{q.x(), q.y(), q.z(), q.w()}; }
 void rotate(const Q &q, const double v[3], double out[3]) { // v + 2 w (u x v) + 2 u x (u x v)
     const double ux = q.x, uy = q.y, uz = q.z;
     const double tx = 2.0 * (uy * v[2] - uz * v[1]), ty = 2.0 * (uz * v[0] - ux * v[2]), tz = 2.0 * (ux * v[1] - uy * v[0]);
@@ -103,9 +103,9 @@ void predict_keypoints(const Frame &curr, const Frame &next, std::vector<vector<
     const Q chain = qmul(qmul(qmul(qmul(qconj(load(curr.camera.q_cs)), load(curr.imu.q_cs)), load(next.preintegration.delta.q)), qconj(load(next.imu.q_cs))),
                          load(next.camera.q_cs));
     const Q delta = qconj(chain);
-    next_pixels.resize(curr.keypoints.size());
-    for (size_t i = 0; i < curr.keypoints.size(); ++i) {
-        const double b[3] = {curr.keypoints[i][0], curr.keypoints[i][1], 1.0};
+    next_pixels.resize(curr.keypoint_num());
+    for (size_t i = 0; i < curr.keypoint_num(); ++i) {
+        const double b[3] = {curr.get_keypoint(i)[0], curr.get_keypoint(i)[1], 1.0};
         double r[3];
         rotate(delta, b, r);
         next_pixels[i][0] = (r[0] / r[2]) * next.K(0, 0) + next.K(0, 2);
@@ -145,6 +145,53 @@ void HipImage::preprocess() {
     if (img_) pvio_hip_image_release(ctx_, img_), img_ = nullptr;
     const int32_t rc = pvio_hip_image_create(ctx_, pixels_.data(), w_, h_, w_, /*apply_clahe=*/1, &img_);
     if (rc != 0) throw std::runtime_error(std::string("pvio_hip_image_create: ") + pvio_hip_last_error(ctx_)); // no CPU path
+}
+
+const HipImage::HostLevel &HipImage::host_level(int level) const {
+    if (!img_) throw std::runtime_error("HipImage::evaluate: preprocess() was not called");
+    if (host_levels_.empty()) host_levels_.resize(PVIO_KLT_LEVELS);
+    HostLevel &L = host_levels_.at((size_t)level);
+    if (L.px.empty()) {
+        int32_t w = 0, h = 0;
+        if (pvio_hip_image_download_level(ctx_, img_, level, nullptr, nullptr, &w, &h) != 0) throw std::runtime_error(pvio_hip_last_error(ctx_));
+        L.px.resize((size_t)w * h);
+        if (pvio_hip_image_download_level(ctx_, img_, level, L.px.data(), nullptr, &w, &h) != 0) throw std::runtime_error(pvio_hip_last_error(ctx_));
+        L.w = w, L.h = h;
+    }
+    return L;
+}
+
+namespace {
+// Catmull-Rom segment through p1, p2 (Ceres' CubicHermiteSpline): value and derivative at x in [0, 1]
+inline void cubic(double p0, double p1, double p2, double p3, double x, double &f, double &dfdx) {
+    const double a = 0.5 * (-p0 + 3.0 * p1 - 3.0 * p2 + p3), b = 0.5 * (2.0 * p0 - 5.0 * p1 + 4.0 * p2 - p3), c = 0.5 * (-p0 + p2);
+    f = p1 + x * (c + x * (b + x * a));
+    dfdx = c + x * (2.0 * b + 3.0 * a * x);
+}
+} // namespace
+
+double HipImage::evaluate(const vector<2> &u, vector<2> &ddu, int level) const {
+    const HostLevel &L = host_level(level);
+    // opencv_image.cpp:150-154: the per-level scale is an INTEGER quotient of the extents
+    const double sx = 1.0 / (double)((w_ - 1) / (L.w - 1)), sy = 1.0 / (double)((h_ - 1) / (L.h - 1));
+    const double c = u[0] * sx, r = u[1] * sy;
+    const int row = (int)std::floor(r), col = (int)std::floor(c);
+    auto px = [&](int rr, int cc) { // Grid2D clamps to the image
+        rr = std::min(std::max(rr, 0), L.h - 1), cc = std::min(std::max(cc, 0), L.w - 1);
+        return (double)L.px[(size_t)rr * L.w + cc];
+    };
+    double f[4], dfdc[4];
+    for (int k = 0; k < 4; ++k) cubic(px(row - 1 + k, col - 1), px(row - 1 + k, col), px(row - 1 + k, col + 1), px(row - 1 + k, col + 2), c - col, f[k], dfdc[k]);
+    double val, dfdr, dc, unused;
+    cubic(f[0], f[1], f[2], f[3], r - row, val, dfdr);
+    cubic(dfdc[0], dfdc[1], dfdc[2], dfdc[3], r - row, dc, unused);
+    ddu[0] = dc * sx, ddu[1] = dfdr * sy;
+    return val;
+}
+
+double HipImage::evaluate(const vector<2> &u, int level) const {
+    vector<2> ddu;
+    return evaluate(u, ddu, level);
 }
 
 void HipImage::detect_keypoints(std::vector<vector<2>> &keypoints, size_t max_points, double keypoint_distance) const {

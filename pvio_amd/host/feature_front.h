@@ -20,7 +20,7 @@
 #include <vector>
 
 #include "../../include/pvio_hip.h"
-#include "pvio_min.h"
+#include "host_seam.h"
 
 namespace pvio {
 
@@ -69,6 +69,10 @@ class HipImage : public Image {
     size_t width() const override { return (size_t)w_; }
     size_t height() const override { return (size_t)h_; }
     size_t level_num() const override { return 3; } // opencv_image.h: level_num() = 3 -> maxLevel 3, four levels
+    // bicubic sample of the preprocessed pyramid level (and its gradient), opencv_image.cpp:36-52 (ceres::BiCubicInterpolator
+    // over the level's pixels).  No caller inside the library; the level is copied back from the device on first use.
+    double evaluate(const vector<2> &u, int level = 0) const override;
+    double evaluate(const vector<2> &u, vector<2> &ddu, int level = 0) const override;
     void preprocess() override;
     void detect_keypoints(std::vector<vector<2>> &keypoints, size_t max_points, double keypoint_distance) const override;
     void track_keypoints(const Image *next_image, const std::vector<vector<2>> &curr_keypoints, std::vector<vector<2>> &next_keypoints, std::vector<char> &result_status) const override;
@@ -85,6 +89,12 @@ class HipImage : public Image {
     pvio_hip_image *img_ = nullptr;
 
   private:
+    struct HostLevel {
+        int w = 0, h = 0;
+        std::vector<uint8_t> px;
+    };
+    const HostLevel &host_level(int level) const;
+    mutable std::vector<HostLevel> host_levels_;
     OutlierFilter filter_;
     bool ransac_ = true;
 };

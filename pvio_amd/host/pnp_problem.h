@@ -1,4 +1,4 @@
-// pnp.h -- host `visual_inertial_pnp` without Ceres.
+// pnp_problem.h -- host `visual_inertial_pnp` without Ceres.
 //
 // Reference: pvio/src/pvio/estimation/pnp.cpp:32-100 -- the per-frame pose refinement that runs right before the sliding
 // window bundle adjustment (sliding_window_tracker.cpp:79, initializer.cpp:186) and produces its initial guess: one free
@@ -11,7 +11,6 @@
 #include <vector>
 
 #include "dense_minimizer.h"
-#include "pvio_min.h"
 
 namespace pvio {
 
@@ -35,10 +34,9 @@ struct PnpProblem {
 // minimizes over state16 in place (q, p and -- when inertial -- v, bg, ba)
 dense::Summary solve_pnp(const PnpProblem &pb, double state16[16], int max_iterations);
 
-// the reference's entry point: flattens `frame` against `map` and writes the result back into frame->pose / motion.
-// Built without PVIO_ENABLE_PLANE_CONSTRAINT semantics: PLANE tracks that are VALID take the ordinary factor (the
-// best-plane search of pnp.cpp:61-88 needs the plane extractor, which is outside this seam; callers that resolve the
-// plane point themselves use PnpProblem::point_factors).
-void visual_inertial_pnp(Map *map, Frame *frame, Config *config, bool use_inertial = true);
+// The reference's entry point `void visual_inertial_pnp(Map *, Frame *, Config *, bool use_inertial = true)`
+// (estimation/pnp.h:26) is declared by host_seam.h (the reference's own header inside the PVIO tree) and defined in
+// pnp.cpp: it flattens `frame` against `map` into a PnpProblem -- best-plane search of pnp.cpp:61-88 included -- and writes
+// the result back into frame->pose / motion.
 
 } // namespace pvio

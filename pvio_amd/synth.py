@@ -105,7 +105,7 @@ def _pose(t):
 
 def make_window(n_frames=10, n_landmarks=1000, use_inertial=False, visibility=None, plane_fraction=0.0,
                 seed=SEED, preintegrate=None, kf_dt=0.25, imu_rate=200.0, perturb=True, max_iterations=10,
-                bias_init="near_truth", perturb_scale=None):
+                bias_init="near_truth", perturb_scale=None, plane_outliers=0, plane_outlier_offset=0.3):
     """Builds a BAProblem.  `preintegrate(t, w, a, t_end, bg, ba, noise_dict) -> (delta11, cov225, U225, jac45)`
     is required when use_inertial (the product's pvio_preintegrate or the oracle's).
 
@@ -168,6 +168,11 @@ def make_window(n_frames=10, n_landmarks=1000, use_inertial=False, visibility=No
         for k, (nrm, dist) in enumerate(plane_defs):
             sl = slice(0, half) if k == 0 else slice(half, n_plane)
             pts[sl] = pts[sl] - np.outer(pts[sl] @ nrm - dist, nrm)
+        # a few plane tracks whose true point sits OFF its plane (what the post-solve re-validation of
+        # bundle_adjustor.cpp:251-275 exists for): the first `plane_outliers` tracks of each plane
+        for k, (nrm, dist) in enumerate(plane_defs):
+            o = 0 if k == 0 else half
+            pts[o:o + plane_outliers] += plane_outlier_offset * nrm
 
     # visibility: landmark l is seen in frames [s_l, s_l + K) (contiguous run); anchor = first
     if visibility is None or visibility >= N:

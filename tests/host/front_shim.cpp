@@ -36,12 +36,14 @@ void host_select_tracked(int n, const double *next_xy, const uint64_t *track_len
 void host_predict_keypoints(const double q_cam_i[4], const double q_imu_i[4], const double dq[4], const double q_imu_j[4], const double q_cam_j[4],
                             const double K_next[4], int n, const double *kp_xy, double *out_xy) {
     Frame a, b;
-    std::memcpy(a.camera.q_cs.c, q_cam_i, 32), std::memcpy(a.imu.q_cs.c, q_imu_i, 32);
-    std::memcpy(b.camera.q_cs.c, q_cam_j, 32), std::memcpy(b.imu.q_cs.c, q_imu_j, 32);
-    std::memcpy(b.preintegration.delta.q.c, dq, 32);
+    for (int k = 0; k < 4; ++k) {
+        a.camera.q_cs.coeffs()[k] = q_cam_i[k], a.imu.q_cs.coeffs()[k] = q_imu_i[k];
+        b.camera.q_cs.coeffs()[k] = q_cam_j[k], b.imu.q_cs.coeffs()[k] = q_imu_j[k];
+        b.preintegration.delta.q.coeffs()[k] = dq[k];
+    }
+    b.K.setZero();
     b.K(0, 0) = K_next[0], b.K(1, 1) = K_next[1], b.K(0, 2) = K_next[2], b.K(1, 2) = K_next[3], b.K(2, 2) = 1;
-    a.keypoints.resize((size_t)n);
-    for (int i = 0; i < n; ++i) a.keypoints[i][0] = kp_xy[2 * i], a.keypoints[i][1] = kp_xy[2 * i + 1];
+    for (int i = 0; i < n; ++i) a.append_keypoint(vector<2>(kp_xy[2 * i], kp_xy[2 * i + 1]));
     std::vector<vector<2>> out;
     predict_keypoints(a, b, out);
     for (int i = 0; i < n; ++i) out_xy[2 * i] = out[i][0], out_xy[2 * i + 1] = out[i][1];

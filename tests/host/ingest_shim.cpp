@@ -188,7 +188,7 @@ int host_tum_write(const char *filename, int n, const double *t, const double *p
     for (int i = 0; i < n; ++i) {
         OutputPose pose;
         for (int k = 0; k < 3; ++k) pose.p[k] = p[3 * i + k];
-        for (int k = 0; k < 4; ++k) pose.q.c[k] = q[4 * i + k];
+        for (int k = 0; k < 4; ++k) pose.q.coeffs()[k] = q[4 * i + k];
         w.write_pose(t[i], pose);
     }
     return 0;

@@ -1,58 +1,96 @@
 // roundtrip.cpp -- test harness for the host adapter (pvio_amd/host/bundle_adjustor.cpp): rebuilds a pvio::Map object
-// graph from a flat window, calls pvio::BundleAdjustor exactly like the reference's SlidingWindowTracker does
-// (`BundleAdjustor().solve(map, config, true)`, sliding_window_tracker.cpp:113) and copies the in-place results back.
+// graph from a flat window THROUGH THE REFERENCE'S OWN MAP API (Map::put_frame / create_track, Frame::append_keypoint,
+// Track::add_keypoint, Map::put_plane, Factor::create_marginalization_error), calls pvio::BundleAdjustor exactly like
+// the reference's SlidingWindowTracker does (`BundleAdjustor().solve(map, config, true)`, sliding_window_tracker.cpp:113)
+// and copies the in-place results back.  Written against host_seam.h, i.e. it compiles against the real PVIO headers too
+// (`make refcheck`).
 #include <cstring>
 #include <map>
 #include <utility>
 
 #include "../../include/pvio_hip.h"
-#include "../../pvio_amd/host/pvio_min.h"
+#include "../../pvio_amd/host/host_seam.h"
 
 using namespace pvio;
 
 namespace {
-struct Cfg : Config {
-    size_t iters;
-    double plane_cov;
+struct Cfg : Config { // the reference's Config has ten pure virtuals; the estimation seam reads only the three at the bottom
+    size_t iters = 10;
+    double plane_cov = 1e-4;
+    matrix<3> camera_intrinsic() const override { return matrix<3>(); }
+    quaternion camera_to_body_rotation() const override { return quaternion(); }
+    vector<3> camera_to_body_translation() const override { return vector<3>(); }
+    quaternion imu_to_body_rotation() const override { return quaternion(); }
+    vector<3> imu_to_body_translation() const override { return vector<3>(); }
+    matrix<2> keypoint_noise_cov() const override { return matrix<2>(); }
+    matrix<3> gyroscope_noise_cov() const override { return matrix<3>(); }
+    matrix<3> accelerometer_noise_cov() const override { return matrix<3>(); }
+    matrix<3> gyroscope_bias_noise_cov() const override { return matrix<3>(); }
+    matrix<3> accelerometer_bias_noise_cov() const override { return matrix<3>(); }
     size_t solver_iteration_limit() const override { return iters; }
     double plane_distance_cov() const override { return plane_cov; }
 };
 
-void build_map(const pvio_ba_problem *pb, const pvio_ba_state *st, Map &map, std::vector<Track *> &lm_tracks) {
+struct TimeImage : Image { // the BA seam reads frame->image->t only (bundle_adjustor.cpp:224)
+    explicit TimeImage(double time) { t = time; }
+    size_t width() const override { return 0; }
+    size_t height() const override { return 0; }
+    double evaluate(const vector<2> &, int) const override { return 0; }
+    double evaluate(const vector<2> &, vector<2> &, int) const override { return 0; }
+    void detect_keypoints(std::vector<vector<2>> &, size_t, double) const override {}
+    void track_keypoints(const Image *, const std::vector<vector<2>> &, std::vector<vector<2>> &, std::vector<char> &) const override {}
+};
+
+void set_q(quaternion &q, const double *c) {
+    for (int k = 0; k < 4; ++k) q.coeffs()[k] = c[k];
+}
+void set_state(Frame *f, const double *s) {
+    set_q(f->pose.q, s);
+    for (int k = 0; k < 3; ++k) f->pose.p[k] = s[4 + k], f->motion.v[k] = s[7 + k], f->motion.bg[k] = s[10 + k], f->motion.ba[k] = s[13 + k];
+}
+void get_state(const Frame *f, double *s) {
+    for (int k = 0; k < 4; ++k) s[k] = f->pose.q.coeffs()[k];
+    for (int k = 0; k < 3; ++k) s[4 + k] = f->pose.p[k], s[7 + k] = f->motion.v[k], s[10 + k] = f->motion.bg[k], s[13 + k] = f->motion.ba[k];
+}
+void set_m3(matrix<3> &m, const double *rowmajor) {
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) m(r, c) = rowmajor[3 * r + c];
+}
+
+// Frames 0 .. n_in_map-1 go into the map; later ones (the PnP harness solves a frame BEFORE put_frame) are returned in
+// `loose`.  Frame / track / plane ids are the reference's auto-incrementing ones: creation order = flat order.
+void build_map(const pvio_ba_problem *pb, const pvio_ba_state *st, Map &map, std::vector<Track *> &lm_tracks, int n_in_map = -1,
+               std::vector<std::unique_ptr<Frame>> *loose = nullptr, std::vector<Track *> *plane_tracks = nullptr) {
     const int N = pb->n_frames;
+    if (n_in_map < 0) n_in_map = N;
+    std::vector<Frame *> fr;
     for (int i = 0; i < N; ++i) {
         auto f = std::make_unique<Frame>();
-        f->id_ = i;
-        f->flags[(size_t)FrameFlag::FF_FIX_POSE] = pb->frame_fixed[i] != 0;
-        std::memcpy(f->camera.q_cs.c, pb->cam_extrinsic + 7 * i, 32);
-        std::memcpy(f->imu.q_cs.c, pb->imu_extrinsic + 7 * i, 32);
+        f->flag(FrameFlag::FF_FIX_POSE) = pb->frame_fixed[i] != 0;
+        set_q(f->camera.q_cs, pb->cam_extrinsic + 7 * i), set_q(f->imu.q_cs, pb->imu_extrinsic + 7 * i);
         for (int k = 0; k < 3; ++k) f->camera.p_cs[k] = pb->cam_extrinsic[7 * i + 4 + k], f->imu.p_cs[k] = pb->imu_extrinsic[7 * i + 4 + k];
         f->sqrt_inv_cov(0, 0) = pb->sqrt_inv_cov[4 * i], f->sqrt_inv_cov(0, 1) = pb->sqrt_inv_cov[4 * i + 1];
         f->sqrt_inv_cov(1, 0) = pb->sqrt_inv_cov[4 * i + 2], f->sqrt_inv_cov(1, 1) = pb->sqrt_inv_cov[4 * i + 3];
+        f->K.setZero();
         f->K(0, 0) = pb->intrinsics[4 * i], f->K(1, 1) = pb->intrinsics[4 * i + 1], f->K(0, 2) = pb->intrinsics[4 * i + 2], f->K(1, 2) = pb->intrinsics[4 * i + 3], f->K(2, 2) = 1;
-        const double *s = st->frame_state + 16 * i;
-        std::memcpy(f->pose.q.c, s, 32);
-        for (int k = 0; k < 3; ++k) f->pose.p[k] = s[4 + k], f->motion.v[k] = s[7 + k], f->motion.bg[k] = s[10 + k], f->motion.ba[k] = s[13 + k];
-        map.frames.push_back(std::move(f));
+        set_state(f.get(), st->frame_state + 16 * i);
+        f->image = std::make_shared<TimeImage>(0.0);
+        fr.push_back(f.get());
+        if (i < n_in_map) map.put_frame(std::move(f)); // also creates the pre-integration factor against its predecessor
+        else loose->push_back(std::move(f));
     }
     auto add_kp = [&](Track *t, int frame, const double *z) {
-        Frame *f = map.get_frame(frame);
-        vector<2> kp;
-        kp[0] = z[0], kp[1] = z[1];
-        f->keypoints.push_back(kp);
-        f->tracks.push_back(t);
-        t->keypoint_refs[f] = f->keypoints.size() - 1;
-        t->life++;
+        Frame *f = fr[(size_t)frame];
+        f->append_keypoint(vector<2>(z[0], z[1]));
+        t->add_keypoint(f, f->keypoint_num() - 1);
     };
     for (int l = 0; l < pb->n_landmarks; ++l) {
-        auto t = std::make_unique<Track>();
-        t->id_ = l;
-        t->set_flag(TrackFlag::TF_VALID, true);
+        Track *t = map.create_track();
+        t->flag(TrackFlag::TF_VALID) = true;
         t->landmark.inv_depth = st->lm_inv_depth[l];
-        add_kp(t.get(), pb->lm_anchor_frame[l], pb->lm_anchor_z + 2 * l);
-        for (int o = pb->lm_obs_ptr[l]; o < pb->lm_obs_ptr[l + 1]; ++o) add_kp(t.get(), pb->obs_frame[o], pb->obs_z + 2 * o);
-        lm_tracks.push_back(t.get());
-        map.tracks.push_back(std::move(t));
+        add_kp(t, pb->lm_anchor_frame[l], pb->lm_anchor_z + 2 * l);
+        for (int o = pb->lm_obs_ptr[l]; o < pb->lm_obs_ptr[l + 1]; ++o) add_kp(t, pb->obs_frame[o], pb->obs_z + 2 * o);
+        lm_tracks.push_back(t);
     }
     // plane factors -> PLANE tracks grouped into planes by (normal, distance)
     std::map<std::pair<double, double>, Plane *> planes;
@@ -61,48 +99,61 @@ void build_map(const pvio_ba_problem *pb, const pvio_ba_state *st, Map &map, std
         Plane *pl;
         if (!planes.count(key)) {
             auto p = std::make_unique<Plane>();
-            p->id_ = map.planes.size();
             for (int k = 0; k < 3; ++k) p->parameter.normal[k] = pb->plane_normal[3 * f + k];
             p->parameter.distance = pb->plane_distance[f];
             planes[key] = pl = p.get();
-            map.planes.push_back(std::move(p));
+            map.put_plane(std::move(p));
         } else {
             pl = planes[key];
         }
-        auto t = std::make_unique<Track>();
-        t->id_ = pb->n_landmarks + f;
-        t->set_flag(TrackFlag::TF_PLANE, true);
+        Track *t = map.create_track();
+        t->flag(TrackFlag::TF_PLANE) = true;
         t->landmark.plane_id = pl->id();
         t->landmark.inv_depth = 1.0;
-        for (int o = pb->plane_obs_ptr[f]; o < pb->plane_obs_ptr[f + 1]; ++o) add_kp(t.get(), pb->plane_obs_frame[o], pb->plane_obs_z + 2 * o);
-        pl->tracks.insert(t.get());
-        map.tracks.push_back(std::move(t));
+        for (int o = pb->plane_obs_ptr[f]; o < pb->plane_obs_ptr[f + 1]; ++o) add_kp(t, pb->plane_obs_frame[o], pb->plane_obs_z + 2 * o);
+        pl->tracks.insert(t);
+        if (plane_tracks) plane_tracks->push_back(t);
     }
     if (pb->prior_n > 0) {
-        auto pr = std::make_unique<MarginalizationPrior>();
-        const size_t D = 15 * (size_t)pb->prior_n;
-        pr->sqrt_infomat.assign(pb->prior_S, pb->prior_S + D * D);
-        pr->sqrt_infovec.assign(pb->prior_s, pb->prior_s + D);
-        for (int i = 0; i < pb->prior_n; ++i) {
-            pr->frames.push_back(map.get_frame(pb->prior_frames[i]));
-            PoseState p0;
-            MotionState m0;
-            const double *s = pb->prior_lin_state + 16 * i;
-            std::memcpy(p0.q.c, s, 32);
-            for (int k = 0; k < 3; ++k) p0.p[k] = s[4 + k], m0.v[k] = s[7 + k], m0.bg[k] = s[10 + k], m0.ba[k] = s[13 + k];
-            pr->pose_0.push_back(p0), pr->motion_0.push_back(m0);
+        // the holder captures the linearization states from the frames at construction (marginalization_error_cost.h:36-47):
+        // put them there for the moment of the call
+        const int n = pb->prior_n, D = 15 * n;
+        matrix<> S;
+        vector<> sv;
+        S.resize(D, D), sv.resize(D);
+        for (int r = 0; r < D; ++r) {
+            sv[r] = pb->prior_s[r];
+            for (int c = 0; c < D; ++c) S(r, c) = pb->prior_S[(size_t)r * D + c];
         }
-        map.set_marginalization_factor(std::move(pr));
+        std::vector<Frame *> rel;
+        std::vector<double> keep((size_t)16 * n);
+        for (int i = 0; i < n; ++i) {
+            Frame *f = fr[(size_t)pb->prior_frames[i]];
+            rel.push_back(f);
+            get_state(f, &keep[(size_t)16 * i]);
+            set_state(f, pb->prior_lin_state + 16 * i);
+        }
+        std::vector<Frame *> rel2 = rel;
+        map.set_marginalization_factor(Factor::create_marginalization_error(S, sv, std::move(rel2)));
+        for (int i = 0; i < n; ++i) set_state(rel[(size_t)i], &keep[(size_t)16 * i]);
     }
 }
 
+void set_delta(Frame *f, const pvio_ba_problem *pb, int j) { // a stored pre-integration result
+    PreIntegrator::Delta &d = f->preintegration.delta;
+    const double *pd = pb->preint_delta + 11 * j;
+    d.t = pd[0];
+    set_q(d.q, pd + 1);
+    for (int k = 0; k < 3; ++k) d.p[k] = pd[5 + k], d.v[k] = pd[8 + k];
+    for (int r = 0; r < 15; ++r)
+        for (int c = 0; c < 15; ++c) d.sqrt_inv_cov(r, c) = pb->preint_sqrt_inv_cov[225 * (size_t)j + 15 * r + c];
+    PreIntegrator::Jacobian &jc = f->preintegration.jacobian;
+    const double *pj = pb->preint_jacobian + 45 * j;
+    set_m3(jc.dq_dbg, pj), set_m3(jc.dp_dbg, pj + 9), set_m3(jc.dp_dba, pj + 18), set_m3(jc.dv_dbg, pj + 27), set_m3(jc.dv_dba, pj + 36);
+}
+
 void copy_back(const Map &map, const std::vector<Track *> &lm_tracks, pvio_ba_state *st) {
-    for (size_t i = 0; i < map.frame_num(); ++i) {
-        Frame *f = map.get_frame(i);
-        double *s = st->frame_state + 16 * i;
-        std::memcpy(s, f->pose.q.c, 32);
-        for (int k = 0; k < 3; ++k) s[4 + k] = f->pose.p[k], s[7 + k] = f->motion.v[k], s[10 + k] = f->motion.bg[k], s[13 + k] = f->motion.ba[k];
-    }
+    for (size_t i = 0; i < map.frame_num(); ++i) get_state(map.get_frame(i), st->frame_state + 16 * i);
     for (size_t l = 0; l < lm_tracks.size(); ++l) {
         st->lm_inv_depth[l] = lm_tracks[l]->landmark.inv_depth;
         if (st->lm_quality) st->lm_quality[l] = lm_tracks[l]->landmark.quality;
@@ -113,57 +164,72 @@ void copy_back(const Map &map, const std::vector<Track *> &lm_tracks, pvio_ba_st
 
 extern "C" {
 
-// imu_ptr[N+1] indexes the concatenated IMU samples of frame j (those between frame j-1 and j); imu_tend[j] = image time
-int host_roundtrip_solve(const pvio_ba_problem *pb, pvio_ba_state *st, const int32_t *imu_ptr, const double *imu_t, const double *imu_w,
-                         const double *imu_a, const double *imu_tend, const pvio_imu_noise *nz, double plane_cov, int32_t *usable) {
+// imu_ptr[N+1] indexes the concatenated IMU samples of frame j (those between frame j-1 and j); imu_tend[j] = image time.
+// Optional per-track outputs (tracks in creation order: the landmarks, then the plane tracks; planes in creation order):
+// TF_VALID, TF_PLANE, inv_depth, quality, and membership[n_planes][n_tracks] = track in Plane::tracks.
+int host_roundtrip_solve_tracks(const pvio_ba_problem *pb, pvio_ba_state *st, const int32_t *imu_ptr, const double *imu_t, const double *imu_w,
+                                const double *imu_a, const double *imu_tend, const pvio_imu_noise *nz, double plane_cov, int32_t *usable,
+                                uint8_t *trk_valid, uint8_t *trk_plane, double *trk_inv_depth, double *trk_quality, uint8_t *membership, int32_t *n_planes_out) {
     Map map;
-    std::vector<Track *> lm_tracks;
-    build_map(pb, st, map, lm_tracks);
+    std::vector<Track *> lm_tracks, plane_tracks;
+    build_map(pb, st, map, lm_tracks, -1, nullptr, &plane_tracks);
     if (pb->use_inertial && imu_ptr)
         for (int j = 1; j < pb->n_frames; ++j) {
             Frame *f = map.get_frame(j);
-            f->image_t = imu_tend[j];
-            std::memcpy(f->preintegration.cov_w, nz->cov_w, 72), std::memcpy(f->preintegration.cov_a, nz->cov_a, 72);
-            std::memcpy(f->preintegration.cov_bg, nz->cov_bg, 72), std::memcpy(f->preintegration.cov_ba, nz->cov_ba, 72);
+            f->image->t = imu_tend[j];
+            set_m3(f->preintegration.cov_w, nz->cov_w), set_m3(f->preintegration.cov_a, nz->cov_a);
+            set_m3(f->preintegration.cov_bg, nz->cov_bg), set_m3(f->preintegration.cov_ba, nz->cov_ba);
             for (int k = imu_ptr[j]; k < imu_ptr[j + 1]; ++k) {
                 ImuData d;
                 d.t = imu_t[k];
                 for (int c = 0; c < 3; ++c) d.w[c] = imu_w[3 * k + c], d.a[c] = imu_a[3 * k + c];
                 f->preintegration.data.push_back(d);
             }
-            f->has_preintegration_factor = true;
         }
     Cfg cfg;
     cfg.iters = pb->max_iterations, cfg.plane_cov = plane_cov;
     const bool ok = BundleAdjustor().solve(&map, &cfg, pb->use_inertial != 0);
     if (usable) *usable = ok ? 1 : 0;
     copy_back(map, lm_tracks, st);
+    if (trk_valid) {
+        std::vector<Track *> all(lm_tracks);
+        all.insert(all.end(), plane_tracks.begin(), plane_tracks.end());
+        for (size_t t = 0; t < all.size(); ++t) {
+            trk_valid[t] = all[t]->flag(TrackFlag::TF_VALID) ? 1 : 0, trk_plane[t] = all[t]->flag(TrackFlag::TF_PLANE) ? 1 : 0;
+            trk_inv_depth[t] = all[t]->landmark.inv_depth, trk_quality[t] = all[t]->landmark.quality;
+            for (size_t j = 0; j < map.plane_num(); ++j) membership[j * all.size() + t] = map.get_plane(j)->tracks.count(all[t]) ? 1 : 0;
+        }
+        *n_planes_out = (int32_t)map.plane_num();
+    }
     return 0;
+}
+
+int host_roundtrip_solve(const pvio_ba_problem *pb, pvio_ba_state *st, const int32_t *imu_ptr, const double *imu_t, const double *imu_w,
+                         const double *imu_a, const double *imu_tend, const pvio_imu_noise *nz, double plane_cov, int32_t *usable) {
+    return host_roundtrip_solve_tracks(pb, st, imu_ptr, imu_t, imu_w, imu_a, imu_tend, nz, plane_cov, usable, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
 }
 
 int host_roundtrip_marginalize(const pvio_ba_problem *pb, const pvio_ba_state *st, int32_t victim, double *S, double *s) {
     Map map;
     std::vector<Track *> lm_tracks;
     build_map(pb, st, map, lm_tracks);
-    for (int j = 1; j < pb->n_frames; ++j) { // stored deltas are reused as they are (bundle_adjustor.cpp:416-450)
-        if (!pb->preint_valid || !pb->preint_valid[j]) continue;
-        Frame *f = map.get_frame(j);
-        f->has_preintegration_factor = true;
-        auto &d = f->preintegration.delta;
-        const double *pd = pb->preint_delta + 11 * j;
-        d.t = pd[0];
-        std::memcpy(d.q.c, pd + 1, 32);
-        for (int k = 0; k < 3; ++k) d.p[k] = pd[5 + k], d.v[k] = pd[8 + k];
-        std::memcpy(d.sqrt_inv_cov, pb->preint_sqrt_inv_cov + 225 * j, sizeof d.sqrt_inv_cov);
-        auto &jc = f->preintegration.jacobian;
-        const double *pj = pb->preint_jacobian + 45 * j;
-        std::memcpy(jc.dq_dbg, pj, 72), std::memcpy(jc.dp_dbg, pj + 9, 72), std::memcpy(jc.dp_dba, pj + 18, 72), std::memcpy(jc.dv_dbg, pj + 27, 72), std::memcpy(jc.dv_dba, pj + 36, 72);
-    }
+    // stored deltas are reused as they are (bundle_adjustor.cpp:416-450).  Map::put_frame gave every frame after the first a
+    // pre-integration factor; the flat window says which of them exist
+    for (int j = 1; j < pb->n_frames; ++j)
+        if (pb->preint_valid && pb->preint_valid[j]) set_delta(map.get_frame(j), pb, j);
+    if (pb->preint_valid)
+        for (int j = 1; j < pb->n_frames; ++j)
+            if (!pb->preint_valid[j]) return 2; // the harness cannot express a missing factor between neighbours
     BundleAdjustor().marginalize_frame(&map, (size_t)victim);
-    MarginalizationPrior *pr = map.get_marginalization_factor();
-    if (!pr || (int)pr->frames.size() != pb->n_frames - 1) return 1;
-    std::memcpy(S, pr->sqrt_infomat.data(), pr->sqrt_infomat.size() * sizeof(double));
-    std::memcpy(s, pr->sqrt_infovec.data(), pr->sqrt_infovec.size() * sizeof(double));
+    Factor *mf = map.get_marginalization_factor();
+    if (!mf) return 1;
+    const MarginalizationErrorCost *pr = mf->get_cost_function<MarginalizationErrorCost>();
+    if ((int)pr->related_frames().size() != pb->n_frames - 1) return 1;
+    const int D = 15 * (pb->n_frames - 1);
+    for (int r = 0; r < D; ++r) {
+        s[r] = pr->information_vector()[r];
+        for (int c = 0; c < D; ++c) S[(size_t)r * D + c] = pr->sqrt_information()(r, c);
+    }
     return 0;
 }
 
@@ -171,7 +237,7 @@ int host_roundtrip_marginalize(const pvio_ba_problem *pb, const pvio_ba_state *s
 
 // ---- visual_inertial_pnp through the Map object graph: the window's last frame is taken out of the map (the reference
 // solves it before put_frame) and refined against the rest ------------------------------------------------------------
-#include "../../pvio_amd/host/pnp.h"
+#include "../../pvio_amd/host/pnp_problem.h"
 
 namespace pvio {
 double flatten_seconds(Map *map, bool use_inertial, int reps);
@@ -183,30 +249,30 @@ extern "C" double host_flatten_seconds(const pvio_ba_problem *pb, const pvio_ba_
     return pvio::flatten_seconds(&map, use_inertial != 0, reps);
 }
 
-extern "C" int host_roundtrip_pnp(const pvio_ba_problem *pb, pvio_ba_state *st, int32_t use_inertial, int32_t max_iter, double *state_out) {
+// plane_tracks_valid: the window's plane tracks are VALID as well as PLANE (what the plane extractor leaves behind for a
+// triangulated track it has attached to a plane) -> they take the best-plane branch of pnp.cpp:61-88
+extern "C" int host_roundtrip_pnp_planes(const pvio_ba_problem *pb, pvio_ba_state *st, int32_t use_inertial, int32_t max_iter, int32_t plane_tracks_valid,
+                                         double *state_out) {
     Map map;
-    std::vector<Track *> lm_tracks;
-    build_map(pb, st, map, lm_tracks);
+    std::vector<Track *> lm_tracks, plane_tracks;
+    std::vector<std::unique_ptr<Frame>> loose;
     const int N = pb->n_frames;
-    std::unique_ptr<Frame> frame = std::move(map.frames.back());
-    map.frames.pop_back();
-    if (use_inertial) {
-        auto &d = frame->preintegration.delta;
-        const double *dl = pb->preint_delta + 11 * (N - 1);
-        d.t = dl[0];
-        std::memcpy(d.q.c, dl + 1, 32);
-        for (int k = 0; k < 3; ++k) d.p[k] = dl[5 + k], d.v[k] = dl[8 + k];
-        std::memcpy(d.sqrt_inv_cov, pb->preint_sqrt_inv_cov + 225 * (size_t)(N - 1), sizeof d.sqrt_inv_cov);
-        auto &jc = frame->preintegration.jacobian;
-        const double *j = pb->preint_jacobian + 45 * (size_t)(N - 1);
-        std::memcpy(jc.dq_dbg, j, 72), std::memcpy(jc.dp_dbg, j + 9, 72), std::memcpy(jc.dp_dba, j + 18, 72), std::memcpy(jc.dv_dbg, j + 27, 72), std::memcpy(jc.dv_dba, j + 36, 72);
-    }
+    build_map(pb, st, map, lm_tracks, N - 1, &loose, &plane_tracks);
+    if (plane_tracks_valid)
+        for (Track *t : plane_tracks) t->flag(TrackFlag::TF_VALID) = true;
+    Frame *frame = loose[0].get();
+    if (use_inertial) set_delta(frame, pb, N - 1);
     Cfg cfg;
     cfg.iters = (size_t)max_iter, cfg.plane_cov = 1e-4;
-    visual_inertial_pnp(&map, frame.get(), &cfg, use_inertial != 0);
-    std::memcpy(state_out, frame->pose.q.c, 32);
-    for (int k = 0; k < 3; ++k) state_out[4 + k] = frame->pose.p[k], state_out[7 + k] = frame->motion.v[k], state_out[10 + k] = frame->motion.bg[k], state_out[13 + k] = frame->motion.ba[k];
+    visual_inertial_pnp(&map, frame, &cfg, use_inertial != 0);
+    get_state(frame, state_out);
+    // the loose frame's keypoints still sit in their tracks: detach them before the frame goes away
+    for (size_t i = 0; i < frame->keypoint_num(); ++i)
+        if (Track *t = frame->get_track(i)) t->remove_keypoint(frame, false);
     return 0;
+}
+extern "C" int host_roundtrip_pnp(const pvio_ba_problem *pb, pvio_ba_state *st, int32_t use_inertial, int32_t max_iter, double *state_out) {
+    return host_roundtrip_pnp_planes(pb, st, use_inertial, max_iter, 0, state_out);
 }
 
 // flat entry: world-point factors as well (PoseOnlyReprojectionXYZErrorCost)

@@ -22,7 +22,8 @@ def load(target):
     return lib
 
 
-def roundtrip_solve(lib, pb, st):
+def roundtrip_solve(lib, pb, st, tracks=None):
+    """tracks: optional dict that receives the per-track flags / plane memberships after the solve (post-solve passes)"""
     pbc, stc = pb.as_c(), st.as_c()
     N = pb.n_frames
     ptr = np.zeros(N + 1, np.int32)
@@ -40,11 +41,73 @@ def roundtrip_solve(lib, pb, st):
     A = np.ascontiguousarray(np.concatenate(as_)) if as_ else np.zeros(3)
     dp = capi.c_double_p
     usable = C.c_int32(0)
-    rc = lib.host_roundtrip_solve(C.byref(pbc), C.byref(stc), ptr.ctypes.data_as(capi.c_int32_p), T.ctypes.data_as(dp), W.ctypes.data_as(dp),
-                                  A.ctypes.data_as(dp), tend.ctypes.data_as(dp), C.byref(nzc) if nzc is not None else None,
-                                  C.c_double(1.0e-4), C.byref(usable))
+    args = [C.byref(pbc), C.byref(stc), ptr.ctypes.data_as(capi.c_int32_p), T.ctypes.data_as(dp), W.ctypes.data_as(dp),
+            A.ctypes.data_as(dp), tend.ctypes.data_as(dp), C.byref(nzc) if nzc is not None else None, C.c_double(1.0e-4), C.byref(usable)]
+    if tracks is None:
+        rc = lib.host_roundtrip_solve(*args)
+    else:
+        nt = pb.n_landmarks + pb.n_plane_factors
+        u8p = C.POINTER(C.c_uint8)
+        tracks.update(valid=np.zeros(nt, np.uint8), plane=np.zeros(nt, np.uint8), inv_depth=np.zeros(nt), quality=np.zeros(nt),
+                      membership=np.zeros((8, nt), np.uint8))
+        npl = C.c_int32(0)
+        lib.host_roundtrip_solve_tracks.restype = C.c_int
+        rc = lib.host_roundtrip_solve_tracks(*args, tracks["valid"].ctypes.data_as(u8p), tracks["plane"].ctypes.data_as(u8p),
+                                             tracks["inv_depth"].ctypes.data_as(dp), tracks["quality"].ctypes.data_as(dp),
+                                             tracks["membership"].ctypes.data_as(u8p), C.byref(npl))
+        tracks["membership"] = tracks["membership"].reshape(-1)[:npl.value * nt].reshape(npl.value, nt)
     assert rc == 0
     return usable.value
+
+
+def flat_tracks(pb, st):
+    """Every track of the Map the harness builds from `pb` (landmarks, then plane tracks), as the oracle's post-pass input:
+    observation lists with the anchor first, flags before the passes, plane table and memberships."""
+    M, P = pb.n_landmarks, pb.n_plane_factors
+    ptr, frames, zs = [0], [], []
+    for l in range(M):
+        frames.append(int(pb.lm_anchor_frame[l])), zs.append(pb.lm_anchor_z[l])
+        for o in range(pb.lm_obs_ptr[l], pb.lm_obs_ptr[l + 1]):
+            frames.append(int(pb.obs_frame[o])), zs.append(pb.obs_z[o])
+        ptr.append(len(frames))
+    keys, plane_of = [], []
+    for f in range(P):
+        for o in range(pb.plane_obs_ptr[f], pb.plane_obs_ptr[f + 1]):
+            frames.append(int(pb.plane_obs_frame[o])), zs.append(pb.plane_obs_z[o])
+        ptr.append(len(frames))
+        key = (tuple(pb.plane_normal[f]), float(pb.plane_distance[f]))
+        if key not in keys:
+            keys.append(key)
+        plane_of.append(keys.index(key))
+    nt = M + P
+    t = dict(ptr=np.array(ptr, np.int32), frame=np.array(frames, np.int32), z=np.ascontiguousarray(np.array(zs, float).reshape(-1, 2)),
+             life=np.diff(ptr).astype(np.int64), valid=np.r_[np.ones(M, np.uint8), np.zeros(P, np.uint8)],
+             plane=np.r_[np.zeros(M, np.uint8), np.ones(P, np.uint8)], inv_depth=np.r_[st.lm_inv_depth, np.ones(P)], quality=np.zeros(nt),
+             normal=np.ascontiguousarray(np.array([k[0] for k in keys], float).reshape(-1, 3)), distance=np.array([k[1] for k in keys], float),
+             membership=np.zeros((len(keys), nt), np.uint8))
+    for f in range(P):
+        t["membership"][plane_of[f], M + f] = 1
+    return t
+
+
+def check_adapter_post_passes(lib, oracle, **kw):
+    """bundle_adjustor.cpp:251-296 through the adapter against the oracle's restatement (oracle/oracle_post.cpp), on a window whose
+    planes hold a few tracks that are really 0.3 m off (synth plane_outliers)."""
+    pb = ba_compare.make(oracle, **kw)
+    st0, sm0 = BAState(pb), BASummary(pb)
+    oracle.solve(pb, st0, sm0)
+    exp = flat_tracks(pb, st0)
+    oracle.post_passes(pb, st0.frame_state, exp)
+    st1, got = BAState(pb), {}
+    roundtrip_solve(lib, pb, st1, got)
+    M = pb.n_landmarks
+    assert (got["valid"] == exp["valid"]).all() and (got["plane"] == exp["plane"]).all()
+    assert (got["membership"] == exp["membership"]).all()
+    moved = (exp["plane"][M:] == 0) & (exp["valid"][M:] == 1)
+    np.testing.assert_allclose(got["inv_depth"], exp["inv_depth"], rtol=1e-6, atol=1e-9)
+    ok = exp["valid"] == 1
+    np.testing.assert_allclose(got["quality"][ok], exp["quality"][ok], rtol=0, atol=1e-5)
+    return moved, exp["membership"].sum(0)[M:] == 0
 
 
 def check_adapter(lib, oracle, **kw):

@@ -28,6 +28,28 @@ def test_adapter_marginalize_emulated(emu_host, oracle):
     host_compare.check_adapter_marginalize(emu_host, oracle, 2, n_frames=5, n_landmarks=50, use_inertial=True, visibility=4)
 
 
+POST = dict(n_frames=12, n_landmarks=200, use_inertial=True, plane_fraction=0.4, plane_outliers=5)
+
+
+def test_adapter_post_passes_emulated(emu_host, oracle):
+    """plane-track re-validation (DLT triangulation, 0.1 m gate, plane erase, re-promotion to VALID) + depth gate / quality over
+    ALL valid-or-plane tracks: bundle_adjustor.cpp:251-296"""
+    moved, orphaned = host_compare.check_adapter_post_passes(emu_host, oracle, **POST)
+    # the 5 off-plane tracks of each of the two planes (80 plane tracks, 40 per plane) are thrown out of their plane and
+    # re-promoted; the remaining tracks of the first plane stay.  (The second plane loses all of its tracks: the sign
+    # quirk of the plane factor's regularization row, SURVEY App. D item 3, drags the solved poses ~10 cm off there --
+    # reference behaviour, reproduced by both sides.)
+    assert moved[:5].all() and moved[40:45].all() and not moved[5:40].any()
+    assert (moved == orphaned).all()
+
+
+@pytest.mark.gpu
+def test_adapter_post_passes_gpu(oracle):
+    lib = host_compare.load("libpvio_host.so")
+    moved, _ = host_compare.check_adapter_post_passes(lib, oracle, **POST)
+    assert moved[:5].all() and moved[40:45].all() and not moved[5:40].any()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_adapter_solve_gpu(oracle, name):

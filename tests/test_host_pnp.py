@@ -28,9 +28,9 @@ def host():
     return lib
 
 
-def make_case(use_inertial, n_frames=6, n_landmarks=120, seed_shift=0, perturb=1.0):
+def make_case(use_inertial, n_frames=6, n_landmarks=120, seed_shift=0, perturb=1.0, **extra):
     """A synthetic window; its last frame is the one being localized, the one before it the map's last frame."""
-    kw = dict(n_frames=n_frames, n_landmarks=n_landmarks, use_inertial=use_inertial, visibility=n_frames)
+    kw = dict(n_frames=n_frames, n_landmarks=n_landmarks, use_inertial=use_inertial, visibility=n_frames, **extra)
     if use_inertial:
         from pvio_amd.solver import preintegrate  # host C++ integrator behind the C ABI
 
@@ -190,3 +190,56 @@ def test_pnp_world_point_factors_and_degenerate_inputs(host):
     # zero iterations allowed: initial evaluation only
     x3, it3, tm3, c3 = run_flat(host, pb, T, Lf, fac, False, x0, max_iter=0)
     assert (x3 == x0).all() and it3 == 0 and tm3 == 1 and c3[0] == c3[1]
+
+
+def test_pnp_best_plane_search_keeps_the_reference_quirk(host):
+    """pnp.cpp:61-88: a VALID + PLANE track contributes a fixed world point -- its anchor ray cast onto the 'best' plane.  The
+    reference never updates max_rpe, so the LAST plane of the map that is not parallel to the ray wins, whatever plane the
+    track belongs to.  The numpy side below restates exactly that, independently of the C++."""
+    pb, T, Lf, fac = make_case(False, n_landmarks=150, plane_fraction=0.4)
+    assert pb.n_plane_factors == 60
+    planes = []  # map order = first appearance in the flat window
+    for f in range(pb.n_plane_factors):
+        key = (tuple(pb.plane_normal[f]), float(pb.plane_distance[f]))
+        if key not in planes:
+            planes.append(key)
+    assert len(planes) == 2
+    pts, chosen = [], []
+    for f in range(pb.n_plane_factors):
+        obs = list(range(pb.plane_obs_ptr[f], pb.plane_obs_ptr[f + 1]))
+        frames = [int(pb.plane_obs_frame[o]) for o in obs]
+        if T not in frames or Lf not in frames or frames[0] == T:
+            continue
+        a = frames[0]
+        sa, ca = pb.frame_state[a], pb.cam_extrinsic[a]
+        Rwc = _rot(sa[0:4]) @ _rot(ca[0:4])
+        pwc = sa[4:7] + _rot(sa[0:4]) @ ca[4:7]
+        za = pb.plane_obs_z[obs[0]]
+        direction = Rwc @ np.array([za[0], za[1], 1.0])
+        best = None
+        for j, (nrm, dist) in enumerate(planes):
+            nrm = np.array(nrm)
+            if abs(direction @ nrm / np.linalg.norm(direction)) < np.sin(np.deg2rad(10.0)):
+                continue
+            best = (j, pwc + direction * ((dist - nrm @ pwc) / (nrm @ direction)))  # rpe < DBL_MAX always: the last one stays
+        if best is None:
+            continue
+        chosen.append(best[0])
+        pts.append((best[1], pb.plane_obs_z[obs[frames.index(T)]].copy()))
+    assert len(pts) > 30 and set(chosen) == {1}  # every plane track ends up on the map's LAST plane
+    x0 = pb.frame_state[T].copy()
+    x0[4:7] += [0.03, -0.02, 0.02]
+    D = PnpDense(pb, T, Lf, fac, False, points=pts)
+    trace, fs, _, term, its = np_reference.solve_dense(D, x0.reshape(1, 16).copy(), np.zeros(0), 10)
+    st = BAState(pb)
+    st.frame_state[T] = x0
+    pbc, stc = pb.as_c(), st.as_c()
+    out = np.zeros(16)
+    host.host_roundtrip_pnp_planes.restype = C.c_int
+    assert host.host_roundtrip_pnp_planes(C.byref(pbc), C.byref(stc), C.c_int32(0), C.c_int32(10), C.c_int32(1), _d(out)) == 0
+    assert np.abs(out[:7] - fs[0][:7]).max() < 1e-6  # the numpy Jacobian of the point factors is a central difference
+    # and it is not what the anchored-factor-only solve gives: the plane points (wrong plane for half of them) pull the pose
+    out2 = np.zeros(16)
+    st.frame_state[T] = x0
+    assert host.host_roundtrip_pnp_planes(C.byref(pbc), C.byref(stc), C.c_int32(0), C.c_int32(10), C.c_int32(0), _d(out2)) == 0
+    assert np.abs(out2[:7] - out[:7]).max() > 1e-4
