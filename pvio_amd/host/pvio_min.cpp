@@ -6,12 +6,14 @@
 // it calls are restated here, each citing what it follows.  Scalar bookkeeping, no hot path.
 #include <cmath>
 #include <cstring>
+#include <iterator>
 #include <limits>
 
 #include "../../include/pvio_hip.h"
 #include "dropin/pvio/estimation/ceres/marginalization_error_cost.h"
 #include "dropin/pvio/estimation/ceres/preintegration_error_cost.h"
 #include "dropin/pvio/estimation/ceres/reprojection_error_cost.h"
+#include "feature_front.h"
 #include "pvio_min.h"
 
 namespace pvio {
@@ -61,7 +63,54 @@ std::unique_ptr<Factor> Factor::create_preintegration_error(Frame *frame_i, Fram
     return std::make_unique<Factor>(std::make_unique<PreIntegrationErrorCost>(frame_i, frame_j), factor_construct_t());
 }
 
-// ---- map/frame.cpp:53-57,187-200 ---------------------------------------------------------------------------------
+// ---- map/frame.cpp:27-139,187-200 --------------------------------------------------------------------------------
+create_if_empty_t create_if_empty{};
+
+std::unique_ptr<Frame> Frame::clone() const {
+    std::unique_ptr<Frame> f = std::make_unique<Frame>(id(), construct_by_frame_t());
+    f->K = K, f->sqrt_inv_cov = sqrt_inv_cov, f->image = image, f->pose = pose, f->motion = motion, f->camera = camera, f->imu = imu;
+    f->preintegration = preintegration;
+    f->keypoints = keypoints;
+    f->tracks.assign(keypoints.size(), nullptr);
+    f->reprojection_factors.resize(keypoints.size());
+    return f;
+}
+
+Track *Frame::get_track(size_t keypoint_index, const create_if_empty_t &) {
+    if (tracks[keypoint_index] == nullptr) map->create_track()->add_keypoint(this, keypoint_index);
+    return tracks[keypoint_index];
+}
+
+// pixels in, pixels out through the Image seam; new corners appended behind the existing keypoints (frame.cpp:72-87)
+void Frame::detect_keypoints(Config *config) {
+    std::vector<vector<2>> px(keypoints.size());
+    for (size_t i = 0; i < keypoints.size(); ++i) px[i] = vector<2>(keypoints[i][0] * K(0, 0) + K(0, 2), keypoints[i][1] * K(1, 1) + K(1, 2));
+    image->detect_keypoints(px, config->feature_tracker_max_keypoint_detection(), config->feature_tracker_min_keypoint_distance());
+    const size_t old = keypoints.size();
+    keypoints.resize(px.size()), tracks.resize(px.size(), nullptr), reprojection_factors.resize(px.size());
+    for (size_t i = old; i < px.size(); ++i) keypoints[i] = vector<2>((px[i][0] - K(0, 2)) / K(0, 0), (px[i][1] - K(1, 2)) / K(1, 1));
+}
+
+// gyro-only prediction -> Image::track_keypoints -> longest-track-first Poisson-disk acceptance -> survivors appended to the
+// next frame and to their tracks (frame.cpp:89-139); the first three steps are feature_front.h
+void Frame::track_keypoints(Frame *next_frame, Config *config) {
+    std::vector<vector<2>> curr(keypoints.size()), next;
+    for (size_t i = 0; i < keypoints.size(); ++i) curr[i] = vector<2>(keypoints[i][0] * K(0, 0) + K(0, 2), keypoints[i][1] * K(1, 1) + K(1, 2));
+    if (config->feature_tracker_predict_keypoints()) predict_keypoints(*this, *next_frame, next);
+    std::vector<char> status;
+    image->track_keypoints(next_frame->image.get(), curr, next, status);
+    std::vector<size_t> length(curr.size(), 0);
+    for (size_t i = 0; i < curr.size(); ++i)
+        if (status[i] && tracks[i]) length[i] = tracks[i]->keypoint_num();
+    select_tracked(next, length, config->feature_tracker_min_keypoint_distance(), status);
+    for (size_t i = 0; i < curr.size(); ++i)
+        if (status[i]) {
+            const size_t k = next_frame->keypoint_num();
+            next_frame->append_keypoint(vector<2>((next[i][0] - next_frame->K(0, 2)) / next_frame->K(0, 0), (next[i][1] - next_frame->K(1, 2)) / next_frame->K(1, 1)));
+            get_track(i, create_if_empty)->add_keypoint(next_frame, k);
+        }
+}
+
 void Frame::append_keypoint(const vector<2> &keypoint) {
     keypoints.emplace_back(keypoint), tracks.emplace_back(nullptr), reprojection_factors.emplace_back(nullptr);
 }
@@ -103,6 +152,16 @@ void Map::marginalize_frame(size_t index) {
         if (Track *track = frame->get_track(i)) track->remove_keypoint(frame);
     frames.erase(frames.begin() + (std::ptrdiff_t)index);
     if (index > 0 && index < frames.size()) frames[index]->preintegration_factor.reset();
+}
+
+size_t Map::frame_index_by_id(size_t id) const { // frames are kept in ascending id order (map.cpp:88-106)
+    size_t lo = 0, hi = frames.size();
+    while (lo < hi) {
+        const size_t mid = (lo + hi) / 2;
+        if (frames[mid]->id() < id) lo = mid + 1;
+        else hi = mid;
+    }
+    return (lo < frames.size() && frames[lo]->id() == id) ? lo : nil();
 }
 
 Track *Map::create_track() {

@@ -205,6 +205,9 @@ class Factor {
 };
 
 // ---- map/frame.h:37-111 ------------------------------------------------------------------------------------------
+struct create_if_empty_t {};
+extern create_if_empty_t create_if_empty;
+
 enum class FrameFlag { FF_KEYFRAME = 0, FF_FIX_POSE, FLAG_NUM };
 
 class Frame : public Flagged<FrameFlag>, public Identifiable<Frame> {
@@ -213,12 +216,18 @@ class Frame : public Flagged<FrameFlag>, public Identifiable<Frame> {
     Map *map = nullptr;
 
   public:
+    struct construct_by_frame_t {};
     Frame() = default;
+    Frame(size_t id, const construct_by_frame_t &) : Identifiable(id) {}
     virtual ~Frame() = default;
+    std::unique_ptr<Frame> clone() const; // same id, keypoints kept, tracks / factors / map dropped (frame.cpp:43-58)
     size_t keypoint_num() const { return keypoints.size(); }
     void append_keypoint(const vector<2> &keypoint);
     const vector<2> &get_keypoint(size_t keypoint_index) const { return keypoints[keypoint_index]; }
     Track *get_track(size_t keypoint_index) const { return tracks[keypoint_index]; }
+    Track *get_track(size_t keypoint_index, const create_if_empty_t &);
+    void detect_keypoints(Config *config);                   // frame.cpp:72-87
+    void track_keypoints(Frame *next_frame, Config *config); // frame.cpp:89-139
     Factor *get_reprojection_factor(size_t keypoint_index) { return reprojection_factors[keypoint_index].get(); }
     Factor *get_preintegration_factor() { return preintegration_factor.get(); }
     PoseState get_pose(const ExtrinsicParams &sensor) const;
@@ -255,6 +264,7 @@ class Map {
     void put_frame(std::unique_ptr<Frame> frame, size_t position = nil());
     void erase_frame(size_t index);
     void marginalize_frame(size_t index);
+    size_t frame_index_by_id(size_t id) const;
     size_t track_num() const { return tracks.size(); }
     Track *get_track(size_t index) const { return tracks[index].get(); }
     Track *create_track();

@@ -1,0 +1,115 @@
+"""Headless pipeline (pvio_amd/host/headless.*, feature_tracker.*; tools/pvio_headless.cpp is its dataset loop): a rendered
+sequence -- a textured wall seen from the synthetic orbit of pvio_amd.synth, 200 Hz IMU synthesized from the same analytic
+trajectory -- goes through image preprocessing, LK tracking, RANSAC, corner detection (GPU), the keyframe bootstrap, PnP,
+marginalization and sliding-window bundle adjustment (GPU); the reported trajectory must follow the ground truth.
+
+This is an end-to-end plumbing test of the rows SURVEY.md section 8 marks K6 / F3, not a parity test: there is no reference
+trajectory to compare with (the reference cannot run here), so the bar is the known ground truth of the rendered scene."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import host_compare
+from pvio_amd import synth
+
+dp = C.POINTER(C.c_double)
+
+
+def _d(a):
+    return a.ctypes.data_as(dp)
+
+
+W, H = 512, 384
+K4 = np.array([300.0, 300.0, 255.5, 191.5])
+TEX_PPM = 160.0  # texture pixels per metre of wall
+
+
+def _texture():
+    rng = synth.Rng(synth.SEED + 17)
+    n = 64
+    fx, fy, ph, amp = (rng.uniform(n) - 0.5) * 0.9, (rng.uniform(n) - 0.5) * 0.9, rng.uniform(n) * 2 * np.pi, 0.5 + rng.uniform(n)
+
+    def tex(x, y):
+        acc = np.zeros_like(x)
+        for k in range(n):
+            acc += amp[k] * np.cos(fx[k] * x + fy[k] * y + ph[k])
+        return 128.0 + acc * (90.0 / np.sqrt(n))
+    return tex
+
+
+def render_sequence(n_frames, fps=20.0, imu_rate=200.0, t_start=0.0):
+    """images (n, H, W) u8, image times, IMU (t, w, a), body poses at the image times (t p q)"""
+    q_bc = synth.Q_BC / np.linalg.norm(synth.Q_BC)
+    R_bc, p_bc = synth.qmat(q_bc), synth.P_BC
+    # the wall: through the orbit centre, facing the camera at mid-sequence, tilted by 20 degrees so that depth varies
+    t_mid = t_start + 0.5 * n_frames / fps
+    R_mid, p_mid, _, _ = synth._pose(t_mid)
+    fwd = R_mid[:, 2]
+    tilt = np.deg2rad(20.0)
+    nrm = np.cos(tilt) * fwd + np.sin(tilt) * R_mid[:, 1]
+    nrm /= np.linalg.norm(nrm)
+    e1 = np.cross(nrm, np.array([0.0, 0.0, 1.0]))
+    e1 /= np.linalg.norm(e1)
+    e2 = np.cross(nrm, e1)
+    d = 0.0  # n . X = 0: the plane passes through the orbit centre (the origin)
+    tex = _texture()
+    us, vs = np.meshgrid(np.arange(W, dtype=float), np.arange(H, dtype=float))
+    rays_c = np.stack([(us - K4[2]) / K4[0], (vs - K4[3]) / K4[1], np.ones_like(us)], -1)
+    rng = np.random.default_rng(5)
+    images, times, poses = [], [], []
+    for k in range(n_frames):
+        t = t_start + k / fps
+        R, p, _, _ = synth._pose(t)
+        R_wc, p_wc = R @ R_bc, p + R @ p_bc
+        rays = rays_c @ R_wc.T
+        s = (d - nrm @ p_wc) / (rays @ nrm)
+        X = p_wc + rays * s[..., None]
+        img = tex(TEX_PPM * (X @ e1), TEX_PPM * (X @ e2)) + rng.normal(0, 1.5, (H, W))
+        images.append(np.clip(np.rint(img), 0, 255).astype(np.uint8))
+        times.append(t)
+        poses.append(np.concatenate([[t], p, synth.mat2q(R)]))
+    n_imu = int(round((n_frames / fps + 0.1) * imu_rate))
+    imu_t = t_start - 0.02 + np.arange(n_imu) / imu_rate
+    imu_w, imu_a = np.zeros((n_imu, 3)), np.zeros((n_imu, 3))
+    bg, ba = np.full(3, 2e-3), np.full(3, 2e-2)
+    nw = rng.normal(0, np.sqrt(synth.COV_G * imu_rate), (n_imu, 3))
+    na = rng.normal(0, np.sqrt(synth.COV_A * imu_rate), (n_imu, 3))
+    for k in range(n_imu):
+        R, _, _, acc = synth._pose(imu_t[k])
+        imu_w[k] = np.array([synth.OMEGA, 0.0, 0.0]) + bg + nw[k]  # body x = world z (synth._pose)
+        imu_a[k] = R.T @ (acc + np.array([0, 0, synth.GRAVITY])) + ba + na[k]
+    return (np.ascontiguousarray(np.stack(images)), np.array(times), imu_t, np.ascontiguousarray(imu_w), np.ascontiguousarray(imu_a),
+            np.ascontiguousarray(np.stack(poses)), q_bc, p_bc)
+
+
+def run(lib, n_frames, window, gap, distance=25.0):
+    images, times, imu_t, imu_w, imu_a, gt, q_bc, p_bc = render_sequence(n_frames)
+    out, stats = np.zeros((n_frames, 8)), np.zeros(4, np.int32)
+    err = C.create_string_buffer(512)
+    lib.host_headless_run.restype = C.c_int
+    rc = lib.host_headless_run(C.c_int(n_frames), C.c_int(W), C.c_int(H), images.ctypes.data_as(C.POINTER(C.c_uint8)), _d(times), C.c_int(len(imu_t)),
+                               _d(imu_t), _d(imu_w), _d(imu_a), _d(K4), _d(np.ascontiguousarray(q_bc)), _d(np.ascontiguousarray(p_bc)), C.c_int(len(gt)),
+                               _d(gt), C.c_int(window), C.c_int(gap), C.c_double(distance), _d(out), stats.ctypes.data_as(C.POINTER(C.c_int32)), err,
+                               C.c_int(512))
+    assert rc == 0, err.value.decode()
+    return out, stats, gt
+
+
+@pytest.mark.gpu
+def test_headless_pipeline_follows_the_rendered_trajectory():
+    lib = host_compare.load("libpvio_host.so")
+    n_frames, window, gap = 60, 6, 3
+    out, stats, gt = run(lib, n_frames, window, gap)
+    assert stats[0] == 1, "the window was never bootstrapped"
+    assert stats[1] == window + 1 or stats[1] == window  # steady state: sliding_window_size (+ 1 while a non-keyframe rides on top)
+    assert stats[2] >= 3 and stats[3] >= 40              # keyframe solves after the bootstrap; a populated window
+    valid = np.abs(out[:, 4:8]).sum(1) > 0
+    first = int(np.argmax(valid))
+    assert first <= (window - 1) * gap + 3 and valid[first:].all()
+    err = np.linalg.norm(out[valid, 1:4] - gt[valid, 1:4], axis=1)
+    # output poses are IMU-propagated from the newest optimized frame (core.cpp:142-163): a few centimetres on a 3 m orbit
+    print("headless: first pose at frame", first, "solves", stats[2], "tracks", stats[3], "position error cm: median %.2f max %.2f" % (100 * np.median(err), 100 * err.max()))
+    assert np.median(err) < 0.05 and err.max() < 0.15
+    qe = np.abs(np.sum(out[valid, 4:8] * gt[valid, 4:8], axis=1))
+    assert np.degrees(2 * np.arccos(np.clip(qe, 0, 1))).max() < 2.0
