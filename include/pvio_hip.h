@@ -126,6 +126,18 @@ typedef struct pvio_ba_problem {
     int32_t max_iterations;        /* config->solver_iteration_limit()                                   */
     int32_t reserved0;
     double max_solver_time;        /* config->solver_time_limit() [s]                                    */
+
+    /* Rotation priors -- the `RotationPriorFactor` BASELINE.json's north_star names.  NO REFERENCE COUNTERPART: the class
+     * does not exist in the reference @ v0 (name-mapping note).  Defined as that note prescribes, as
+     * the rotation rows of the marginalization factor (marginalization_error_cost.h:65,77) with a 3x3 sqrt-information:
+     *   r = W log(q0^-1 (x) q_body),   dr/dtheta = W Jr^-1(log(q0^-1 (x) q_body)),   no loss function.
+     * At most one per frame; a prior on an FF_FIX_POSE frame is a constant and is left out (Ceres folds such blocks into
+     * fixed_cost).  marginalize_frame folds the victim's rotation prior into the new marginalization prior. */
+    int32_t n_rot_priors;          /* R                                                                  */
+    int32_t reserved1;
+    const int32_t *rot_prior_frame;    /* [R]    window index                                            */
+    const double *rot_prior_q0;        /* [R][4] x y z w                                                 */
+    const double *rot_prior_sqrt_info; /* [R][9] W, row-major                                            */
 } pvio_ba_problem;
 
 /* In/out states, updated in place exactly like Frame::pose/motion and Track::landmark.inv_depth. */

@@ -73,6 +73,7 @@ Layout make_layout(const pvio_ba_problem &pb) {
         L.prior_active = true;
         for (int i = 0; i < pb.prior_n; ++i) pose_used[pb.prior_frames[i]] = motion_used[pb.prior_frames[i]] = 1;
     }
+    for (int i = 0; i < pb.n_rot_priors; ++i) pose_used[pb.rot_prior_frame[i]] = 1;
     for (int f = 0; f < pb.n_plane_factors; ++f) {
         bool any_free = false;
         for (int o = pb.plane_obs_ptr[f]; o < pb.plane_obs_ptr[f + 1]; ++o)
@@ -168,6 +169,21 @@ struct Evaluator {
                         lin->Hpp[(size_t)col[a] * P + col[b]] += s;
                     }
                 }
+            }
+        }
+        // rotation priors (no reference counterpart, see eval_rot_prior): no loss; a prior on a constant pose block is
+        // an all-constant residual block and is left out like Ceres does
+        for (int i = 0; i < pb.n_rot_priors; ++i) {
+            const int f = pb.rot_prior_frame[i], po = L.pose_off[f];
+            if (po < 0) continue;
+            double r[3], J[9];
+            eval_rot_prior(fs + 16 * f, pb.rot_prior_q0 + 4 * i, pb.rot_prior_sqrt_info + 9 * i, r, lin ? J : nullptr);
+            const double sq = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+            if (!std::isfinite(sq)) ok = false;
+            cost += 0.5 * sq;
+            if (lin) {
+                add_block(lin->Hpp, P, po, po, J, 3, J, 3, 3, 3, 3);
+                for (int k = 0; k < 3; ++k) lin->gp[po + k] += J[k] * r[0] + J[3 + k] * r[1] + J[6 + k] * r[2];
             }
         }
         // reprojection factors: bundle_adjustor.cpp:142-161, CauchyLoss(1.0)
@@ -844,6 +860,17 @@ int32_t oracle_ba_marginalize(const pvio_ba_problem *pbp, const pvio_ba_state *s
                     }
             }
     }
+    // (a') the victim's rotation prior (no reference counterpart, see eval_rot_prior): a factor on the victim goes into the
+    // new prior like every other factor on it
+    for (int i = 0; i < pb.n_rot_priors; ++i) {
+        if (pb.rot_prior_frame[i] != victim) continue;
+        double r[3], J[9];
+        eval_rot_prior(fs + 16 * victim, pb.rot_prior_q0 + 4 * i, pb.rot_prior_sqrt_info + 9 * i, r, J);
+        for (int a = 0; a < 3; ++a) {
+            b[15 * victim + a] += J[a] * r[0] + J[3 + a] * r[1] + J[6 + a] * r[2];
+            for (int c = 0; c < 3; ++c) H[(size_t)(15 * victim + a) * D + 15 * victim + c] += J[a] * J[c] + J[3 + a] * J[3 + c] + J[6 + a] * J[6 + c];
+        }
+    }
     // (b) pre-integration factors touching the victim (:416-450); live biases == parameters -> dbg = 0
     for (int j = victim; j <= victim + 1; ++j) {
         if (j == 0 || j >= N) continue;
@@ -1012,6 +1039,7 @@ void oracle_eval_prior(int32_t n, const double *states, const double *lin, const
     for (int i = 0; i < n; ++i) sp[i] = states + 16 * i;
     eval_prior(n, sp.data(), lin, S, s, r, J);
 }
+void oracle_eval_rot_prior(const double *state, const double *q0, const double *W, double *r, double *J) { eval_rot_prior(state, q0, W, r, J); }
 void oracle_eval_plane(int32_t K, const double *states, const double *cams, const double *z, const double *normal, double distance,
                        double sqrt_inv_cov, double *r, double *J) {
     std::vector<const double *> sp(K);

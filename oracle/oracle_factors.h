@@ -301,6 +301,22 @@ inline void eval_prior(int n, const double *const *states, const double *lin, co
 }
 
 // ---------------------------------------------------------------------------------------------
+// RotationPriorFactor -- NO REFERENCE COUNTERPART (the name is BASELINE.json's; the class does not exist @ v0).  Defined as
+// SURVEY.md section 8a's name-mapping note prescribes: the r_q rows of MarginalizationErrorCost
+// (marginalization_error_cost.h:65 residual, :77 Jacobian) under a 3 x 3 sqrt-information W (row-major):
+//   r = W log(q0^-1 q),   J = W Jr^-1(log(q0^-1 q))   (3 x 3 row-major, columns = the frame's theta tangent)
+// ---------------------------------------------------------------------------------------------
+inline void eval_rot_prior(const double *state, const double *q0, const double *W, double *r, double *J) {
+    V3 rq = logmap(qmul(qconj(qload(q0)), qload(state)));
+    for (int i = 0; i < 3; ++i) r[i] = W[3 * i] * rq[0] + W[3 * i + 1] * rq[1] + W[3 * i + 2] * rq[2];
+    if (J) {
+        M3 JrInv = inverse(right_jacobian(rq));
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) J[3 * i + j] = W[3 * i] * JrInv.m[0][j] + W[3 * i + 1] * JrInv.m[1][j] + W[3 * i + 2] * JrInv.m[2][j];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // AugmentedPlaneDistanceErrorCost::Evaluate -- estimation/ceres/augmented_plane_distance_error_cost.h:53-136
 // K observations; states[k] = 16-double state of the k-th observing frame; cams[k] its camera extrinsic.
 // J: K x 6 row-major (theta, p per observing frame); plane blocks are constant (bundle_adjustor.cpp:108-109).

@@ -39,6 +39,8 @@ class BAProblemC(C.Structure):
         ("plane_obs_ptr", c_int32_p), ("plane_obs_frame", c_int32_p), ("plane_obs_z", c_double_p),
         ("plane_normal", c_double_p), ("plane_distance", c_double_p), ("plane_sqrt_inv_cov", C.c_double),
         ("max_iterations", C.c_int32), ("reserved0", C.c_int32), ("max_solver_time", C.c_double),
+        ("n_rot_priors", C.c_int32), ("reserved1", C.c_int32),
+        ("rot_prior_frame", c_int32_p), ("rot_prior_q0", c_double_p), ("rot_prior_sqrt_info", c_double_p),
     ]
 
 

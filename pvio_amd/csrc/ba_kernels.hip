@@ -976,6 +976,27 @@ __global__ void __launch_bounds__(kLinThreads) k_linearize(View v) {
     lin_prologue(v, lds, pro);
     PV_STAMP(0, 1);
     if (!pro->valid) return; // invalid trust-region step: k_dense handles it (HandleInvalidStep)
+    if (blockIdx.x == 0 && v.dm.n_rot > 0) {
+        // rotation priors (RotationPriorFactor, no reference counterpart): one thread per frame, at the evaluation point the
+        // prologue left in LDS; k_reduce / k_dense add the 3 x 3 blocks, the gradient and the cost like the IMU / prior terms
+        const int N = v.dm.N, tid = threadIdx.x;
+        double *rc = lds + N * 16 + N * kFrameRec; // scratch (free until the roles start)
+        if (tid < N) {
+            const int slot = v.rot_slot[tid];
+            double r[3] = {0, 0, 0}, H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
+            if (slot >= 0 && (v.pose_active[tid] || pro->mode == MODE_MARG)) rot_prior_eval(lds + 16 * tid, v.rot_q0 + 4 * slot, v.rot_W + 9 * slot, r, H, g);
+            for (int k = 0; k < 9; ++k) v.rot_H[9 * tid + k] = H[k];
+            for (int k = 0; k < 3; ++k) v.rot_g[3 * tid + k] = g[k];
+            rc[tid] = 0.5 * (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double c2 = 0;
+            for (int f = 0; f < N; ++f) c2 += rc[f];
+            v.rot_cost[0] = c2;
+        }
+        __syncthreads();
+    }
     // launch order = [IMU | prior | planes | landmarks]: the longest workgroups are dispatched first; b keeps the role
     // numbering [landmarks | planes | IMU | prior] the partial rows use
     const int g0 = v.dm.G_lm, g1 = g0 + v.dm.G_plane, g2 = g1 + v.dm.G_pre, naux = v.dm.G_pre + v.dm.G_prior;
@@ -1005,6 +1026,7 @@ constexpr int kRedElems = 16, kRedGroups = 64; // one block = 16 output elements
 // IMU factor blocks (odd factor first) and marginalization prior added to entry ((fa, ka), (fb, kb)), fb <= fa, of the
 // unscaled reduced system whose landmark / plane part is `val`
 __device__ __forceinline__ double reduced_entry_terms(const View &v, double val, int fa, int ka, int fb, int kb) {
+    if (v.dm.n_rot > 0 && fa == fb && ka < 3 && kb < 3) val += v.rot_H[9 * fa + 3 * ka + kb]; // rotation prior of the frame
     if (v.dm.d != 15) return val;
     const int N = v.dm.N;
     if (v.dm.G_pre) {
@@ -1469,6 +1491,7 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
         }
         else if (tid >= 128 && tid < 128 + N) aux_costs[tid - 128] = (tid - 128 >= 1 && v.dm.G_pre && v.pre_valid[tid - 128]) ? v.pre_cost[tid - 128] : 0.0;
         else if (tid >= 192 && tid < 192 + v.dm.prior_n) aux_costs[N + tid - 192] = v.prior_cost[tid - 192];
+        else if (tid == 255) aux_costs[N + v.dm.prior_n] = v.dm.n_rot > 0 ? v.rot_cost[0] : 0.0;
     }
     // Tile ownership of the register-resident factorization (LDSMAT): wave w owns tiles w, w + 4, ... of the block triangle
     // enumerated by DEscending tile column, so that the tiles still alive at any panel are a prefix of every wave's list.
@@ -1539,6 +1562,7 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
         if (lr != LIN_INVALID_STEP) {
             for (int j = 1; j < N; ++j) aux_cost += aux_costs[j]; // 0 where there is no factor (x + 0 is exact)
             for (int i = 0; i < v.dm.prior_n; ++i) aux_cost += aux_costs[N + i];
+            aux_cost += aux_costs[N + v.dm.prior_n]; // rotation priors
         }
         const double lm_cost = redS[0], lm_bad = redS[5];
         double total_cost = aux_cost + lm_cost;
@@ -1648,6 +1672,10 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
                     const double pg = v.prior_g[pa];
                     dg += v.prior_H[(size_t)pa * D + pa], g += pg, r += pg;
                 }
+            }
+            if (v.dm.n_rot > 0 && k < 3) {
+                const double rg = v.rot_g[3 * f + k];
+                dg += v.rot_H[9 * f + 4 * k], g += rg, r += rg;
             }
             act[a] = (k < 6 ? v.pose_active[f] : v.motion_active[f]) ? 1.0 : 0.0;
             diagH[a] = dg, gtot[a] = g, rhs[a] = r;

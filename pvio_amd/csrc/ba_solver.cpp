@@ -154,6 +154,18 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st) {
         if (f < 0 || f >= N) return fail(PVIO_ERR_INVALID_ARGUMENT, "prior frame out of range");
         pose_used[f] = motion_used[f] = 1;
     }
+    // rotation priors: at most one per frame; one on a fixed frame is a constant block and is dropped
+    std::vector<int32_t> rot_slot(N, -1);
+    if (pb->n_rot_priors < 0 || (pb->n_rot_priors > 0 && (!pb->rot_prior_frame || !pb->rot_prior_q0 || !pb->rot_prior_sqrt_info)))
+        return fail(PVIO_ERR_INVALID_ARGUMENT, "bad rotation prior arrays");
+    for (int i = 0; i < pb->n_rot_priors; ++i) {
+        const int f = pb->rot_prior_frame[i];
+        if (f < 0 || f >= N) return fail(PVIO_ERR_INVALID_ARGUMENT, "rotation prior frame out of range");
+        if (rot_slot[f] >= 0) return fail(PVIO_ERR_UNSUPPORTED, "more than one rotation prior on a frame");
+        rot_slot[f] = i;
+        pose_used[f] = 1;
+    }
+    dm.n_rot = pb->n_rot_priors;
     for (int f = 0; f < dm.n_plane; ++f) {
         bool any_free = false;
         for (int o = pb->plane_obs_ptr[f]; o < pb->plane_obs_ptr[f + 1]; ++o) any_free |= !pb->frame_fixed[pb->plane_obs_frame[o]];
@@ -267,6 +279,9 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st) {
     stage.add(pb->plane_normal, (size_t)dm.n_plane * 3, &v.plane_normal);
     stage.add(pb->plane_distance, (size_t)dm.n_plane, &v.plane_dist);
     v.plane_sic = pb->plane_sqrt_inv_cov;
+    stage.add(rot_slot.data(), Ns, &v.rot_slot);
+    stage.add(pb->rot_prior_q0, (size_t)dm.n_rot * 4, &v.rot_q0);
+    stage.add(pb->rot_prior_sqrt_info, (size_t)dm.n_rot * 9, &v.rot_W);
     // state + work
     ok &= dev(pool_, "ctrl", 1, &v.ctrl, &grew);
     ok &= dev(pool_, "fs", 2 * Ns * 16, &v.fs, &grew);
@@ -294,6 +309,14 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st) {
     ok &= dev(pool_, "prior_H", Dp * Dp, &v.prior_H, &grew);
     ok &= dev(pool_, "prior_g", Dp, &v.prior_g, &grew);
     ok &= dev(pool_, "prior_cost", (size_t)std::max(dm.prior_n, 1), &v.prior_cost, &grew);
+    ok &= dev(pool_, "rot_H", Ns * 9, &v.rot_H, &grew);
+    ok &= dev(pool_, "rot_g", Ns * 3, &v.rot_g, &grew);
+    ok &= dev(pool_, "rot_cost", 1, &v.rot_cost, &grew);
+    if (ok && dm.n_rot == 0) { // read unconditionally by k_reduce / k_dense: zero when the window has none
+        if (check(hipMemsetAsync(v.rot_H, 0, Ns * 9 * sizeof(double), stream_), "memset rot") || check(hipMemsetAsync(v.rot_g, 0, Ns * 3 * sizeof(double), stream_), "memset rot") ||
+            check(hipMemsetAsync(v.rot_cost, 0, sizeof(double), stream_), "memset rot"))
+            return PVIO_ERR_HIP;
+    }
     const size_t P = dm.P;
     ok &= dev(pool_, "Smat", dense_tile_doubles(dm), &v.Smat, &grew);
     // tile image: k_reduce also assembles the reduced system entry by entry where the dense kernel's tile owners load it
@@ -644,6 +667,9 @@ int BASolver::marginalize(const pvio_ba_problem *pb, const pvio_ba_state *st, in
     const size_t Dp = 15 * (size_t)dm.prior_n;
     std::vector<double> priH(Dp * Dp), prig(Dp);
     std::vector<int32_t> tasks(dm.n_tasks);
+    std::vector<double> rotH(Ns * 9), rotg(Ns * 3);
+    if (check(hipMemcpyAsync(rotH.data(), v_.rot_H, rotH.size() * sizeof(double), hipMemcpyDeviceToHost, stream_), "D2H")) return PVIO_ERR_HIP;
+    if (check(hipMemcpyAsync(rotg.data(), v_.rot_g, rotg.size() * sizeof(double), hipMemcpyDeviceToHost, stream_), "D2H")) return PVIO_ERR_HIP;
     if (check(hipMemcpyAsync(red.data(), v_.red, red.size() * sizeof(double), hipMemcpyDeviceToHost, stream_), "D2H")) return PVIO_ERR_HIP;
     if (check(hipMemcpyAsync(preH.data(), v_.pre_H, preH.size() * sizeof(double), hipMemcpyDeviceToHost, stream_), "D2H")) return PVIO_ERR_HIP;
     if (check(hipMemcpyAsync(preg.data(), v_.pre_g, preg.size() * sizeof(double), hipMemcpyDeviceToHost, stream_), "D2H")) return PVIO_ERR_HIP;
@@ -674,6 +700,10 @@ int BASolver::marginalize(const pvio_ba_problem *pb, const pvio_ba_state *st, in
             b[15 * (j - 1) + a] += preg[(size_t)j * 30 + a];
             for (int c = 0; c < 30; ++c) H[(size_t)(15 * (j - 1) + a) * D + 15 * (j - 1) + c] += preH[(size_t)j * 900 + a * 30 + c];
         }
+    }
+    for (int a = 0; a < 3; ++a) { // the victim's rotation prior (evaluated un-gated in MODE_MARG; zero when it has none)
+        b[15 * victim + a] += rotg[(size_t)victim * 3 + a];
+        for (int c = 0; c < 3; ++c) H[(size_t)(15 * victim + a) * D + 15 * victim + c] += rotH[(size_t)victim * 9 + 3 * a + c];
     }
     for (size_t a = 0; a < Dp; ++a) {
         const int ga = 15 * pb->prior_frames[a / 15] + (int)(a % 15);

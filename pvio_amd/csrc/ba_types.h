@@ -87,6 +87,7 @@ struct Dims {
     int32_t fuse_backsub; // landmark back-substitution inside k_dense (small windows, single GPU)
     int32_t use_img;      // k_reduce also assembles the reduced system as a tile image the dense kernel loads straight into registers
     int32_t img_sz;       // doubles in the image (tiles * 256)
+    int32_t n_rot;        // rotation priors (RotationPriorFactor, no reference counterpart): evaluated by workgroup 0 of k_linearize
     int32_t lm_mm;        // landmark workgroups accumulate the Schur complement as 16x16 f64 MFMA tiles and walk a contiguous chunk range
 };
 
@@ -109,6 +110,9 @@ struct View { // passed by value to every kernel
     const int32_t *plane_ptr, *plane_frame, *plane_chunk; // CSR + chunk ranges
     const double *plane_z, *plane_normal, *plane_dist;
     double plane_sic;
+    const int32_t *rot_slot;      // [N] rotation prior of the frame or -1
+    const double *rot_q0, *rot_W; // [n_rot][4], [n_rot][9]
+    double *rot_H, *rot_g, *rot_cost; // [N][9], [N][3], [1]: J^T J, J^T r per frame; 1/2 sum |r|^2 (zero without a prior)
     // state
     double *fs;        // [2][N][16]
     double *fs_user;   // [N][16]

@@ -211,6 +211,26 @@ PV_HD void prior_frame_error(const double *x, const double *x0, double *e, doubl
     }
 }
 
+// ---- RotationPriorFactor: NO REFERENCE COUNTERPART (BASELINE.json names it; the class does not exist @ v0).  Defined as
+// SURVEY.md section 8a prescribes -- the r_q rows of the marginalization factor (marginalization_error_cost.h:65,77) under
+// a 3 x 3 sqrt-information W (row-major): r = W Log(q0^-1 q), J = W Jr^-1(Log(q0^-1 q)).  Outputs r[3], H = J^T J [9], g = J^T r [3].
+PV_HD void rot_prior_eval(const double *q, const double *q0, const double *W, double *r, double *H, double *g) {
+    double qc[4], dq[4], e[3], Jr[9], Ji[9], J[9];
+    q_conj(qc, q0);
+    q_mul(dq, qc, q);
+    q_logmap(e, dq);
+    so3_right_jacobian(Jr, e);
+    m3_inverse(Ji, Jr);
+    for (int i = 0; i < 3; ++i) {
+        r[i] = W[3 * i] * e[0] + W[3 * i + 1] * e[1] + W[3 * i + 2] * e[2];
+        for (int j = 0; j < 3; ++j) J[3 * i + j] = W[3 * i] * Ji[j] + W[3 * i + 1] * Ji[3 + j] + W[3 * i + 2] * Ji[6 + j];
+    }
+    for (int a = 0; a < 3; ++a) {
+        g[a] = J[a] * r[0] + J[3 + a] * r[1] + J[6 + a] * r[2];
+        for (int c = 0; c < 3; ++c) H[3 * a + c] = J[a] * J[c] + J[3 + a] * J[3 + c] + J[6 + a] * J[6 + c];
+    }
+}
+
 // ---- A6: augmented plane-distance factor ------------------------------------------------------------------
 // 3x3 symmetric pseudo-inverse via cyclic Jacobi, eigenvalues <= 1e-8 dropped (:90-92)
 PV_HD void sym3_pinv(double *P, const double *Ain) {

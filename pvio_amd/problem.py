@@ -49,6 +49,10 @@ class BAProblem:
         self.plane_normal = np.zeros((0, 3))
         self.plane_distance = np.zeros(0)
         self.plane_sqrt_inv_cov = 0.0
+        # rotation priors (RotationPriorFactor; no reference counterpart, include/pvio_hip.h)
+        self.rot_prior_frame = np.zeros(0, np.int32)
+        self.rot_prior_q0 = np.zeros((0, 4))
+        self.rot_prior_sqrt_info = np.zeros((0, 9))
         self.max_iterations = 10
         self.max_solver_time = 1.0e6
         # states (initial guess) and, for synthetic windows, the ground truth
@@ -84,9 +88,9 @@ class BAProblem:
         u8 = lambda a: np.ascontiguousarray(a, dtype=np.uint8)
         for name in ["cam_extrinsic", "imu_extrinsic", "sqrt_inv_cov", "intrinsics", "lm_anchor_z", "obs_z", "preint_delta",
                      "preint_sqrt_inv_cov", "preint_jacobian", "prior_S", "prior_s", "prior_lin_state", "plane_obs_z",
-                     "plane_normal", "plane_distance", "frame_state", "lm_inv_depth"]:
+                     "plane_normal", "plane_distance", "frame_state", "lm_inv_depth", "rot_prior_q0", "rot_prior_sqrt_info"]:
             setattr(self, name, f64(getattr(self, name)))
-        for name in ["lm_anchor_frame", "lm_obs_ptr", "obs_frame", "prior_frames", "plane_obs_ptr", "plane_obs_frame"]:
+        for name in ["lm_anchor_frame", "lm_obs_ptr", "obs_frame", "prior_frames", "plane_obs_ptr", "plane_obs_frame", "rot_prior_frame"]:
             setattr(self, name, i32(getattr(self, name)))
         for name in ["frame_fixed", "preint_valid"]:
             setattr(self, name, u8(getattr(self, name)))
@@ -126,6 +130,10 @@ class BAProblem:
         pb.plane_sqrt_inv_cov = float(self.plane_sqrt_inv_cov)
         pb.max_iterations = int(self.max_iterations)
         pb.max_solver_time = float(self.max_solver_time)
+        pb.n_rot_priors = int(self.rot_prior_frame.shape[0])
+        pb.rot_prior_frame = _p(self.rot_prior_frame, ip)
+        pb.rot_prior_q0 = _p(self.rot_prior_q0, dp)
+        pb.rot_prior_sqrt_info = _p(self.rot_prior_sqrt_info, dp)
         return pb
 
     def shard(self, rank, world):

@@ -105,7 +105,7 @@ def _pose(t):
 
 def make_window(n_frames=10, n_landmarks=1000, use_inertial=False, visibility=None, plane_fraction=0.0,
                 seed=SEED, preintegrate=None, kf_dt=0.25, imu_rate=200.0, perturb=True, max_iterations=10,
-                bias_init="near_truth", perturb_scale=None, plane_outliers=0, plane_outlier_offset=0.3):
+                bias_init="near_truth", perturb_scale=None, plane_outliers=0, plane_outlier_offset=0.3, rot_prior_frames=()):
     """Builds a BAProblem.  `preintegrate(t, w, a, t_end, bg, ba, noise_dict) -> (delta11, cov225, U225, jac45)`
     is required when use_inertial (the product's pvio_preintegrate or the oracle's).
 
@@ -279,6 +279,18 @@ def make_window(n_frames=10, n_landmarks=1000, use_inertial=False, visibility=No
         pb.prior_S = S
         pb.prior_s = np.zeros(15 * n)
         pb.prior_lin_state = init[:n].copy()
+    if len(rot_prior_frames) > 0:
+        # RotationPriorFactor (no reference counterpart): "an attitude measurement" of the listed frames -- truth turned by
+        # 0.3 degrees of noise, sqrt-information of ~0.3 degrees with a little cross-coupling.  Own random stream: the rest
+        # of the window is the same with and without them.
+        rr = Rng(seed + 4099)
+        nrp = len(rot_prior_frames)
+        noise_r = rr.normal(3 * nrp).reshape(nrp, 3) * np.deg2rad(0.3)
+        mix = rr.normal(9 * nrp).reshape(nrp, 3, 3) * 0.1
+        pb.rot_prior_frame = np.array(rot_prior_frames, np.int32)
+        pb.rot_prior_q0 = np.stack([qmul(truth[f, 0:4], qexp(noise_r[k])) for k, f in enumerate(rot_prior_frames)])
+        pb.rot_prior_q0 /= np.linalg.norm(pb.rot_prior_q0, axis=1, keepdims=True)
+        pb.rot_prior_sqrt_info = np.stack([(np.eye(3) + mix[k]) / np.deg2rad(0.3) for k in range(nrp)]).reshape(nrp, 9)
     pb.frame_state = init
     pb.lm_inv_depth = rho0
     pb.truth_frame_state = truth

@@ -13,6 +13,10 @@ CASES = {
     "vio_partial": dict(n_frames=6, n_landmarks=40, use_inertial=True, visibility=4),
     "plane": dict(n_frames=5, n_landmarks=60, plane_fraction=0.5),
     "vio_plane": dict(n_frames=5, n_landmarks=60, plane_fraction=0.4, use_inertial=True),
+    # RotationPriorFactor (BASELINE.json north_star; no reference counterpart): on free frames, on the fixed frame 0 of a
+    # vision-only window (a constant block, dropped), next to IMU factors and the gauge prior
+    "vision_rot_prior": dict(n_frames=5, n_landmarks=40, visibility=4, rot_prior_frames=(0, 2, 4)),
+    "vio_rot_prior": dict(n_frames=5, n_landmarks=40, use_inertial=True, visibility=4, rot_prior_frames=(1, 3, 4)),
     "vio_zero_bias_quirk": dict(n_frames=4, n_landmarks=30, use_inertial=True, bias_init="zero", perturb_scale=1.0),
     # BASELINE.json configs[1]: 10 KF x 200 landmarks, reprojection factors only
     "config1_10x200": dict(n_frames=10, n_landmarks=200),
@@ -30,6 +34,7 @@ BIG_CASES = {
     "metric_10x1000_vision": dict(n_frames=10, n_landmarks=1000),
     "metric_10x1000_vio": dict(n_frames=10, n_landmarks=1000, use_inertial=True),
     "vio_plane_10x600": dict(n_frames=10, n_landmarks=600, use_inertial=True, plane_fraction=0.4, visibility=6),
+    "vio_rot_prior_10x1000": dict(n_frames=10, n_landmarks=1000, use_inertial=True, rot_prior_frames=(2, 5, 9)),
 }
 
 

@@ -64,6 +64,12 @@ class DenseProblem:
             J = np.zeros((15 * n, 15 * n))
             L.oracle_eval_prior(n, _d(st), _d(pb.prior_lin_state), _d(pb.prior_S), _d(pb.prior_s), _d(r), _d(J) if jac else None)
             push(r, [(self.frame_cols(f), J[:, 15 * i:15 * i + 15]) for i, f in enumerate(pb.prior_frames)], False)
+        for i, f in enumerate(getattr(pb, "rot_prior_frame", [])):  # RotationPriorFactor (no reference counterpart), no loss
+            if self.pose_off[f] < 0:
+                continue
+            r, J = np.zeros(3), np.zeros((3, 3))
+            L.oracle_eval_rot_prior(_d(np.ascontiguousarray(fs[f])), _d(pb.rot_prior_q0[i]), _d(pb.rot_prior_sqrt_info[i]), _d(r), _d(J) if jac else None)
+            push(r, [(self.frame_cols(f)[:3], J)], False)
         for l in range(pb.n_landmarks):
             a = pb.lm_anchor_frame[l]
             for o in range(pb.lm_obs_ptr[l], pb.lm_obs_ptr[l + 1]):
@@ -287,6 +293,14 @@ def marginalize(pb, O, fs, rho, victim):
         Jr = np.zeros((15 * n, ncols))
         for i, f in enumerate(pb.prior_frames):
             Jr[:, 15 * f:15 * f + 15] += J[:, 15 * i:15 * i + 15]
+        rows_r.append(r), rows_J.append(Jr)
+    for i, f in enumerate(getattr(pb, "rot_prior_frame", [])):  # the victim's rotation prior goes into the new prior
+        if f != victim:
+            continue
+        r, J = np.zeros(3), np.zeros((3, 3))
+        L.oracle_eval_rot_prior(_d(np.ascontiguousarray(fs[f])), _d(pb.rot_prior_q0[i]), _d(pb.rot_prior_sqrt_info[i]), _d(r), _d(J))
+        Jr = np.zeros((3, ncols))
+        Jr[:, 15 * f:15 * f + 3] = J
         rows_r.append(r), rows_J.append(Jr)
     if pb.use_inertial:
         for j in (victim, victim + 1):

@@ -67,6 +67,11 @@ def test_emulated_marginalize_matches_oracle(emu_ctx, oracle, victim):
     marg_compare.check_marginalize(emu_ctx, oracle, victim, n_frames=5, n_landmarks=60, use_inertial=True, visibility=4)
 
 
+@pytest.mark.parametrize("victim", [1, 2])
+def test_emulated_marginalize_folds_the_victims_rotation_prior(emu_ctx, oracle, victim):
+    marg_compare.check_marginalize(emu_ctx, oracle, victim, n_frames=5, n_landmarks=40, use_inertial=True, visibility=4, rot_prior_frames=(1, 3, 4))
+
+
 def test_emulated_marginalize_last_frame_no_prior(emu_ctx, oracle):
     import numpy as np
     pb, st = marg_compare.solved_window(oracle, n_frames=4, n_landmarks=40, use_inertial=True)

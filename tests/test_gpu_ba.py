@@ -88,6 +88,12 @@ def test_gpu_marginalize_matches_oracle(gpu_ctx, oracle, victim):
 
 # rarely taken solver paths (failed factorization -> mu escalation + re-linearization, invalid steps, solver failure), forced
 # by fault injection on both sides; includes the metric-size window so that the register-resident dense path is the one hit
+@pytest.mark.parametrize("victim", [2, 5])
+def test_gpu_marginalize_folds_the_victims_rotation_prior(gpu_ctx, oracle, victim):
+    import marg_compare
+    marg_compare.check_marginalize(gpu_ctx, oracle, victim, n_frames=10, n_landmarks=300, use_inertial=True, visibility=6, rot_prior_frames=(2, 5, 9))
+
+
 @pytest.mark.parametrize("fail,invalid", [(1, 0), (3, 0), (0, 1), (0, 2), (0, 5), (8, 0)])
 @pytest.mark.parametrize("case", ["vio_small", "metric_10x1000_vio"])
 def test_gpu_fault_paths_match_oracle(oracle, fail, invalid, case):

@@ -183,6 +183,38 @@ def test_prior_jacobian_and_identity(oracle):
     np.testing.assert_allclose(J, Jfd, rtol=1e-6, atol=1e-6)
 
 
+def test_rotation_prior_jacobian_and_zero(oracle):
+    """RotationPriorFactor (no reference counterpart): r = W Log(q0^-1 q), zero at q0, Jacobian by central differences, and the
+    residual against a numpy restatement of the logarithm"""
+    rng = np.random.default_rng(11)
+    L = oracle.lib()
+    for _ in range(5):
+        x0 = rand_state(rng)
+        W = rng.normal(size=(3, 3)) + 3 * np.eye(3)
+        r = np.zeros(3)
+        L.oracle_eval_rot_prior(_d(x0), _d(np.ascontiguousarray(x0[0:4])), _d(W), _d(r), None)
+        np.testing.assert_allclose(r, 0, atol=1e-14)
+        x = plus(oracle, x0, np.r_[rng.normal(size=3) * 0.3, np.zeros(12)])
+        J = np.zeros((3, 3))
+        L.oracle_eval_rot_prior(_d(x), _d(np.ascontiguousarray(x0[0:4])), _d(W), _d(r), _d(J))
+        # numpy: dq = q0^-1 q, Log = 2 atan2(|v|, w) v / |v|
+        a, b = x0[0:4] * np.array([-1, -1, -1, 1.0]), x[0:4]
+        dq = np.r_[a[3] * b[:3] + b[3] * a[:3] + np.cross(a[:3], b[:3]), a[3] * b[3] - a[:3] @ b[:3]]
+        if dq[3] < 0:
+            dq = -dq
+        nv = np.linalg.norm(dq[:3])
+        np.testing.assert_allclose(r, W @ (2 * np.arctan2(nv, dq[3]) * dq[:3] / nv), rtol=1e-12, atol=1e-14)
+
+        def f(sts):
+            rr = np.zeros(3)
+            L.oracle_eval_rot_prior(_d(sts[0]), _d(np.ascontiguousarray(x0[0:4])), _d(W), _d(rr), None)
+            return rr
+
+        Jfd = fd_jacobian(f, [x], oracle)
+        np.testing.assert_allclose(J, Jfd[:, 0:3], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(Jfd[:, 3:], 0, atol=1e-9)
+
+
 def test_plane_jacobian(oracle):
     rng = np.random.default_rng(5)
     L = oracle.lib()

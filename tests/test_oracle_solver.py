@@ -13,6 +13,8 @@ CASES = {
     "vio_partial": dict(n_frames=6, n_landmarks=40, use_inertial=True, visibility=4),
     "plane": dict(n_frames=5, n_landmarks=60, plane_fraction=0.5),
     "vio_plane": dict(n_frames=5, n_landmarks=60, plane_fraction=0.4, use_inertial=True),
+    "vision_rot_prior": dict(n_frames=5, n_landmarks=40, visibility=4, rot_prior_frames=(0, 2, 4)),
+    "vio_rot_prior": dict(n_frames=5, n_landmarks=40, use_inertial=True, visibility=4, rot_prior_frames=(1, 3, 4)),
 }
 
 
@@ -104,7 +106,7 @@ def test_metric_config_converges_and_reduces_cost(oracle):
     assert all(b < a for a, b in zip(costs, costs[1:]))
 
 
-@pytest.mark.parametrize("case,victim", [("vio", 0), ("vio", 1), ("vio", 3), ("vio_partial", 0), ("vio_partial", 2),
+@pytest.mark.parametrize("case,victim", [("vio", 0), ("vio", 1), ("vio", 3), ("vio_partial", 0), ("vio_partial", 2), ("vio_rot_prior", 1), ("vio_rot_prior", 2),
                                          ("vio_partial", 5), ("vio_plane", 0), ("vio_plane", 4)])
 def test_oracle_marginalization_matches_dense_numpy(oracle, case, victim):
     """marginalize_frame (bundle_adjustor.cpp:348-599): the oracle's block accumulation + two-stage elimination against
