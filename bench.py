@@ -10,8 +10,11 @@ BASELINE.json.  Default workload = the configuration the metric is quoted on: 10
 factor set of a steady-state VIO window (9000 reprojection factors with Cauchy loss, 9 IMU pre-integration factors,
 the gauge/marginalization prior).  `--workload vision` gives the reprojection-only variant.
 
-With N > 1 the SAME window is landmark-sharded over the ranks (contiguous CSR ranges); the reduced pose system and 8
-scalars are all-reduced with RCCL once per linearization / back-substitution -> "scaling": "strong".
+With N > 1 the window is landmark-sharded over the ranks (contiguous CSR ranges); the reduced pose system and 8 scalars are
+all-reduced with RCCL once per linearization / back-substitution -> "scaling": "strong".  The N > 1 headline window is the
+one north_star states the multi-GPU target on, 10 KF x 50 000 landmarks (named in config.workload); the line also carries the
+same window's single-GPU rate measured in the same run (`single_gpu_same_workload`) and the sharded 10 x 1000 window
+(`small_window`).  Every N = 1 line carries the 50 000-landmark window as `scaling_window`.
 
 Extra objects on the JSON line:
   roofline      dominant kernel (k_linearize): algorithmic bytes per launch / its average duration, measured here with
@@ -46,8 +49,15 @@ def pmc_traffic(kernel, workload="vio"):
     if not files:
         return None
     try:
+        sys.path.insert(0, os.path.join(ROOT, "profiles"))
+        from summarize_pmc import source_sha256
         with open(files[-1]) as f:
-            return json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"]
+            d = json.load(f)
+        # counters of OTHER kernel sources say nothing about this run: null unless the pass was collected on exactly these
+        # sources (profiles/collect.sh stamps the file with their fingerprint)
+        if d.get("source_sha256") != source_sha256():
+            return None
+        return d["kernels"][kernel]["hbm_bytes_per_launch"]
     except Exception:
         return None
 
@@ -238,7 +248,31 @@ def main():
     from pvio_amd.solver import HipContext, preintegrate
 
     lib = capi.load()
+    # N > 1: the headline is the window north_star states the multi-GPU target on (10 KF x 50 000 landmarks) -- the 10 x 1000
+    # window of the N = 1 line is latency-bound per iteration and cannot gain from landmark shards; it rides along as
+    # `small_window`.  The same window's single-GPU rate is measured in this run (rank 0, before the sharded solves) and is
+    # also what every N = 1 line carries as `scaling_window`.
+    multi_headline = world > 1 and args.workload == "vio"
+    if multi_headline:
+        args.workload = "10x50000_vio"
     pb_full, (n_frames, n_lm, vio) = build_window(args, preintegrate)
+    single_gpu = None
+    if world > 1:
+        if rank == 0:
+            c1 = HipContext(device=local_rank, use_graph=not args.no_graph)
+            c1.upload(pb_full)
+            s1 = BASummary(pb_full, trace=False)
+            for _ in range(2):
+                c1.solve_resident(s1)
+            torch.cuda.synchronize()
+            t1, it1, n1 = time.perf_counter(), 0, max(5, min(args.steps, 20))
+            for _ in range(n1):
+                c1.solve_resident(s1)
+                it1 += s1.num_iterations
+            torch.cuda.synchronize()
+            single_gpu = {"value": it1 / (time.perf_counter() - t1), "unit": "iterations/s", "steps": n1, "what": "the same window unsharded on rank 0's GPU, this run"}
+            c1.close()
+        dist.barrier()
     pb = pb_full.shard(rank, world)
     ctx = HipContext(device=local_rank, rank=rank, world_size=world, use_graph=not args.no_graph, force_sharded=args.force_sharded)
     if sharded:
@@ -325,24 +359,40 @@ def main():
             scaling_window = bench_scaling_window(ctx, args, rank, world, dist, barrier, preintegrate)
         except Exception as e:  # the headline line must still be printed
             scaling_window = {"error": repr(e)}
+    small_window = None
+    if multi_headline and not args.no_scaling_window:
+        try:
+            small_window = bench_scaling_window(ctx, args, rank, world, dist, barrier, preintegrate, n_frames=10, n_landmarks=1000, steps=50, warmup=5)
+        except Exception as e:
+            small_window = {"error": repr(e)}
 
     cpu = None
     if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
         from oracle import oracle_py as O
         O.build()
-        st, so = BAState(pb_full), BASummary(pb_full, trace=False)
-        O.solve(pb_full, st, so)  # warm-up
-        c_it, c_t, c_n = 0, 0.0, 0
-        while c_t < args.cpu_seconds and c_n < 2000:
+
+        def time_cpu(solve, budget):
             st, so = BAState(pb_full), BASummary(pb_full, trace=False)
-            t1 = time.perf_counter()
-            O.solve(pb_full, st, so)
-            c_t += time.perf_counter() - t1
-            c_it += so.num_iterations
-            c_n += 1
-        cpu = {"value": c_it / c_t, "unit": "BA iterations/s", "cores": 1, "kind": "port",
+            solve(pb_full, st, so)  # warm-up
+            c_it, c_t, c_n = 0, 0.0, 0
+            while c_t < budget and c_n < 2000:
+                st, so = BAState(pb_full), BASummary(pb_full, trace=False)
+                t1 = time.perf_counter()
+                solve(pb_full, st, so)
+                c_t += time.perf_counter() - t1
+                c_it += so.num_iterations
+                c_n += 1
+            return c_it / c_t, c_n, c_t
+        # two builds of the same restatement are timed: release style (-O3 -march=native of this host, FMA contraction on) and
+        # the checker build the parity tests use (-ffp-contract=off); the FASTER one is quoted (contraction does not always pay)
+        v_fast, c_n, c_t = time_cpu(O.solve_fast, 0.7 * args.cpu_seconds)
+        v_chk, _, _ = time_cpu(O.solve, 0.3 * args.cpu_seconds)
+        cpu = {"value": max(v_fast, v_chk), "unit": "BA iterations/s", "cores": 1, "kind": "port",
                "sample": "%d solves of the same window (%.1f s), single thread as the reference's num_threads=1 "
-                         "(solver_options.h:31); host has %d cores" % (c_n, c_t, os.cpu_count())}
+                         "(solver_options.h:31); host has %d cores" % (c_n, c_t, os.cpu_count()),
+               "build": "g++ -O3 -march=native (compiled on this host), FMA contraction on; dense-Schur restatement of the Ceres path "
+                        "(the reference configures SPARSE_SCHUR; it cannot be built here)",
+               "value_fast_build": v_fast, "value_checker_build": v_chk, "quoted": "the faster of the two builds", "checker_build": "-O3 -march=native -ffp-contract=off (the build the parity tests compare against)"}
 
     # ---- KLT leg (second half of BASELINE.json's metric): tracks/ms, pyramids resident, TUM-VI-sized frames ----
     klt = None
@@ -373,6 +423,11 @@ def main():
             "concurrent_windows": multi,
             "scaling_window": scaling_window,
         }
+        if world > 1:
+            out["single_gpu_same_workload"] = single_gpu
+            out["small_window"] = small_window
+            if single_gpu:
+                out["speedup_vs_single_gpu"] = value / single_gpu["value"]
         if cpu:
             out["speedup_vs_cpu_baseline"] = value / cpu["value"]
         sys.stdout.flush()

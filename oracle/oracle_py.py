@@ -26,7 +26,22 @@ def build(force=False):
     return LIB
 
 
+def solve_fast(problem, state, summary):
+    """oracle_ba_solve of the contraction-on build (liboracle_fast.so): bench.py's timed cpu_baseline only"""
+    global _fast
+    if _fast is None:
+        # rebuilt on the box it is timed on: -march=native must mean THIS host
+        subprocess.check_call(["make", "-s", "-B", "-C", HERE, "liboracle_fast.so"])
+        _fast = C.CDLL(os.path.join(HERE, "liboracle_fast.so"))
+        _fast.oracle_ba_solve.argtypes = [C.POINTER(capi.BAProblemC), C.POINTER(capi.BAStateC), C.POINTER(capi.BASummaryC)]
+    pbc, stc = problem.as_c(), state.as_c()
+    rc = _fast.oracle_ba_solve(C.byref(pbc), C.byref(stc), C.byref(summary.c))
+    assert rc == 0
+    return state, summary
+
+
 _lib = None
+_fast = None
 
 
 def lib():

@@ -27,6 +27,19 @@ def per_kernel(directory, counter):
     return {k: (s / n, n) for k, (s, n) in acc.items() if n}
 
 
+def source_sha256():
+    """Fingerprint of the kernel sources the counters were collected on (bench.py prints `traffic` only when it matches the
+    sources it runs: the GPU box has no .git, so the commit hash is not available there)"""
+    import hashlib
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "pvio_amd", "csrc")
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(root)):
+        if name.endswith((".hip", ".h", ".cpp")):
+            h.update(name.encode())
+            h.update(open(os.path.join(root, name), "rb").read())
+    return h.hexdigest()
+
+
 def main():
     fetch_dir, write_dir, out = sys.argv[1:4]
     fetch, write = per_kernel(fetch_dir, "FETCH_SIZE"), per_kernel(write_dir, "WRITE_SIZE")
@@ -45,7 +58,7 @@ def main():
             "FETCH_SIZE and WRITE_SIZE, ROCm 7.2, gfx950). Counter unit = KiB. Per MI355X_MICROARCH.md FETCH_SIZE reports 1/2 of the bytes "
             "of wide coalesced reads on gfx950 -> fetch_bytes_corrected = 2 * FETCH_SIZE * 1024 (upper bound for narrow access patterns); "
             "WRITE_SIZE is uncalibrated.")
-    json.dump({"note": note, "kernels": kernels}, open(out, "w"), indent=1)
+    json.dump({"note": note, "source_sha256": source_sha256(), "kernels": kernels}, open(out, "w"), indent=1)
     print(json.dumps(kernels, indent=1))
 
 

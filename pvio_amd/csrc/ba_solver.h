@@ -77,6 +77,7 @@ class BASolver {
     hipGraph_t graph_ = nullptr;
     hipGraphExec_t graph_exec_ = nullptr;
     int graph_slots_ = 0;
+    bool sharded_graph_failed_ = false; // capturing the collectives failed once: eager launches from then on
     Comm *comm_ = nullptr;
     std::string err_;
     std::vector<double> h_init_fs_, h_init_rho_;

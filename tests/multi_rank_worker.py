@@ -42,9 +42,14 @@ def main():
     assert lib.pvio_hip_comm_init(ctx.ctx, uid, rank, world) == 0
     st, sm = ctx.solve(shard)
     l0, l1 = shard.meta["lm_range"] if world > 1 else (0, pb.n_landmarks)
+    # marginalize_frame on the sharded window: every rank sums its landmarks' part, the reduced buffer is all-reduced
+    marg = {}
+    if pb.use_inertial:
+        S, s_, IM, iv = ctx.marginalize(shard, st, 0)
+        marg = dict(marg_IM=IM, marg_iv=iv)
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), frame_state=st.frame_state, rho=st.lm_inv_depth, l0=l0, l1=l1,
              iters=sm.num_iterations, term=sm.termination, costs=np.array([t["cost"] for t in sm.trace()]),
-             succ=np.array([t["step_is_successful"] for t in sm.trace()]), gmax=np.array([t["gradient_max_norm"] for t in sm.trace()]))
+             succ=np.array([t["step_is_successful"] for t in sm.trace()]), gmax=np.array([t["gradient_max_norm"] for t in sm.trace()]), **marg)
     dist.barrier()
     dist.destroy_process_group()
 

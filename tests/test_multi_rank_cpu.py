@@ -1,4 +1,4 @@
-"""world_size-2 (and 3) CPU test of the landmark-sharded bundle adjustment: gloo stands in for RCCL, the fiber emulator
+"""world_size-2 (3, 4, 8) CPU test of the landmark-sharded bundle adjustment: gloo stands in for RCCL, the fiber emulator
 for the GPU.  Every rank must take the same decisions and reproduce the unsharded oracle."""
 import os
 import subprocess
@@ -15,7 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 # mode 2 = the matrix-core form of k_linearize (what sharded large windows run: bench.py's scaling_window leg)
-@pytest.mark.parametrize("case,world,mode", [("vio_partial", 2, 0), ("vio_plane", 2, 0), ("vision_partial", 3, 0), ("vio_partial", 2, 2)])
+@pytest.mark.parametrize("case,world,mode", [("vio_partial", 2, 0), ("vio_plane", 2, 0), ("vision_partial", 3, 0), ("vio_partial", 2, 2),
+                                             ("vio_partial", 4, 0), ("vio_partial", 8, 0), ("vio_13_frames_global_matrix", 2, 0)])
 def test_sharded_solve_matches_oracle(oracle, case, world, mode):
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "hipemu"), "libpvio_hipemu.so"])
     pb = ba_compare.make(oracle, **ba_compare.CASES[case])
@@ -38,3 +39,9 @@ def test_sharded_solve_matches_oracle(oracle, case, world, mode):
             np.testing.assert_allclose(z["frame_state"], st0.frame_state, rtol=0, atol=1e-6)  # identical on every rank
             rho[int(z["l0"]):int(z["l1"])] = z["rho"]
         np.testing.assert_allclose(rho, st0.lm_inv_depth, rtol=0, atol=1e-6)
+        if pb.use_inertial:  # the prior every rank builds from its shard + the all-reduce = the unsharded one
+            _, _, IM0, iv0 = oracle.marginalize(pb, st0, 0)
+            for r in range(world):
+                z = np.load(os.path.join(d, "rank%d.npz" % r))
+                np.testing.assert_allclose(z["marg_IM"], IM0, rtol=1e-5, atol=1e-7 * np.abs(IM0).max())
+                np.testing.assert_allclose(z["marg_iv"], iv0, rtol=1e-5, atol=1e-6 * np.abs(iv0).max())
