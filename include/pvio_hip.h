@@ -125,7 +125,8 @@ typedef struct pvio_ba_problem {
     /* solver options (solver_options.h:26-33); everything else is a Ceres 1.14 default                   */
     int32_t max_iterations;        /* config->solver_iteration_limit()                                   */
     int32_t reserved0;
-    double max_solver_time;        /* config->solver_time_limit() [s]                                    */
+    double max_solver_time;        /* config->solver_time_limit() [s]; checked between replays of the iteration
+                                      graph (one replay = every iteration of an ordinary solve), <= 0: no limit     */
 
     /* Rotation priors -- the `RotationPriorFactor` BASELINE.json's north_star names.  NO REFERENCE COUNTERPART: the class
      * does not exist in the reference @ v0 (name-mapping note).  Defined as that note prescribes, as

@@ -109,6 +109,22 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st) {
     const int N = pb->n_frames, M = pb->n_landmarks, F = pb->n_obs;
     if (N < 1 || N > kMaxFrames) return fail(PVIO_ERR_UNSUPPORTED, "n_frames must be in [1, 32]");
     if (M < 0 || F < 0 || (M > 0 && !st->lm_inv_depth)) return fail(PVIO_ERR_INVALID_ARGUMENT, "bad landmark arrays");
+    if (!pb->frame_fixed || !pb->cam_extrinsic || !pb->imu_extrinsic || !pb->sqrt_inv_cov || !pb->intrinsics) return fail(PVIO_ERR_INVALID_ARGUMENT, "null per-frame array");
+    if (M > 0 && (!pb->lm_anchor_frame || !pb->lm_anchor_z || !pb->lm_obs_ptr)) return fail(PVIO_ERR_INVALID_ARGUMENT, "null landmark array");
+    if (F > 0 && (!pb->obs_frame || !pb->obs_z)) return fail(PVIO_ERR_INVALID_ARGUMENT, "null observation array");
+    if (M > 0 && (pb->lm_obs_ptr[0] != 0 || pb->lm_obs_ptr[M] != F)) return fail(PVIO_ERR_INVALID_ARGUMENT, "lm_obs_ptr must start at 0 and end at n_obs");
+    if (pb->prior_n < 0 || pb->prior_n > N || pb->max_iterations < 0 || pb->n_plane_factors < 0) return fail(PVIO_ERR_INVALID_ARGUMENT, "negative count / prior_n > n_frames");
+    if (pb->prior_n > 0 && (!pb->prior_frames || !pb->prior_S || !pb->prior_s || !pb->prior_lin_state)) return fail(PVIO_ERR_INVALID_ARGUMENT, "null prior array");
+    if (pb->use_inertial && (!pb->preint_valid || !pb->preint_delta || !pb->preint_sqrt_inv_cov || !pb->preint_jacobian)) return fail(PVIO_ERR_INVALID_ARGUMENT, "null pre-integration array");
+    if (pb->n_plane_factors > 0) {
+        if (!pb->plane_obs_ptr || !pb->plane_obs_frame || !pb->plane_obs_z || !pb->plane_normal || !pb->plane_distance) return fail(PVIO_ERR_INVALID_ARGUMENT, "null plane array");
+        if (pb->plane_obs_ptr[0] != 0) return fail(PVIO_ERR_INVALID_ARGUMENT, "plane_obs_ptr must start at 0");
+        for (int f = 0; f < pb->n_plane_factors; ++f) {
+            if (pb->plane_obs_ptr[f + 1] < pb->plane_obs_ptr[f]) return fail(PVIO_ERR_INVALID_ARGUMENT, "plane_obs_ptr is not a valid CSR");
+            for (int o = pb->plane_obs_ptr[f]; o < pb->plane_obs_ptr[f + 1]; ++o)
+                if (pb->plane_obs_frame[o] < 0 || pb->plane_obs_frame[o] >= N) return fail(PVIO_ERR_INVALID_ARGUMENT, "plane observation frame out of range");
+        }
+    }
     if (check(hipSetDevice(device_), "hipSetDevice")) return PVIO_ERR_HIP;
     Dims dm{};
     dm.N = N, dm.M = M, dm.F = F;
@@ -118,6 +134,7 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st) {
     dm.P = dm.d * N, dm.P6 = 6 * N;
     dm.n_tasks = 4 * N * (N + 1) / 2;
     dm.max_iter = pb->max_iterations;
+    max_solver_time_ = pb->max_solver_time > 0 ? pb->max_solver_time : 0.0;
     dm.world = world_, dm.rank = rank_;
     dm.n_plane = pb->n_plane_factors;
 
@@ -127,7 +144,7 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st) {
     int maxK = 1;
     for (int l = 0; l < M; ++l) {
         const int b = pb->lm_obs_ptr[l], e = pb->lm_obs_ptr[l + 1];
-        if (e < b || e > F) return fail(PVIO_ERR_INVALID_ARGUMENT, "lm_obs_ptr is not a valid CSR");
+        if (b < 0 || e < b || e > F) return fail(PVIO_ERR_INVALID_ARGUMENT, "lm_obs_ptr is not a valid CSR");
         const int a = pb->lm_anchor_frame[l];
         if (a < 0 || a >= N) return fail(PVIO_ERR_INVALID_ARGUMENT, "anchor frame out of range");
         if (e > b) pose_used[a] = 1;
@@ -533,6 +550,13 @@ int BASolver::solve(pvio_ba_summary *sum, pvio_ba_kernel_times *prof) {
         if (check(hipEventRecord(ev1_, stream_), "event")) return PVIO_ERR_HIP;
         if (check(hipStreamSynchronize(stream_), "solve sync")) return PVIO_ERR_HIP;
         if (h_ctrl_->done || ++rounds > 16) break;
+        // max_solver_time_in_seconds (solver_options.h:30): the state machine runs on the device, so the wall clock is looked at
+        // between replays of the slot graph only (one replay covers every iteration of an ordinary solve): NO_CONVERGENCE at
+        // the iterate reached, like Ceres' time-limit exit
+        if (max_solver_time_ > 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > max_solver_time_) {
+            h_ctrl_->done = 1, h_ctrl_->termination = PVIO_TERM_NO_CONVERGENCE;
+            break;
+        }
     }
     if (prof) {
         for (auto &e : pev) (void)hipEventDestroy(e);

@@ -77,6 +77,7 @@ class BASolver {
     hipGraph_t graph_ = nullptr;
     hipGraphExec_t graph_exec_ = nullptr;
     int graph_slots_ = 0;
+    double max_solver_time_ = 0.0; // seconds; checked between graph replays
     bool sharded_graph_failed_ = false; // capturing the collectives failed once: eager launches from then on
     Comm *comm_ = nullptr;
     std::string err_;

@@ -655,13 +655,15 @@ int Klt::track(const Image *prev, const Image *next, int n, const float *prev_xy
             err_ = "hipMalloc failed";
             return PVIO_ERR_OUT_OF_MEMORY;
         }
-        pts_cap_ = need * 2;
+        pts_cap_ = 0; // the capacity counts only once BOTH buffers exist
         if (h_pts_) (void)hipHostFree(h_pts_);
         h_pts_ = nullptr;
-        if (hipHostMalloc(&h_pts_, pts_cap_) != hipSuccess) {
+        if (hipHostMalloc(&h_pts_, need * 2) != hipSuccess) {
+            h_pts_ = nullptr;
             err_ = "hipHostMalloc failed";
             return PVIO_ERR_OUT_OF_MEMORY;
         }
+        pts_cap_ = need * 2;
     }
     float *d_prev = static_cast<float *>(d_pts_), *d_next = d_prev + 2 * (size_t)n;
     uint8_t *d_st = reinterpret_cast<uint8_t *>(d_next + 2 * (size_t)n);

@@ -57,6 +57,9 @@ GrayImage decode_png_gray(const uint8_t *data, size_t size) {
     default: throw std::runtime_error("png: unsupported colour type (palette?)");
     }
     const size_t bpp = (size_t)channels * depth / 8, row = bpp * w;
+    // the header is untrusted: deflate expands at most ~1032 : 1, so a stream this short cannot hold an image this large
+    // (refused before the allocation instead of failing in it with bad_alloc)
+    if (w == 0 || h == 0 || (row + 1) * (double)h > 1032.0 * (double)idat.size() + 64.0) throw std::runtime_error("png: image size does not match the compressed data");
     std::vector<uint8_t> raw((row + 1) * h);
     uLongf out_len = (uLongf)raw.size();
     if (uncompress(raw.data(), &out_len, idat.data(), (uLong)idat.size()) != Z_OK || out_len != raw.size()) throw std::runtime_error("png: inflate failed");

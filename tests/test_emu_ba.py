@@ -57,6 +57,38 @@ def test_rejects_bad_input(emu_ctx, oracle):
     pb.obs_frame[1] = pb.obs_frame[0]  # same target frame twice for one landmark
     with pytest.raises(HipError):
         emu_ctx.solve(pb)
+    # CSR that does not start at 0 / is not monotone, plane observation outside the window, negative counts, a second
+    # rotation prior on one frame: PVIO_ERR_INVALID_ARGUMENT / UNSUPPORTED, never an out-of-bounds read
+    def broken(edit, **kw):
+        q = ba_compare.make(oracle, **dict(ba_compare.CASES["plane"], **kw))
+        edit(q)
+        with pytest.raises(HipError):
+            emu_ctx.solve(q)
+
+    def shift_ptr(q):
+        q.lm_obs_ptr = q.lm_obs_ptr.copy()
+        q.lm_obs_ptr[0] = -1
+    broken(shift_ptr)
+
+    def dip(q):
+        q.lm_obs_ptr = q.lm_obs_ptr.copy()
+        q.lm_obs_ptr[2] = q.lm_obs_ptr[1] - 1
+    broken(dip)
+
+    def plane_oob(q):
+        q.plane_obs_frame = q.plane_obs_frame.copy()
+        q.plane_obs_frame[3] = q.n_frames
+    broken(plane_oob)
+
+    def neg_iter(q):
+        q.max_iterations = -3
+    broken(neg_iter)
+
+    def two_rot(q):
+        q.rot_prior_frame = np.array([1, 1], np.int32)
+        q.rot_prior_q0 = np.tile([0, 0, 0, 1.0], (2, 1))
+        q.rot_prior_sqrt_info = np.tile(np.eye(3).ravel(), (2, 1))
+    broken(two_rot)
 
 
 import marg_compare  # noqa: E402
