@@ -4,6 +4,7 @@ tests are tests/test_gpu_ba.py (-m gpu, same checks through libpvio_hip.so)."""
 import os
 import subprocess
 
+import numpy as np
 import pytest
 
 import ba_compare
