@@ -153,6 +153,38 @@ def test_gpu_both_linearize_modes_agree_on_a_large_window(oracle):
     np.testing.assert_allclose(out[0][3], out[1][3], rtol=1e-9)
 
 
+def test_gpu_full_size_window_matches_the_oracle_golden(oracle):
+    """BASELINE.json configs[4] at full size against the oracle's states: the oracle's solve of the same (regenerated,
+    fingerprinted) window was run once offline and frozen in tests/golden/ba_vio_30x50000.npz (make_golden_large.py): same
+    accept / reject trace and termination, costs and trust-region radii, frame states after EVERY iteration and the final
+    50 000 inverse depths within the 1e-6 bar of north_star."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden_large
+    from pvio_amd.solver import HipContext
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ba_vio_30x50000.npz"))
+    pb = ba_compare.make(oracle, n_frames=30, n_landmarks=50000, use_inertial=True)
+    assert make_golden_large.fingerprint(pb) == str(g["inputs_sha256"]), "the regenerated window is not the one the golden was computed on"
+    ctx = HipContext(device=0)
+    st, sm = ctx.solve(pb)
+    ctx.close()
+    tr = sm.trace()
+    assert sm.termination == int(g["termination"]) and sm.num_iterations == int(g["num_iterations"]) and len(tr) == len(g["costs"])
+    assert ([t["step_is_successful"] for t in tr] == g["successful"]).all()
+    np.testing.assert_allclose([t["cost"] for t in tr], g["costs"], rtol=1e-7)
+    np.testing.assert_allclose([t["trust_region_radius"] for t in tr], g["radius"], rtol=1e-6)
+    nfs = pb.n_frames * 16
+    worst = 0.0
+    for k in range(len(tr)):
+        d = np.abs(sm.trace_states[k][:nfs] - g["frame_states"][k]).max()
+        worst = max(worst, float(d))
+        assert d <= ba_compare.STATE_TOL, (k, d)
+    np.testing.assert_allclose(st.frame_state, g["final_frame_state"], rtol=0, atol=ba_compare.STATE_TOL)
+    np.testing.assert_allclose(st.lm_inv_depth, g["final_inv_depth"], rtol=0, atol=ba_compare.STATE_TOL)
+    print("30x50000 vs the oracle golden: max frame-state difference over all iterations %.2e, inverse depths %.2e" % (worst, np.abs(st.lm_inv_depth - g["final_inv_depth"]).max()))
+
+
 def test_gpu_full_size_window_properties(oracle):
     """BASELINE.json configs[4] (30 KF x 50 000 landmarks, 1.45 M factors, full VIO factor set) at full size, through
     properties that do not need the oracle's solve: the cost the solver reports for its final state is the cost the
