@@ -1,9 +1,9 @@
 #!/bin/bash
 # Collects the round's evidence on the GPU box: run from the repo root through gpurun, e.g.
-#   gpurun --timeout 1500 -- 'bash profiles/collect.sh r1'
+#   gpurun --timeout 1500 -- 'bash profiles/collect.sh r2'
 # Everything lands in gpurun_out/<tag>_*; copy what should be judged into profiles/.
 set -u
-TAG=${1:-r1}
+TAG=${1:-r2}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 mkdir -p $OUT
@@ -28,6 +28,10 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_pro
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_prof_write -- python $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-scaling-window > $OUT/${TAG}_prof_write.log 2>&1
 python $R/profiles/summarize_pmc.py $OUT/${TAG}_prof_fetch $OUT/${TAG}_prof_write $OUT/${TAG}_pmc_hbm.json > /dev/null
 find $OUT/${TAG}_prof_stats -name '*kernel_stats.csv' -exec cp {} $OUT/${TAG}_kernel_stats_bench_vio.csv \;
+# the multi-GPU code path with the one rank there is: process group, RCCL communicator, sharded iteration (captured in the hipGraph)
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29555 $R/bench.py --gpus 1 --force-sharded --steps 100 --warmup 10 --no-klt --no-cpu-baseline > $OUT/${TAG}_bench_sharded_1rank.json 2> $OUT/${TAG}_bench_sharded_1rank.err
+# end to end: rendered sequence -> front end -> PnP -> sliding-window BA (tests/test_host_headless.py prints the trajectory error)
+(cd $R && python -m pytest tests/test_host_headless.py -m gpu -q -s 2>&1 | grep "^headless") > $OUT/${TAG}_headless.txt
 # complete keyframe solves (upload + solve + download), LK launch time against the batch size, dense kernel of large windows
 (cd $R && python tests/prof_upload.py) > $OUT/${TAG}_prof_upload.txt 2>&1
 (cd $R && python tests/prof_klt.py) > $OUT/${TAG}_prof_klt.txt 2>&1

@@ -70,6 +70,7 @@ inline size_t ptr_hash(const void *p) {
     x ^= x >> 17, x *= 0x9E3779B97F4A7C15ull, x ^= x >> 29;
     return (size_t)x;
 }
+constexpr int kMaxWindow = 64;
 class FrameIndex { // <= kMaxFrames entries
   public:
     void clear() {
@@ -137,6 +138,64 @@ class PtrSet {
     size_t used_ = 0;
 };
 
+// ---- incremental flattening -------------------------------------------------------------
+// From one keyframe solve to the next almost every track is the track it was, plus one observation.  Walking its
+// std::map of observations again (pointer chasing through the reference's object graph: 215 us of a 1.1 ms keyframe solve
+// at 10 x 1000) is replaced by a per-track cache of the flattened list -- (frame id, keypoint) of every non-anchor
+// observation, in keypoint_map() order -- validated by a signature that every way the reference changes a track alters:
+// (track id, number of keypoints, first frame id, last frame id).  Hit: the list is replayed (frame ids -> window indices by
+// a merge, both ascending).  Grown by exactly the newest observation: that one is appended.  Anything else: rebuilt.
+// No hooks in the reference's map layer are needed; the output is identical to a walk from scratch
+// (PVIO_HIP_FLATTEN_VERIFY=1 re-walks every window and compares; the headless tests run with it).
+class ObsCache {
+  public:
+    struct Entry {
+        const Track *key = nullptr;
+        size_t id = 0, nkp = 0, first_id = 0, last_id = 0;
+        uint32_t off = 0, cnt = 0;
+    };
+    Entry *find(const Track *t) {
+        if (slots_.empty()) return nullptr;
+        const size_t mask = slots_.size() - 1;
+        for (size_t h = ptr_hash(t) & mask;; h = (h + 1) & mask) {
+            if (!slots_[h].key) return nullptr;
+            if (slots_[h].key == t) return &slots_[h];
+        }
+    }
+    Entry *insert(const Track *t) {
+        if (2 * (used_ + 1) > slots_.size()) rehash(std::max<size_t>(256, 4 * (used_ + 1)));
+        const size_t mask = slots_.size() - 1;
+        size_t h = ptr_hash(t) & mask;
+        while (slots_[h].key && slots_[h].key != t) h = (h + 1) & mask;
+        if (!slots_[h].key) ++used_;
+        slots_[h].key = t;
+        return &slots_[h];
+    }
+    // lists are append-only between resets; dead lists are dropped wholesale once they outweigh the live ones
+    void begin_window(size_t live_obs_estimate) {
+        if (fid_.size() > 8 * live_obs_estimate + 65536) clear();
+    }
+    void clear() {
+        slots_.clear(), fid_.clear(), z_.clear(), used_ = 0;
+    }
+    std::vector<size_t> fid_; // frame id per cached observation
+    std::vector<double> z_;   // 2 per cached observation
+
+  private:
+    void rehash(size_t n) {
+        size_t cap = 256;
+        while (cap < n) cap <<= 1;
+        std::vector<Entry> old;
+        old.swap(slots_);
+        slots_.assign(cap, Entry());
+        used_ = 0;
+        for (const Entry &e : old)
+            if (e.key) *insert(e.key) = e;
+    }
+    std::vector<Entry> slots_;
+    size_t used_ = 0;
+};
+
 void put_q(std::vector<double> &v, size_t off, const quaternion &q) {
     for (int k = 0; k < 4; ++k) v[off + k] = q.coeffs()[k]; // x y z w
 }
@@ -149,7 +208,7 @@ void put_m3(std::vector<double> &v, size_t off, const matrix<3> &m) { // -> row-
 // keypoint index (:91-103); reprojection blocks per track in ascending frame id with the anchor first (track.h:69).
 // (Ceres sums residual blocks frame-major; the flat CSR is landmark-major -- a different summation order, i.e. a
 // difference at rounding level only.)
-void flatten(Map *map, Config *config, bool use_inertial, bool for_marginalization, Flat &F) {
+void flatten(Map *map, Config *config, bool use_inertial, bool for_marginalization, Flat &F, ObsCache *cache = nullptr) {
     const int N = (int)map->frame_num();
     FrameIndex fidx;
     for (int i = 0; i < N; ++i) fidx.put(map->get_frame(i), i);
@@ -182,6 +241,22 @@ void flatten(Map *map, Config *config, bool use_inertial, bool for_marginalizati
     static thread_local PtrSet visited; // keeps its table between solves
     visited.reset(F.lm_track.size());
     F.lm_track.clear(), F.lm_anchor.clear(), F.lm_ptr.assign(1, 0), F.obs_frame.clear(), F.lm_z.clear(), F.obs_z.clear(), F.rho.clear();
+    size_t win_id[kMaxWindow];
+    for (int i = 0; i < N && i < kMaxWindow; ++i) win_id[i] = map->get_frame(i)->id();
+    if (N > kMaxWindow) cache = nullptr;
+    if (cache) cache->begin_window(F.obs_frame.capacity());
+    auto walk = [&](Track *track, Frame *anchor_frame, ObsCache::Entry *e) { // from scratch; fills the cache entry as well
+        if (e) e->off = (uint32_t)cache->fid_.size(), e->cnt = 0;
+        for (const auto &kv : track->keypoint_map()) {
+            if (kv.first == anchor_frame) continue;              // the anchor observation has no factor (:149)
+            const auto &z = kv.first->get_keypoint(kv.second);
+            if (e) cache->fid_.push_back(kv.first->id()), cache->z_.push_back(z(0)), cache->z_.push_back(z(1)), ++e->cnt;
+            const int t = fidx.find(kv.first);
+            if (t < 0) continue;
+            F.obs_frame.push_back(t);
+            F.obs_z.push_back(z(0)), F.obs_z.push_back(z(1));
+        }
+    };
     auto add_landmark = [&](Track *track) {
         if (!visited.insert(track)) return;
         auto first = track->first_keypoint();
@@ -192,13 +267,44 @@ void flatten(Map *map, Config *config, bool use_inertial, bool for_marginalizati
         const auto &za = first.first->get_keypoint(first.second);
         F.lm_z.push_back(za(0)), F.lm_z.push_back(za(1));
         F.rho.push_back(track->landmark.inv_depth);
-        for (const auto &kv : track->keypoint_map()) {
-            if (kv.first == first.first) continue;              // the anchor observation has no factor (:149)
-            const int t = fidx.find(kv.first);
-            if (t < 0) continue;
-            const auto &z = kv.first->get_keypoint(kv.second);
-            F.obs_frame.push_back(t);
-            F.obs_z.push_back(z(0)), F.obs_z.push_back(z(1));
+        if (!cache) {
+            walk(track, first.first, nullptr);
+        } else {
+            const size_t nkp = track->keypoint_num(), first_id = first.first->id();
+            const auto last = track->last_keypoint();
+            const size_t last_id = last.first->id();
+            ObsCache::Entry *e = cache->find(track);
+            bool hit = e && e->id == track->id() && e->first_id == first_id;
+            if (hit && e->nkp == nkp && e->last_id == last_id) {
+                // unchanged
+            } else if (hit && e->nkp + 1 == nkp && nkp >= 2 && std::prev(track->keypoint_map().end(), 2)->first->id() == e->last_id) {
+                // grown by its newest observation: the list moves to the end of the store with the new entry behind it
+                const uint32_t off = (uint32_t)cache->fid_.size();
+                for (uint32_t k = 0; k < e->cnt; ++k) {
+                    cache->fid_.push_back(cache->fid_[e->off + k]);
+                    cache->z_.push_back(cache->z_[2 * (size_t)(e->off + k)]), cache->z_.push_back(cache->z_[2 * (size_t)(e->off + k) + 1]);
+                }
+                const auto &z = last.first->get_keypoint(last.second);
+                cache->fid_.push_back(last_id), cache->z_.push_back(z(0)), cache->z_.push_back(z(1));
+                e->off = off, e->cnt += 1, e->nkp = nkp, e->last_id = last_id;
+            } else {
+                hit = false;
+            }
+            if (hit) { // replay: cached frame ids and the window's frame ids are both ascending
+                int w = 0;
+                for (uint32_t k = 0; k < e->cnt; ++k) {
+                    const size_t fid = cache->fid_[e->off + k];
+                    while (w < N && win_id[w] < fid) ++w;
+                    if (w < N && win_id[w] == fid) {
+                        F.obs_frame.push_back(w);
+                        F.obs_z.push_back(cache->z_[2 * (size_t)(e->off + k)]), F.obs_z.push_back(cache->z_[2 * (size_t)(e->off + k) + 1]);
+                    }
+                }
+            } else {
+                e = cache->insert(track);
+                e->id = track->id(), e->nkp = nkp, e->first_id = first_id, e->last_id = last_id;
+                walk(track, first.first, e);
+            }
         }
         F.lm_ptr.push_back((int32_t)F.obs_frame.size());
     };
@@ -352,12 +458,16 @@ struct DefaultConfig : Config { // solver_iteration_limit / solver_time_limit / 
 } // namespace
 
 // diagnostics (tests/host/roundtrip.cpp): seconds per flattening of `map`, steady state (the arrays keep their capacity)
+// reps > 0: walk from scratch every time; reps < 0: |reps| repetitions with the observation cache (steady state of an unchanged window)
 double flatten_seconds(Map *map, bool use_inertial, int reps) {
     DefaultConfig dc;
     Flat F;
-    flatten(map, &dc, use_inertial, false, F);
+    ObsCache cache;
+    ObsCache *c = reps < 0 ? &cache : nullptr;
+    if (reps < 0) reps = -reps;
+    flatten(map, &dc, use_inertial, false, F, c);
     const auto t0 = std::chrono::steady_clock::now();
-    for (int i = 0; i < reps; ++i) flatten(map, &dc, use_inertial, false, F);
+    for (int i = 0; i < reps; ++i) flatten(map, &dc, use_inertial, false, F, c);
     return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() / (reps > 0 ? reps : 1);
 }
 
@@ -368,6 +478,10 @@ struct BundleAdjustor::BundleAdjustorSolver { // the pimpl of bundle_adjustor.h:
         static thread_local Flat F; // keeps the capacity of its arrays from one keyframe to the next
         return F;
     }
+    static ObsCache &obs_cache() {
+        static thread_local ObsCache c; // the flattened observation lists of the tracks, kept from one keyframe to the next
+        return c;
+    }
 
     bool solve(Map *map, Config *config, bool use_inertial) {
         pvio_hip_ctx *ctx = process_ctx();
@@ -375,9 +489,17 @@ struct BundleAdjustor::BundleAdjustorSolver { // the pimpl of bundle_adjustor.h:
         DefaultConfig dc;
         Flat &F = window();
         static const bool timing = std::getenv("PVIO_HIP_TIMING") != nullptr; // diagnostics: host share of a keyframe solve
+        const bool verify = std::getenv("PVIO_HIP_FLATTEN_VERIFY") != nullptr; // tests: the cached flattening against a walk from scratch
+        static const bool no_cache = std::getenv("PVIO_HIP_FLATTEN_NOCACHE") != nullptr;
         const auto t0 = std::chrono::steady_clock::now();
-        flatten(map, config ? config : &dc, use_inertial, false, F);
+        flatten(map, config ? config : &dc, use_inertial, false, F, no_cache ? nullptr : &obs_cache());
         const auto t1 = std::chrono::steady_clock::now();
+        if (verify) {
+            Flat G;
+            flatten(map, config ? config : &dc, use_inertial, false, G, nullptr);
+            if (G.lm_track != F.lm_track || G.lm_anchor != F.lm_anchor || G.lm_ptr != F.lm_ptr || G.obs_frame != F.obs_frame || G.obs_z != F.obs_z || G.lm_z != F.lm_z || G.rho != F.rho)
+                throw std::logic_error("incremental flattening differs from the walk from scratch");
+        }
         F.quality.assign(F.lm_track.size(), 0.0), F.valid.assign(F.lm_track.size(), 1);
         pvio_ba_state st{F.fstate.data(), F.rho.data(), F.quality.data(), F.valid.data()};
         pvio_ba_summary sum;

@@ -84,6 +84,9 @@ def render_sequence(n_frames, fps=20.0, imu_rate=200.0, t_start=0.0):
 
 
 def run(lib, n_frames, window, gap, distance=25.0):
+    import os
+    # every keyframe solve also re-walks the Map from scratch and compares with the incrementally flattened window
+    os.environ["PVIO_HIP_FLATTEN_VERIFY"] = "1"
     images, times, imu_t, imu_w, imu_a, gt, q_bc, p_bc = render_sequence(n_frames)
     out, stats = np.zeros((n_frames, 8)), np.zeros(4, np.int32)
     err = C.create_string_buffer(512)
