@@ -555,7 +555,7 @@ struct BundleAdjustor::BundleAdjustorSolver { // the pimpl of bundle_adjustor.h:
         pvio_hip_ctx *ctx = process_ctx();
         if (!ctx || index >= map->frame_num() || map->frame_num() < 2) return;
         DefaultConfig dc;
-        flatten(map, &dc, true, true, F);
+        flatten(map, &dc, true, true, F, &obs_cache()); // the tracks were flattened by the last solve: their lists are replayed
         const size_t n = map->frame_num() - 1, D = 15 * n;
         std::vector<double> S(D * D, 0.0), s(D, 0.0); // row-major, like the C ABI
         pvio_ba_state st{F.fstate.data(), F.rho.data(), nullptr, nullptr};
