@@ -27,8 +27,9 @@ CASES = {
     "vio_20_frames_panels": dict(n_frames=20, n_landmarks=120, use_inertial=True, visibility=7),
     "vio_32_frames_narrow_panels": dict(n_frames=32, n_landmarks=160, use_inertial=True, visibility=8),
 }
-# too slow for the fiber emulator (a minute): checked on the GPU only
-GPU_ONLY = {"vio_32_frames_narrow_panels"}
+# too slow for the fiber emulator (half a minute and more): checked on the GPU only (the 13-frame window keeps the HBM-matrix
+# form of the dense kernel in the CPU suite)
+GPU_ONLY = {"vio_32_frames_narrow_panels", "vio_20_frames_panels"}
 BIG_CASES = {
     # the configuration the metric is quoted on (10 KF x 1000 landmarks), vision-only and full VIO
     "metric_10x1000_vision": dict(n_frames=10, n_landmarks=1000),

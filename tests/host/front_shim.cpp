@@ -82,6 +82,34 @@ int host_image_track(const uint8_t *img0, const uint8_t *img1, int w, int h, int
     return rc;
 }
 
+// pvio::Image::evaluate (both overloads): value and gradient of the bicubic sample of pyramid level `level` at n points
+int host_image_evaluate(const uint8_t *img, int w, int h, int level, int n, const double *uv, double *val, double *grad, char *err, int err_len) {
+    pvio_hip_ctx *ctx = nullptr;
+    pvio_hip_opts opts;
+    std::memset(&opts, 0, sizeof(opts));
+    if (pvio_hip_create(&opts, &ctx) != 0 || !ctx) {
+        std::strncpy(err, "pvio_hip_create failed (no GPU?)", (size_t)err_len - 1);
+        return -1;
+    }
+    int rc = 0;
+    try {
+        HipImage a(ctx, img, w, h, w, 0.0);
+        a.preprocess();
+        const Image *im = &a;
+        for (int i = 0; i < n; ++i) {
+            vector<2> u(uv[2 * i], uv[2 * i + 1]), d;
+            val[i] = im->evaluate(u, d, level);
+            grad[2 * i] = d[0], grad[2 * i + 1] = d[1];
+            if (im->evaluate(u, level) != val[i]) throw std::runtime_error("the two evaluate() overloads disagree");
+        }
+    } catch (const std::exception &e) {
+        std::strncpy(err, e.what(), (size_t)err_len - 1);
+        rc = -1;
+    }
+    pvio_hip_destroy(ctx);
+    return rc;
+}
+
 int host_ransac(int n, const float *p, const float *q, double threshold, double confidence, uint8_t *mask, double *F) {
     std::vector<uint8_t> m;
     const int good = find_fundamental_ransac(n, p, q, threshold, confidence, m, F);

@@ -214,3 +214,55 @@ def test_image_seam_with_ransac_rejects_planted_outliers(host, oracle):
     # what it removed is, on average, worse than what it kept
     if (lk & ~rs).any():
         assert e[lk & ~rs].mean() >= e[rs].mean()
+
+
+def test_image_evaluate_is_the_bicubic_sample_of_the_preprocessed_level(host, oracle):
+    """pvio::Image::evaluate(u[, ddu], level) (pvio.h:125-126; opencv_image.cpp:36-52 = ceres::BiCubicInterpolator over the level's
+    pixels, Catmull-Rom, indices clamped to the image, level scale = 1 / integer quotient of the extents): on integer pixel
+    positions of level 0 it returns the CLAHE'd pixel itself, in between it equals a numpy restatement of the spline, and the
+    gradient matches central differences of the value."""
+    from pvio_amd import synth
+    w, h = 160, 128
+    img = synth.make_image_pair(w, h, 8)[0]
+    levels = oracle.build_pyramid(oracle.clahe(img))
+    rng = np.random.default_rng(3)
+
+    def run(level, uv):
+        uv = np.ascontiguousarray(uv, float)
+        val, grad = np.zeros(len(uv)), np.zeros((len(uv), 2))
+        err = C.create_string_buffer(256)
+        host.host_image_evaluate.restype = C.c_int
+        rc = host.host_image_evaluate(_p(np.ascontiguousarray(img), u8p), C.c_int(w), C.c_int(h), C.c_int(level), C.c_int(len(uv)), _p(uv, f64p), _p(val, f64p),
+                                      _p(grad, f64p), err, C.c_int(256))
+        assert rc == 0, err.value.decode()
+        return val, grad
+
+    def cubic(p0, p1, p2, p3, x):
+        a, b, c = 0.5 * (-p0 + 3 * p1 - 3 * p2 + p3), 0.5 * (2 * p0 - 5 * p1 + 4 * p2 - p3), 0.5 * (-p0 + p2)
+        return p1 + x * (c + x * (b + x * a))
+
+    def ref(level, u):
+        L = levels[level][0].astype(float) if isinstance(levels[level], (tuple, list)) else levels[level].astype(float)
+        hh, ww = L.shape
+        sx, sy = 1.0 / ((w - 1) // (ww - 1)), 1.0 / ((h - 1) // (hh - 1))
+        c, r = u[0] * sx, u[1] * sy
+        col, row = int(np.floor(c)), int(np.floor(r))
+        px = lambda rr, cc: L[min(max(rr, 0), hh - 1), min(max(cc, 0), ww - 1)]
+        f = [cubic(px(row - 1 + k, col - 1), px(row - 1 + k, col), px(row - 1 + k, col + 1), px(row - 1 + k, col + 2), c - col) for k in range(4)]
+        return cubic(f[0], f[1], f[2], f[3], r - row)
+
+    ints = np.column_stack([rng.integers(0, w, 20), rng.integers(0, h, 20)]).astype(float)
+    v, _ = run(0, ints)
+    L0 = levels[0][0] if isinstance(levels[0], (tuple, list)) else levels[0]
+    assert (v == L0[ints[:, 1].astype(int), ints[:, 0].astype(int)]).all()
+    for level in (0, 2):
+        uv = np.column_stack([rng.uniform(-2, w + 1, 40), rng.uniform(-2, h + 1, 40)])
+        v, g = run(level, uv)
+        np.testing.assert_allclose(v, [ref(level, u) for u in uv], rtol=0, atol=1e-9)
+        eps = 1e-5
+        inner = (np.abs(uv - np.rint(uv)) > 1e-3).all(axis=1)  # the spline's derivative jumps at the knots
+        for k in range(2):
+            d = np.zeros(2)
+            d[k] = eps
+            fd = (np.array([ref(level, u + d) for u in uv]) - np.array([ref(level, u - d) for u in uv])) / (2 * eps)
+            np.testing.assert_allclose(g[inner, k], fd[inner], rtol=1e-5, atol=1e-5)

@@ -22,6 +22,7 @@ def _d(a):
 
 W, H = 512, 384
 K4 = np.array([300.0, 300.0, 255.5, 191.5])
+SMALL = (352, 264, np.array([206.25, 206.25, 175.5, 131.5]))  # same field of view at 0.6875 of the size: the emulated run
 TEX_PPM = 160.0  # texture pixels per metre of wall
 
 
@@ -38,8 +39,9 @@ def _texture():
     return tex
 
 
-def render_sequence(n_frames, fps=20.0, imu_rate=200.0, t_start=0.0):
+def render_sequence(n_frames, fps=20.0, imu_rate=200.0, t_start=0.0, size=None):
     """images (n, H, W) u8, image times, IMU (t, w, a), body poses at the image times (t p q)"""
+    W, H, K4 = size if size is not None else (globals()["W"], globals()["H"], globals()["K4"])
     q_bc = synth.Q_BC / np.linalg.norm(synth.Q_BC)
     R_bc, p_bc = synth.qmat(q_bc), synth.P_BC
     # the wall: through the orbit centre, facing the camera at mid-sequence, tilted by 20 degrees so that depth varies
@@ -83,11 +85,12 @@ def render_sequence(n_frames, fps=20.0, imu_rate=200.0, t_start=0.0):
             np.ascontiguousarray(np.stack(poses)), q_bc, p_bc)
 
 
-def run(lib, n_frames, window, gap, distance=25.0):
+def run(lib, n_frames, window, gap, distance=25.0, size=None):
+    W, H, K4 = size if size is not None else (globals()["W"], globals()["H"], globals()["K4"])
     import os
     # every keyframe solve also re-walks the Map from scratch and compares with the incrementally flattened window
     os.environ["PVIO_HIP_FLATTEN_VERIFY"] = "1"
-    images, times, imu_t, imu_w, imu_a, gt, q_bc, p_bc = render_sequence(n_frames)
+    images, times, imu_t, imu_w, imu_a, gt, q_bc, p_bc = render_sequence(n_frames, size=size)
     out, stats = np.zeros((n_frames, 8)), np.zeros(4, np.int32)
     err = C.create_string_buffer(512)
     lib.host_headless_run.restype = C.c_int
@@ -124,7 +127,7 @@ def test_headless_pipeline_emulated():
     import subprocess
     subprocess.check_call(["make", "-s", "-C", os.path.join(os.path.dirname(os.path.abspath(__file__)), "hipemu"), "libpvio_hipemu.so"])
     lib = host_compare.load("libpvio_host_emu.so")
-    out, stats, gt = run(lib, 9, 3, 2)
+    out, stats, gt = run(lib, 9, 3, 2, distance=18.0, size=SMALL)
     assert stats[0] == 1 and stats[2] >= 2 and stats[3] >= 40
     valid = np.abs(out[:, 4:8]).sum(1) > 0
     assert valid[6:].all() and not valid[:5].any()
