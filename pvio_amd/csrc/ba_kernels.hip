@@ -1439,6 +1439,15 @@ __device__ __forceinline__ void dense_trailing_sweep(double *A, const double *Pn
     }
 }
 
+// slot <-> (tile column g, q) table of the register-resident factorization (see k_dense): column g has ceil((g + 1) / 4) slots
+constexpr int kDenseCols = 11;
+__device__ constexpr int kSlotCol[21] = {0, 1, 2, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 8, 9, 9, 9, 10, 10, 10};
+__device__ constexpr int kSlotQ[21] = {0, 0, 0, 0, 0, 1, 0, 1, 0, 1, 0, 1, 0, 1, 2, 0, 1, 2, 0, 1, 2};
+__device__ constexpr int kColSlot[12] = {0, 1, 2, 3, 4, 6, 8, 10, 12, 15, 18, 21};
+
+// q-th tile row (from the end) of wave w: 0..3 forwards, 4..7 backwards, 8..10 forwards again
+__device__ __forceinline__ int dense_row_of(int w, int q) { return q == 0 ? w : (q == 1 ? 7 - w : 8 + w); }
+
 // compile-time storage choice: a runtime LDS-or-global pointer select degrades every access to FLAT.  The register-resident
 // form runs one wave per SIMD (its tiles live in the accumulators of exactly four waves); the HBM form runs two: its sweeps
 // and passes over the matrix wait on L2 round trips that a second wave fills.
@@ -1493,24 +1502,26 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
         else if (tid >= 192 && tid < 192 + v.dm.prior_n) aux_costs[N + tid - 192] = v.prior_cost[tid - 192];
         else if (tid == 255) aux_costs[N + v.dm.prior_n] = v.dm.n_rot > 0 ? v.rot_cost[0] : 0.0;
     }
-    // Tile ownership of the register-resident factorization (LDSMAT): wave w owns tiles w, w + 4, ... of the block triangle
-    // enumerated by DEscending tile column, so that the tiles still alive at any panel are a prefix of every wave's list.
-    constexpr int kSlots = LDSMAT ? 17 : 1; // ceil(66 / 4): LDV <= 176
+    // Tile ownership of the register-resident factorization (LDSMAT).  Tile (g, h): g = tile column, h <= g = tile row, both
+    // counted from the LAST one.  Rows are dealt to the waves in a zigzag (dense_row_of: rows w, 7 - w, 8 + w -> 15 / 14 / 13 / 13
+    // tiles at P = 150 instead of 21 / 18 / 15 / 12 for h & 3: the rows nearest the end are the longest); a wave keeps the
+    // tile of its q-th row of column g in the
+    // accumulator slot kColSlot[g] + q -- a COMPILE-TIME slot <-> (g, q) table (columns in slot order, ceil((g + 1) / 4) slots
+    // per column whatever the wave: a wave with fewer rows in a column leaves a slot unused).  Only the offset nbk - 1 and
+    // the wave index are runtime values, so the rank-8 update addresses accumulators and operands statically: one A operand
+    // per q (3 per wave), one B operand per column, no per-slot address arithmetic, selects or slot-list branches.
+    constexpr int kSlots = LDSMAT ? 21 : 1; // sum over g < 11 of ceil((g + 1) / 4): LDV <= 176
     const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 15, lk = lane >> 4;
     const bool from_images = LDSMAT && v.dm.use_img; // the reduced system arrives as a tile image: loaded straight into registers
     int sbi[kSlots], sbk[kSlots];
     lds_d2 raw[kSlots][2];
     if constexpr (LDSMAT) {
-        const int ntile = (nbk * (nbk + 1)) >> 1;
-        int e = wv, g = 0;
 #pragma unroll
         for (int i = 0; i < kSlots; ++i) {
-            while ((((g + 1) * (g + 2)) >> 1) <= e) ++g;
-            const int h = e - ((g * (g + 1)) >> 1);
-            const bool valid = e < ntile;
+            const int g = kSlotCol[i], h = dense_row_of(wv, kSlotQ[i]);
+            const bool valid = g < nbk && h <= g;
             sbk[i] = valid ? nbk - 1 - g : -1;
             sbi[i] = valid ? nbk - 1 - h : 0;
-            e += 4;
         }
         // issue the loads of this wave's tiles now: their latency (a trip through the fabric, k_reduce ran on other XCDs)
         // is covered by the control section and the vector assembly
@@ -1911,13 +1922,14 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
             PV_STAMP(2, 23);
         }
         // columns [o2, o2 + 8) of slot i's tile -> Xs (row-major, 8 per row; still negated)
-#define PV_PUBLISH(i, o2)                                                                               \
+#define PV_PUBLISH_ROW(i, brow, o2)                                                                     \
     do {                                                                                                \
         const int cX = lr - (o2);                                                                       \
         if (cX >= 0 && cX < kPanel) {                                                                   \
-            _Pragma("unroll") for (int r = 0; r < 4; ++r) Xs[(16 * sbi[i] + lk + 4 * r) * 8 + cX] = acc[i][r]; \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r) Xs[(16 * (brow) + lk + 4 * r) * 8 + cX] = acc[i][r]; \
         }                                                                                               \
     } while (0)
+#define PV_PUBLISH(i, o2) PV_PUBLISH_ROW(i, sbi[i], o2)
 #pragma unroll
         for (int i = 0; i < kSlots; ++i)
             if (sbk[i] == 0) PV_PUBLISH(i, 0);
@@ -2003,41 +2015,45 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
             // they are walked from the back in groups of four (the tile column that is factored next comes first and is
             // published while the remaining groups still compute).
             {
-                const int R = nbk - b0, nact = (R * (R + 1)) >> 1;
-                const int na = nact > wv ? (nact - wv + 3) >> 2 : 0;
+                const int R = nbk - b0; // live tile columns g = 0 .. R - 1 (from the end); the one that is factored next is g = R - 1
                 const double *Lpan = Lf + lfo - 8 * j0 + 2 * lk + 8 * lr; // + 128 * tile row -> this lane's operand pair
+                // operands: A(q) = rows wv + 4 q (from the end), B(g) = column g; rows / columns outside the live range read the
+                // row block b0 (a valid address; they only ever meet slots that hold no live tile)
+                lds_d2 opA[3], opB[kDenseCols];
+                int hq[3]; // this wave's tile rows (uniform)
 #pragma unroll
-                for (int cg = (kSlots + 3) / 4 - 1; cg >= 0; --cg) {
-                    if (4 * cg < na) {
-                        lds_d2 av[4], pv[4];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const int i = 4 * cg + u;
-                            if (i < kSlots) {
-                                const bool on = i < na;
-                                av[u] = *reinterpret_cast<const lds_d2 *>(Lpan + 128 * (on ? sbi[i] : b0));
-                                pv[u] = *reinterpret_cast<const lds_d2 *>(Lpan + 128 * (on ? sbk[i] : b0));
-                            }
-                        }
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            const int i = 4 * cg + u;
-                            if (i < kSlots && i >= na) av[u][0] = 0.0, av[u][1] = 0.0; // tail of the last group: a = 0 leaves the tile as it is
-                        }
-#pragma unroll
-                        for (int u = 0; u < 4; ++u)
-                            if (4 * cg + u < kSlots) acc[4 * cg + u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][0], pv[u][0], acc[4 * cg + u], 0, 0, 0);
-#pragma unroll
-                        for (int u = 0; u < 4; ++u)
-                            if (4 * cg + u < kSlots) acc[4 * cg + u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][1], pv[u][1], acc[4 * cg + u], 0, 0, 0);
-#pragma unroll
-                        for (int u = 0; u < 4; ++u)
-                            if (4 * cg + u < kSlots && sbk[4 * cg + u] == b0) {
-                                asm volatile("" ::: "memory"); // keep this a real (uniform) branch: nothing of the publish is hoisted
-                                PV_PUBLISH(4 * cg + u, o2);
-                            }
-                    }
+                for (int q = 0; q < 3; ++q) {
+                    hq[q] = dense_row_of(wv, q);
+                    opA[q] = *reinterpret_cast<const lds_d2 *>(Lpan + 128 * (hq[q] < R ? nbk - 1 - hq[q] : b0));
                 }
+#pragma unroll
+                for (int g = 0; g < kDenseCols; ++g)
+                    if (g < R) opB[g] = *reinterpret_cast<const lds_d2 *>(Lpan + 128 * (nbk - 1 - g)); // live columns only
+                // a column's slots, unconditionally: a slot that holds no tile of this wave (its q-th row lies outside the column)
+                // costs two MFMAs on registers nobody reads -- cheaper than a uniform branch per slot, which splits the MFMA
+                // sequence into basic blocks (measured: 54.4 against 49.7 us)
+#define PV_COLUMN(g)                                                                                                   \
+    do {                                                                                                               \
+        _Pragma("unroll") for (int q = 0; q < kColSlot[(g) + 1] - kColSlot[g]; ++q)                                    \
+            acc[kColSlot[g] + q] = __builtin_amdgcn_mfma_f64_16x16x4f64(opA[q][0], opB[g][0], acc[kColSlot[g] + q], 0, 0, 0); \
+        _Pragma("unroll") for (int q = 0; q < kColSlot[(g) + 1] - kColSlot[g]; ++q)                                    \
+            acc[kColSlot[g] + q] = __builtin_amdgcn_mfma_f64_16x16x4f64(opA[q][1], opB[g][1], acc[kColSlot[g] + q], 0, 0, 0); \
+    } while (0)
+                // from the column that is factored next (published as soon as it is updated) down to the last one
+#pragma unroll
+                for (int g = kDenseCols - 1; g >= 0; --g)
+                    if (g < R) { // uniform
+                        PV_COLUMN(g);
+                        if (g == R - 1) {
+#pragma unroll
+                            for (int q = 0; q < kColSlot[g + 1] - kColSlot[g]; ++q)
+                                if (hq[q] <= g) {
+                                    asm volatile("" ::: "memory"); // keep this a real (uniform) branch: nothing of the publish is hoisted
+                                    PV_PUBLISH_ROW(kColSlot[g] + q, nbk - 1 - hq[q], o2); // (the slot tables sbi / sbk are not kept alive across the loop)
+                                }
+                        }
+                    }
+#undef PV_COLUMN
             }
             if (j0 == 0) PV_STAMP(2, 11);
             if (j0 == 80) PV_STAMP(2, 16);
@@ -2047,6 +2063,7 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
             lfo += 8 * (LDV - j0);
         }
 #undef PV_PUBLISH
+#undef PV_PUBLISH_ROW
         PV_STAMP(2, 5);
         // ---------------- back substitution L^T y = z, 8 columns per step ----------------
         // L(i, k) = Lf[off(k >> 3) + (i - 8 (k >> 3)) * 8 + perm(k & 7)], off(p) = 8 p LDV - 32 p (p - 1), perm(c) = 2 (c & 3) + (c >> 2)
