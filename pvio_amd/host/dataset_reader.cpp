@@ -93,6 +93,7 @@ UndistortedHipImage::UndistortedHipImage(pvio_hip_ctx *ctx, std::shared_ptr<pvio
 
 void UndistortedHipImage::preprocess() {
     if (img_) pvio_hip_image_release(ctx_, img_), img_ = nullptr;
+    forget_host_levels();
     const int32_t rc = pvio_hip_image_create_undistorted(ctx_, ud_.get(), pixels_.data(), w_, h_, w_, /*apply_clahe=*/1, &img_);
     if (rc != 0) throw std::runtime_error(std::string("pvio_hip_image_create_undistorted: ") + pvio_hip_last_error(ctx_)); // no CPU path
 }

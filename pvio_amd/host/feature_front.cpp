@@ -143,6 +143,7 @@ HipImage::~HipImage() {
 
 void HipImage::preprocess() {
     if (img_) pvio_hip_image_release(ctx_, img_), img_ = nullptr;
+    forget_host_levels();
     const int32_t rc = pvio_hip_image_create(ctx_, pixels_.data(), w_, h_, w_, /*apply_clahe=*/1, &img_);
     if (rc != 0) throw std::runtime_error(std::string("pvio_hip_image_create: ") + pvio_hip_last_error(ctx_)); // no CPU path
 }
@@ -173,7 +174,8 @@ inline void cubic(double p0, double p1, double p2, double p3, double x, double &
 double HipImage::evaluate(const vector<2> &u, vector<2> &ddu, int level) const {
     const HostLevel &L = host_level(level);
     // opencv_image.cpp:150-154: the per-level scale is an INTEGER quotient of the extents
-    const double sx = 1.0 / (double)((w_ - 1) / (L.w - 1)), sy = 1.0 / (double)((h_ - 1) / (L.h - 1));
+    const int W0 = (int)width(), H0 = (int)height(); // of level 0 (an undistorted image has the size of its maps, not of its source)
+    const double sx = 1.0 / (double)((W0 - 1) / (L.w - 1)), sy = 1.0 / (double)((H0 - 1) / (L.h - 1));
     const double c = u[0] * sx, r = u[1] * sy;
     const int row = (int)std::floor(r), col = (int)std::floor(c);
     auto px = [&](int rr, int cc) { // Grid2D clamps to the image

@@ -83,6 +83,7 @@ class HipImage : public Image {
     const pvio_hip_image *device_image() const { return img_; }
 
   protected: // UndistortedHipImage (dataset_reader.h) builds the pyramid through another C-ABI entry point
+    void forget_host_levels() { host_levels_.clear(); } // evaluate()'s copies belong to the previous pyramid
     pvio_hip_ctx *ctx_;
     std::vector<uint8_t> pixels_;
     int w_, h_;
