@@ -158,7 +158,7 @@ __device__ __forceinline__ int mat_at(int i, int k) { return tile_base(i >> 4, k
 // k_linearize
 // ------------------------------------------------------------------------------------------------------
 struct Pro { // prologue result, one copy in LDS per WG
-    int mode, cur, lin, out_set, eval_buf, valid;
+    int mode, cur, lin, out_set, eval_buf, valid, done, pad_;
     double mu_schur, ca, cb;
 };
 
@@ -170,30 +170,61 @@ __device__ __forceinline__ void lin_prologue(const View &v, double *lds, Pro *&p
     double *est = lds, *frec = lds + N * 16, *scratch = frec + N * kFrameRec;
     Pro *pro = reinterpret_cast<Pro *>(scratch + 160);
     pro_out = pro;
-    const Ctrl *c = v.ctrl;
-    const int mode = c->mode, cur = c->cur, lin = c->lin;
-    if (tid == 0) {
-        pro->mode = mode, pro->cur = cur, pro->lin = lin;
-        pro->valid = 1;
-        pro->ca = 0, pro->cb = 0;
-        pro->out_set = (mode == MODE_CANDIDATE) ? 1 - lin : lin;
-        pro->eval_buf = (mode == MODE_CANDIDATE) ? 1 - cur : cur;
-        pro->mu_schur = (mode == MODE_CANDIDATE) ? fmax(1e-8, 2.0 * c->mu / 10.0) : c->mu; // StepAccepted's mu, assumed
-    }
-    if (mode == MODE_CANDIDATE) {
-        // ---- DoglegStrategy::ComputeTraditionalDoglegStep on the scalars of the accepted linearization ----
-        if (tid < 64) {
-            double b[6] = {0, 0, 0, 0, 0, 0};
-            for (int row = tid; row < v.dm.n_back_rows; row += 64) // <= 64 rows unless the window is large
-                for (int k = 0; k < 6; ++k) b[k] += v.back_part[row * kNumBackScal + k];
+    // Wave 0 does the whole prologue.  Everything it reads was written by the previous kernels on other XCDs, so every
+    // load costs a trip through the fabric: ALL of them are requested up front, whatever the mode turns out to be (control
+    // block, back-substitution partials, both state buffers of this lane's frame, both step vectors, the static frame
+    // data), then used -- one trip instead of the three dependent ones of "read the mode, then the partials, then the
+    // states" (10.3k -> see DESIGN section 5).  The dogleg scalars stay in lane 0; ca / cb / valid reach the frame lanes by
+    // lane reads, so the only barrier is the one that publishes the records to the other waves.
+    if (tid < 64) {
+        const Ctrl *c = v.ctrl;
+        const int lane = tid, f = lane < N ? lane : N - 1;
+        // (1) control block
+        const int done = c->done; // (tested after everything has been requested: a test up front is a fabric trip of its own)
+        const int mode = c->mode, cur = c->cur, lin = c->lin, dbg_invalid_left = c->dbg_invalid_left;
+        const double c_mu = c->mu, radius = c->radius;
+        const double c_g2 = c->pose_g2, c_lm_g2 = c->lm_g2, c_gn2 = c->pose_gn2, c_gdot = c->pose_gdot, c_qvv = c->pose_qvv, c_qvy = c->pose_qvy,
+                     c_qyy = c->pose_qyy, c_gy = c->pose_gy;
+        // (2) partial sums of the landmark back-substitution (<= 64 rows unless the window is large)
+        double b[6] = {0, 0, 0, 0, 0, 0};
+        for (int row = lane; row < v.dm.n_back_rows; row += 64)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) b[k] += v.back_part[row * kNumBackScal + k];
+        // (3) this lane's frame: both state buffers, both step vectors, activity flags, camera / weight records
+        double x0[16], x1[16], vs[15], ys[15];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) x0[k] = v.fs[(size_t)f * 16 + k], x1[k] = v.fs[((size_t)N + f) * 16 + k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) vs[k] = v.vstep[f * d + k], ys[k] = v.ystep[f * d + k];
+#pragma unroll
+        for (int k = 6; k < 15; ++k) vs[k] = 0.0, ys[k] = 0.0;
+        if (d == 15) {
+#pragma unroll
+            for (int k = 6; k < 15; ++k) vs[k] = v.vstep[f * d + k], ys[k] = v.ystep[f * d + k];
+        }
+        const bool p_act = v.pose_active[f], m_act = v.motion_active[f];
+        double cam7[7], w4[4];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) cam7[k] = v.cam_ext[7 * f + k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) w4[k] = v.sic[4 * f + k];
+
+        if (done) { // the solve has terminated: this launch is a no-op slot of the graph; nothing is written
+            if (lane == 0) pro->done = 1, pro->valid = 0;
+            goto prologue_out;
+        }
+        double ca = 0, cb = 0;
+        int valid = 1;
+        if (mode == MODE_CANDIDATE) {
+            // ---- DoglegStrategy::ComputeTraditionalDoglegStep on the scalars of the accepted linearization ----
+#pragma unroll
             for (int k = 0; k < 6; ++k) b[k] = wave_sum(b[k]);
-            if (tid == 0) {
-                const double g2 = c->pose_g2 + c->lm_g2, gn2 = c->pose_gn2 + b[0], gdot = c->pose_gdot + b[1];
-                const double qvv = c->pose_qvv + b[2], qvy = c->pose_qvy + b[3], qyy = c->pose_qyy + b[4], gy = c->pose_gy + b[5];
-                const double radius = c->radius;
+            if (lane == 0) {
+                const double g2 = c_g2 + c_lm_g2, gn2 = c_gn2 + b[0], gdot = c_gdot + b[1];
+                const double qvv = c_qvv + b[2], qvy = c_qvy + b[3], qyy = c_qyy + b[4], gy = c_gy + b[5];
                 const double gradient_norm = sqrt(g2), gauss_newton_norm = sqrt(gn2);
                 const double alpha = g2 / qvv; // |g^|^2 / |J (g^/D)|^2
-                double ca, cb, sn;
+                double sn;
                 if (gauss_newton_norm <= radius) {
                     ca = 0.0, cb = 1.0, sn = gauss_newton_norm;
                 } else if (gradient_norm * alpha >= radius) {
@@ -212,56 +243,76 @@ __device__ __forceinline__ void lin_prologue(const View &v, double *lds, Pro *&p
                 const double gs = ca * g2 + cb * gy;
                 const double q = ca * ca * qvv + 2 * ca * cb * qvy + cb * cb * qyy;
                 const double mcc = -(gs + 0.5 * q);
-                pro->ca = ca, pro->cb = cb;
-                pro->valid = (mcc > 0.0 && c->dbg_invalid_left <= 0) ? 1 : 0; // (fault injection: tests only)
+                valid = (mcc > 0.0 && dbg_invalid_left <= 0) ? 1 : 0; // (fault injection: tests only)
                 if (blockIdx.x == 0) {
                     Ctrl *cw = v.ctrl;
                     cw->ca = ca, cw->cb = cb, cw->dogleg_step_norm = sn, cw->model_cost_change = mcc;
                 }
             }
+            ca = readlane_f64(ca, 0), cb = readlane_f64(cb, 0);
+            valid = __builtin_amdgcn_readlane(valid, 0);
         }
-    }
-    __syncthreads();
-    // ---- evaluation-point frame states (candidate = x (+) delta) -----------------------------------
-    const double ca = pro->ca, cb = pro->cb;
-    double step2 = 0, norm2 = 0;
-    if (tid < N) {
-        const double *x = v.fs + ((size_t)cur * N + tid) * 16;
-        double *y = est + tid * 16;
-        for (int k = 0; k < 16; ++k) y[k] = x[k];
-        if (mode == MODE_CANDIDATE && pro->valid) {
-            const double *vs = v.vstep + tid * d, *ys = v.ystep + tid * d;
-            if (v.pose_active[tid]) {
-                double dl[6];
-                for (int k = 0; k < 6; ++k) dl[k] = ca * vs[k] + cb * ys[k];
-                pose_plus(y, x, dl, dl + 3);
-            }
-            if (v.motion_active[tid] && d == 15)
-                for (int k = 0; k < 9; ++k) y[7 + k] = x[7 + k] + (ca * vs[6 + k] + cb * ys[6 + k]);
-            if (v.pose_active[tid])
-                for (int k = 0; k < 7; ++k) step2 += (y[k] - x[k]) * (y[k] - x[k]), norm2 += y[k] * y[k];
-            if (v.motion_active[tid])
-                for (int k = 7; k < 16; ++k) step2 += (y[k] - x[k]) * (y[k] - x[k]), norm2 += y[k] * y[k];
-            if (blockIdx.x == 0) {
-                double *out = v.fs + ((size_t)(1 - cur) * N + tid) * 16;
-                for (int k = 0; k < 16; ++k) out[k] = y[k];
-            }
-        } else {
-            if (v.pose_active[tid])
-                for (int k = 0; k < 7; ++k) norm2 += y[k] * y[k];
-            if (v.motion_active[tid])
-                for (int k = 7; k < 16; ++k) norm2 += y[k] * y[k];
+        if (lane == 0) {
+            pro->mode = mode, pro->cur = cur, pro->lin = lin;
+            pro->valid = valid, pro->done = 0;
+            pro->ca = ca, pro->cb = cb;
+            pro->out_set = (mode == MODE_CANDIDATE) ? 1 - lin : lin;
+            pro->eval_buf = (mode == MODE_CANDIDATE) ? 1 - cur : cur;
+            pro->mu_schur = (mode == MODE_CANDIDATE) ? fmax(1e-8, 2.0 * c_mu / 10.0) : c_mu; // StepAccepted's mu, assumed
         }
-        frame_record(frec + tid * kFrameRec, y, v.cam_ext + 7 * tid, v.sic + 4 * tid);
-    }
-    if (tid < 64) { // N <= 32 < 64: wave 0 holds all frame partials
-        step2 = wave_sum(step2), norm2 = wave_sum(norm2);
-        if (tid == 0 && blockIdx.x == 0) {
+        // ---- evaluation-point frame states (candidate = x (+) delta) -----------------------------------
+        double step2 = 0, norm2 = 0;
+        if (lane < N) {
+            double x[16], y[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) x[k] = cur ? x1[k] : x0[k], y[k] = x[k];
+            if (mode == MODE_CANDIDATE && valid) {
+                if (p_act) {
+                    double dl[6];
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) dl[k] = ca * vs[k] + cb * ys[k];
+                    pose_plus(y, x, dl, dl + 3);
+                }
+                if (m_act && d == 15) {
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) y[7 + k] = x[7 + k] + (ca * vs[6 + k] + cb * ys[6 + k]);
+                }
+                if (p_act) {
+#pragma unroll
+                    for (int k = 0; k < 7; ++k) step2 += (y[k] - x[k]) * (y[k] - x[k]), norm2 += y[k] * y[k];
+                }
+                if (m_act) {
+#pragma unroll
+                    for (int k = 7; k < 16; ++k) step2 += (y[k] - x[k]) * (y[k] - x[k]), norm2 += y[k] * y[k];
+                }
+                if (blockIdx.x == 0) {
+                    double *out = v.fs + ((size_t)(1 - cur) * N + lane) * 16;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) out[k] = y[k];
+                }
+            } else {
+                if (p_act) {
+#pragma unroll
+                    for (int k = 0; k < 7; ++k) norm2 += y[k] * y[k];
+                }
+                if (m_act) {
+#pragma unroll
+                    for (int k = 7; k < 16; ++k) norm2 += y[k] * y[k];
+                }
+            }
+            double *ye = est + lane * 16;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) ye[k] = y[k];
+            frame_record(frec + lane * kFrameRec, y, cam7, w4);
+        }
+        step2 = wave_sum(step2), norm2 = wave_sum(norm2); // N <= 32 < 64: wave 0 holds all frame partials
+        if (lane == 0 && blockIdx.x == 0) {
             Ctrl *cw = v.ctrl;
             cw->cand_step2_pose = step2, cw->cand_norm2_pose = norm2;
-            cw->lin_result = !pro->valid ? LIN_INVALID_STEP : (mode == MODE_INIT || mode == MODE_MARG ? LIN_INIT : (mode == MODE_CANDIDATE ? LIN_CANDIDATE : LIN_RELIN));
+            cw->lin_result = !valid ? LIN_INVALID_STEP : (mode == MODE_INIT || mode == MODE_MARG ? LIN_INIT : (mode == MODE_CANDIDATE ? LIN_CANDIDATE : LIN_RELIN));
         }
     }
+prologue_out:
     __syncthreads();
 }
 
@@ -969,13 +1020,12 @@ template <int T> struct TilesPerWave { static constexpr int value = T <= 1 ? 3 :
 template <int T, bool MM>
 __global__ void __launch_bounds__(kLinThreads) k_linearize(View v) {
     HIP_DYNAMIC_SHARED(double, lds)
-    if (v.ctrl->done) return;
     PV_STAMP(0, 0);
     if (v.dbg && blockIdx.x == 0 && threadIdx.x == 0) v.dbg[30] = wall_clock64();
     Pro *pro;
     lin_prologue(v, lds, pro);
     PV_STAMP(0, 1);
-    if (!pro->valid) return; // invalid trust-region step: k_dense handles it (HandleInvalidStep)
+    if (!pro->valid) return; // terminated solve (no-op slot), or invalid trust-region step: k_dense handles it (HandleInvalidStep)
     if (blockIdx.x == 0 && v.dm.n_rot > 0) {
         // rotation priors (RotationPriorFactor, no reference counterpart): one thread per frame, at the evaluation point the
         // prologue left in LDS; k_reduce / k_dense add the 3 x 3 blocks, the gradient and the cost like the IMU / prior terms
@@ -2485,29 +2535,54 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
 // pays ten L2 round trips back to back); the two dot products are summed over the row and lane 0 finishes the landmark.
 // The control word and the first operands are requested together: nothing is written before the word has arrived.
 __global__ void __launch_bounds__(256) k_backsub(View v) {
+    // Two dependent rounds of loads instead of four (each is a trip through the fabric, ~2000 cycles: the producers ran on
+    // other XCDs): round 1 = control word, the landmarks' CSR entries and anchors, and the two step vectors, which go to LDS
+    // (the per-observation lookups vs[t] / ys[t] then cost an LDS read instead of a third trip behind obs_frame[o]);
+    // round 2 = everything addressed by `lin` / the CSR offsets, including the per-landmark scalars of the lanes that
+    // finish a landmark (requested before the sums they are combined with, not after).
     const Ctrl *c = v.ctrl;
     const int done = c->done, solve_ok = c->solve_ok, lin = c->lin;
     const double mu = c->mu;
     __shared__ double scratch[6 * 16];
-    const int M = v.dm.M, d = v.dm.d;
+    __shared__ double stepv[kMaxFrames * 15], stepy[kMaxFrames * 15];
+    const int M = v.dm.M, d = v.dm.d, P = v.dm.P;
     const size_t Ms = (size_t)M, Fs = (size_t)v.dm.F;
     const int sub = threadIdx.x & 15, per_block = blockDim.x >> 4;
+    const int l_first = blockIdx.x * per_block + (threadIdx.x >> 4);
+    const int lc_first = l_first < M ? l_first : M - 1;
+    int o0n = v.lm_ptr[lc_first], o1n = v.lm_ptr[lc_first + 1], an = v.lm_anchor[lc_first];
+    for (int e = threadIdx.x; e < P; e += blockDim.x) stepv[e] = v.vstep[e], stepy[e] = v.ystep[e];
+    if (done || !solve_ok) return; // uniform (the loads above were only issued)
+    __syncthreads();
     double s[6] = {0, 0, 0, 0, 0, 0};
     for (int l0 = blockIdx.x * per_block; l0 < M; l0 += gridDim.x * per_block) { // uniform trip count per block
         const int l = l0 + (threadIdx.x >> 4);
         const bool in = l < M;
         const int lc = in ? l : M - 1;
-        const int o0 = v.lm_ptr[lc], o1 = v.lm_ptr[lc + 1], a = v.lm_anchor[lc];
-        if (done || !solve_ok) return; // uniform (the loads above were only issued)
+        const int o0 = o0n, o1 = o1n, a = an;
+        {   // CSR entries of this thread's next landmark (large windows: several per thread)
+            const int ln = l + gridDim.x * per_block, lcn = ln < M ? ln : M - 1;
+            if (l0 + gridDim.x * per_block < M) o0n = v.lm_ptr[lcn], o1n = v.lm_ptr[lcn + 1], an = v.lm_anchor[lcn];
+        }
         const double *Wa = v.Wa + lin * Ms * 6, *Wt = v.Wt + lin * Fs * 6;
+        const bool fin = sub == 0 && in && o1 != o0; // this lane finishes the landmark
+        double Hll = 0, bl = 0, D = 1, gh = 0, cl = 0;
+        if (fin) Hll = v.Hll[lin * Ms + l], bl = v.bl[lin * Ms + l], D = v.Dl[lin * Ms + l], gh = v.ghl[lin * Ms + l], cl = v.cl[l];
         double Wv = 0, Wy = 0; // W_l . (C_p v_p), W_l . (C_p y'_p)
-        if (sub < 6) Wv = Wa[(size_t)lc * 6 + sub] * v.vstep[d * a + sub], Wy = Wa[(size_t)lc * 6 + sub] * v.ystep[d * a + sub];
+        if (sub < 6) {
+            const double wa = Wa[(size_t)lc * 6 + sub];
+            Wv = wa * stepv[d * a + sub], Wy = wa * stepy[d * a + sub];
+        }
         for (int o = o0 + sub; o < o1; o += 16) {
             const int t = v.obs_frame[o];
-            const double *w = Wt + (size_t)o * 6, *vs = v.vstep + d * t, *ys = v.ystep + d * t;
+            const double *w = Wt + (size_t)o * 6;
+            double wk[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) wk[k] = w[k];
+            const double *vs = stepv + d * t, *ys = stepy + d * t;
             double av = 0, ay = 0;
 #pragma unroll
-            for (int k = 0; k < 6; ++k) av += w[k] * vs[k], ay += w[k] * ys[k];
+            for (int k = 0; k < 6; ++k) av += wk[k] * vs[k], ay += wk[k] * ys[k];
             Wv += av, Wy += ay;
         }
 #pragma unroll
@@ -2517,7 +2592,6 @@ __global__ void __launch_bounds__(256) k_backsub(View v) {
             if (o1 == o0) {
                 gnl[l] = 0.0;
             } else {
-                const double Hll = v.Hll[lin * Ms + l], bl = v.bl[lin * Ms + l], D = v.Dl[lin * Ms + l], gh = v.ghl[lin * Ms + l], cl = v.cl[l];
                 const double Hs = cl * cl * Hll, A = Hs + mu * D * D;
                 const double w = cl * cl / A;
                 const double yl = -cl * (bl + Wy) / A; // y'_l
