@@ -1,5 +1,6 @@
-"""Host visual_inertial_pnp (pvio_amd/host/pnp.*, dense_minimizer.h) against an independent dense numpy restatement of the
-same Ceres-1.14 Dogleg loop (tests/np_reference.solve_dense) built on the oracle's single-factor evaluators."""
+"""Host visual_inertial_pnp (pvio_amd/host/pnp.*, dense_minimizer.h) against the C++ oracle (oracle/oracle_pnp.cpp: its own
+dense Ceres-1.14 Dogleg loop and analytic world-point factor) and against an independent dense numpy restatement of the same
+loop (tests/np_reference.solve_dense) built on the oracle's single-factor evaluators."""
 import ctypes as C
 import os
 import subprocess
@@ -114,6 +115,14 @@ def _rot(q):
                      [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
 
 
+class _OracleAsHost:
+    """oracle_pnp_flat has the signature of the test harness's host_pnp_flat"""
+
+    def __init__(self):
+        self.host_pnp_flat = oracle_py.lib().oracle_pnp_flat
+        self.host_pnp_flat.restype = C.c_int
+
+
 def run_flat(host, pb, T, Lf, fac, use_inertial, x0, points=(), max_iter=10):
     n = len(fac)
     A = np.ascontiguousarray(np.array([pb.frame_state[a] for (_, a, _) in fac]).reshape(-1, 16)) if n else np.zeros((1, 16))
@@ -153,6 +162,10 @@ def test_pnp_matches_the_numpy_restatement_and_recovers_the_pose(host, use_inert
     assert abs(costs[0] - trace[0]["cost"]) <= 1e-9 * max(1.0, trace[0]["cost"])
     na = 16 if use_inertial else 7
     assert np.abs(x[:na] - fs[0][:na]).max() < 1e-8
+    xo, ito, tmo, costso = run_flat(_OracleAsHost(), pb, T, Lf, fac, use_inertial, x0)  # the C++ oracle: same iterations, same answer
+    assert (ito, tmo) == (it, tm)
+    assert abs(costso[0] - costs[0]) <= 1e-12 * max(1.0, costs[0]) and abs(costso[1] - costs[1]) <= 1e-9 * max(1.0, costs[1])
+    assert np.abs(xo[:na] - x[:na]).max() < 1e-9
     assert costs[1] < 0.8 * costs[0]  # the rest of the window (anchors, depths) carries its own noise: there is a floor
     # through the Map object graph: same factors in keypoint order -> same answer
     st = BAState(pb)
@@ -184,12 +197,18 @@ def test_pnp_world_point_factors_and_degenerate_inputs(host):
     x, it, tm, costs = run_flat(host, pb, T, Lf, keep, False, x0, points=pts)
     assert tm == term and abs(it - its) <= 1  # the numpy Jacobian of the point factors is a central difference
     assert np.abs(x[:7] - fs[0][:7]).max() < 1e-6
+    xo, ito, tmo, co = run_flat(_OracleAsHost(), pb, T, Lf, keep, False, x0, points=pts)  # analytic point-factor Jacobian on both sides
+    assert (ito, tmo) == (it, tm) and np.abs(xo[:7] - x[:7]).max() < 1e-9 and abs(co[1] - costs[1]) <= 1e-9 * max(1.0, costs[1])
     # no factor at all: nothing to do, the state comes back untouched and the summary says "converged"
     x2, it2, tm2, _ = run_flat(host, pb, T, Lf, [], False, x0)
     assert (x2 == x0).all() and tm2 == 0
+    x2o, _, tm2o, _ = run_flat(_OracleAsHost(), pb, T, Lf, [], False, x0)
+    assert (x2o == x0).all() and tm2o == 0
     # zero iterations allowed: initial evaluation only
     x3, it3, tm3, c3 = run_flat(host, pb, T, Lf, fac, False, x0, max_iter=0)
     assert (x3 == x0).all() and it3 == 0 and tm3 == 1 and c3[0] == c3[1]
+    x3o, it3o, tm3o, c3o = run_flat(_OracleAsHost(), pb, T, Lf, fac, False, x0, max_iter=0)
+    assert (x3o == x0).all() and it3o == 0 and tm3o == 1 and abs(c3o[0] - c3[0]) <= 1e-12 * c3[0]
 
 
 def test_pnp_best_plane_search_keeps_the_reference_quirk(host):

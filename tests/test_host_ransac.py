@@ -1,5 +1,7 @@
 """Fundamental-matrix RANSAC of the host adapter (the place of cv::findFundamentalMat in OpenCvImage::track_keypoints)
-against an independent numpy restatement and against ground truth."""
+against the C++ oracle (oracle/oracle_ransac.cpp: one-sided Jacobi null space, plain scoring), an independent numpy
+restatement (tests/np_ransac.py: LAPACK SVD, interpolated cubic) and ground truth -- three implementations, three null-space
+algorithms, one sampler."""
 import ctypes as C
 import os
 import subprocess
@@ -42,6 +44,17 @@ def two_views(n, outlier_frac, noise, seed):
     return p.astype(np.float32), q.astype(np.float32), out
 
 
+def run_oracle(p, q, thr=1.0, conf=0.99, max_iters=1000):
+    from oracle import oracle_py
+    L = oracle_py.lib()
+    L.oracle_find_fundamental_ransac.restype = C.c_int
+    mask = np.zeros(max(len(p), 1), np.uint8)
+    F = np.zeros(9)
+    good = L.oracle_find_fundamental_ransac(C.c_int(len(p)), np.ascontiguousarray(p).ctypes.data_as(f32p), np.ascontiguousarray(q).ctypes.data_as(f32p), C.c_double(thr),
+                                            C.c_double(conf), C.c_int(max_iters), mask.ctypes.data_as(u8p), F.ctypes.data_as(f64p))
+    return good, mask[:len(p)].astype(bool), F.reshape(3, 3)
+
+
 def run_host(host, p, q, thr=1.0, conf=0.99):
     mask = np.zeros(len(p), np.uint8)
     F = np.zeros(9)
@@ -57,13 +70,20 @@ def test_seven_point_solutions_satisfy_the_constraints(host):
     assert n in (1, 3)
     ref = np_ransac.seven_point(p, q)
     assert len(ref) == n
+    from oracle import oracle_py
+    Fo = np.zeros(27)
+    L = oracle_py.lib()
+    L.oracle_seven_point.restype = C.c_int
+    assert L.oracle_seven_point(np.ascontiguousarray(p).ctypes.data_as(f32p), np.ascontiguousarray(q).ctypes.data_as(f32p), Fo.ctypes.data_as(f64p)) == n
+    ref = ref + [Fo[9 * k:9 * k + 9].reshape(3, 3) for k in range(n)]  # every product model must also be one of the oracle's
     for k in range(n):
         Fk = F[9 * k:9 * k + 9].reshape(3, 3)
         res = [np.array([q[i][0], q[i][1], 1.0]) @ Fk @ np.array([p[i][0], p[i][1], 1.0]) for i in range(7)]
         assert np.abs(res).max() < 1e-6 * np.abs(Fk).max() * 1e6
         assert abs(np.linalg.det(Fk / np.linalg.norm(Fk))) < 1e-9  # rank 2
-        assert min(np.abs(Fk / np.linalg.norm(Fk) - G / np.linalg.norm(G)).max() for G in ref) < 1e-6 or \
-            min(np.abs(Fk / np.linalg.norm(Fk) + G / np.linalg.norm(G)).max() for G in ref) < 1e-6
+        for group in (ref[:n], ref[n:]):
+            assert min(np.abs(Fk / np.linalg.norm(Fk) - G / np.linalg.norm(G)).max() for G in group) < 1e-6 or \
+                min(np.abs(Fk / np.linalg.norm(Fk) + G / np.linalg.norm(G)).max() for G in group) < 1e-6
 
 
 @pytest.mark.parametrize("n,frac,noise,seed", [(300, 0.2, 0.3, 2), (120, 0.4, 0.2, 3), (60, 0.0, 0.5, 4), (800, 0.1, 0.1, 5), (9, 0.0, 0.05, 6)])
@@ -73,6 +93,10 @@ def test_ransac_matches_numpy_restatement_and_finds_the_outliers(host, n, frac, 
     ref_mask, ref_F = np_ransac.ransac(p, q)
     # same sampler, same models: the inlier sets agree (a point exactly at the 1 px threshold may flip with the rounding)
     assert (mask != ref_mask).sum() <= max(1, n // 200)
+    o_good, o_mask, o_F = run_oracle(p, q)
+    assert (mask != o_mask).sum() <= max(1, n // 200) and abs(o_good - good) <= max(1, n // 200)
+    if good and (mask == o_mask).all():  # same winning hypothesis: the same matrix up to the rounding of the null space
+        assert np.abs(F / np.linalg.norm(F) - o_F / np.linalg.norm(o_F)).max() < 1e-6
     assert good == mask.sum()
     # ground truth: gross outliers are rejected, the bulk of the true inliers is kept
     assert mask[out].sum() <= max(1, int(0.02 * n))
@@ -89,7 +113,10 @@ def test_ransac_degenerate_inputs(host):
     p, q, _ = two_views(6, 0.0, 0.0, 7)
     good, mask, _ = run_host(host, p, q)
     assert good == 0 and not mask.any()  # fewer than seven points: no model
+    assert run_oracle(p, q)[0] == 0
     # all points identical: every sample is degenerate -> no model, nothing flagged as inlier
     p = np.tile(np.array([[100.0, 120.0]], np.float32), (20, 1))
     good, mask, _ = run_host(host, p, p.copy())
     assert good == 0 and not mask.any()
+    o_good, o_mask, _ = run_oracle(p, p.copy())
+    assert o_good == 0 and not o_mask.any()
