@@ -1918,51 +1918,51 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
             const double *cv = A, *dgv = yv;
             const int brow = Pp >> 4; // tile row of the rhs row
             double q = 0;
+            // the {scale, v} pairs: a tile needs the pair of its column (one per lane) and of its four rows.  With the static
+            // slot table they depend on the tile column g and on the wave's row index qq only: 11 + 3 * 4 reads for all 21
+            // slots instead of five per slot (rows / columns outside the system read tile row / column 0: in range, never used)
+            lds_d2 colop[kDenseCols], rowop[3][4];
 #pragma unroll
-            for (int g = 0; g < (kSlots + 3) / 4; ++g) {
-                // the {scale, v} pairs of four tiles first (in-range for unused slots), then the arithmetic: one LDS round
-                // trip per group instead of one per tile
-                lds_d2 ck2[4], ci2[4][4];
+            for (int g = 0; g < kDenseCols; ++g) {
+                const int bk = g < nbk ? nbk - 1 - g : 0;
+                colop[g] = *reinterpret_cast<const lds_d2 *>(cv + 2 * (16 * bk + lr));
+            }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int i = 4 * g + u < kSlots ? 4 * g + u : kSlots - 1;
-                    const int bi = sbi[i], bk = sbk[i] >= 0 ? sbk[i] : 0;
-                    ck2[u] = *reinterpret_cast<const lds_d2 *>(cv + 2 * (16 * bk + lr));
+            for (int qq = 0; qq < 3; ++qq) {
+                const int h = dense_row_of(wv, qq), bi = h < nbk ? nbk - 1 - h : 0;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) ci2[u][r] = *reinterpret_cast<const lds_d2 *>(cv + 2 * (16 * bi + lk + 4 * r));
-                }
+                for (int r = 0; r < 4; ++r) rowop[qq][r] = *reinterpret_cast<const lds_d2 *>(cv + 2 * (16 * bi + lk + 4 * r));
+            }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int i = 4 * g + u;
-                    if (i < kSlots) {
-                        acc[i][0] = 0, acc[i][1] = 0, acc[i][2] = 0, acc[i][3] = 0;
-                        if (sbk[i] >= 0) {
-                            const int bi = sbi[i], bk = sbk[i];
-                            // C is 0 on inactive and padding coordinates, the image is 0 above the diagonal and outside
-                            // the real rows: one formula for every entry, the structural entries are patched below
-                            double val[4] = {raw[i][0][0], raw[i][0][1], raw[i][1][0], raw[i][1][1]};
-                            const double vk2 = 2.0 * ck2[u][1];
+            for (int i = 0; i < kSlots; ++i) {
+                acc[i][0] = 0, acc[i][1] = 0, acc[i][2] = 0, acc[i][3] = 0;
+                if (sbk[i] >= 0) {
+                    const int bi = sbi[i], bk = sbk[i];
+                    const lds_d2 ck = colop[kSlotCol[i]];
+                    // C is 0 on inactive and padding coordinates, the image is 0 above the diagonal and outside
+                    // the real rows: one formula for every entry, the structural entries are patched below
+                    double val[4] = {raw[i][0][0], raw[i][0][1], raw[i][1][0], raw[i][1][1]};
+                    const double vk2 = 2.0 * ck[1];
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                val[r] *= ci2[u][r][0] * ck2[u][0];
-                                q += val[r] * (ci2[u][r][1] * vk2);
-                            }
-                            if (bi == bk) { // diagonal tile: its diagonal counts once in v^T S v; unit / mu D^2 diagonal
-                                const double dgk = dgv[16 * bk + lr];
-#pragma unroll
-                                for (int r = 0; r < 4; ++r)
-                                    if (lk + 4 * r == lr) q -= val[r] * (ci2[u][r][1] * ck2[u][1]), val[r] += dgk;
-                            }
-                            if (bi == brow) { // the scaled rhs in row Pp
-                                const double rk = diagH[16 * bk + lr];
-#pragma unroll
-                                for (int r = 0; r < 4; ++r)
-                                    if (16 * bi + lk + 4 * r == Pp) val[r] = rk;
-                            }
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) acc[i][r] = -val[r];
-                        }
+                    for (int r = 0; r < 4; ++r) {
+                        const lds_d2 ci = rowop[kSlotQ[i]][r];
+                        val[r] *= ci[0] * ck[0];
+                        q += val[r] * (ci[1] * vk2);
                     }
+                    if (bi == bk) { // diagonal tile: its diagonal counts once in v^T S v; unit / mu D^2 diagonal
+                        const double dgk = dgv[16 * bk + lr];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (lk + 4 * r == lr) q -= val[r] * (rowop[kSlotQ[i]][r][1] * ck[1]), val[r] += dgk;
+                    }
+                    if (bi == brow) { // the scaled rhs in row Pp
+                        const double rk = diagH[16 * bk + lr];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (16 * bi + lk + 4 * r == Pp) val[r] = rk;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][r] = -val[r];
                 }
             }
             PV_STAMPV(2, 22, q);
@@ -2418,18 +2418,39 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
     }
     PV_STAMP(2, 6);
     // ---------------- outputs ----------------
+    // y solves (S + mu D^2) y = rhs_s ; step direction y' = -y ; gn = D y'.  The scalars of the step are summed together
+    // with the count of non-finite entries (one block reduction, one barrier less than testing the solution first); a
+    // failed solve leaves them unused and the step vectors unread (the next linearization is then not a candidate).
     double nbad = 0;
-    if (!sh_fail)
-        for (int a = tid; a < P; a += nthr) nbad += isfinite(ysol[a]) ? 0.0 : 1.0;
     {
-        double sb[1] = {nbad};
-        block_sum<1>(sb, red_scratch);
-        nbad = sb[0];
+        double s_g2 = 0, s_gn2 = 0, s_gd = 0, s_qvy = 0, s_gy = 0;
+        if (!sh_fail)
+            for (int a = tid; a < P; a += nthr) {
+                nbad += isfinite(ysol[a]) ? 0.0 : 1.0;
+                const double yp = act[a] != 0.0 ? -ysol[a] : 0.0;
+                const double Da = v.Dp[a], gh = v.ghp[a], gn = Da * yp;
+                v.ystep[a] = cpl[a] * yp;
+                v.vstep[a] = act[a] != 0.0 ? cpl[a] * vv[a] : 0.0;
+                s_g2 += gh * gh, s_gn2 += gn * gn, s_gd += gh * gn;
+                s_qvy += act[a] != 0.0 ? vv[a] * (mu * Da * Da * ysol[a] - diagH[a]) : 0.0; // v^T S y' = -v^T (rhs_s - mu D^2 y), S y = rhs_s - mu D^2 y
+                s_gy += act[a] != 0.0 ? cpl[a] * gtot[a] * yp : 0.0;
+            }
+        double sc[6] = {s_g2, s_gn2, s_gd, s_qvy, s_gy, nbad};
+        block_sum<6>(sc, red_scratch);
+        nbad = sc[5];
+        if (tid == 0) {
+            const int injected = c->dbg_fail_left > 0; // fault injection (tests only)
+            if (injected) c->dbg_fail_left--;
+            sh.do_solve = !sh_fail && nbad == 0.0 && !injected;
+            if (sh.do_solve) {
+                // y'^T S y' = |z|^2 - mu sum D_a^2 y'_a^2 = |z|^2 - mu |gn_p|^2
+                c->pose_g2 = sc[0], c->pose_gn2 = sc[1], c->pose_gdot = sc[2], c->pose_qvy = sc[3], c->pose_gy = sc[4];
+                c->pose_qyy = c->pose_qyy - mu * sc[1];
+            }
+        }
     }
     if (tid == 0) {
-        const int injected = c->dbg_fail_left > 0; // fault injection (tests only)
-        if (injected) c->dbg_fail_left--;
-        const int ok = !sh_fail && nbad == 0.0 && !injected;
+        const int ok = sh.do_solve;
         if (ok) {
             c->solve_ok = 1, c->mode = MODE_CANDIDATE, c->scaling_ready = 1, c->retry_relin = 0;
         } else {
@@ -2481,28 +2502,8 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
                 for (int e = tid; e < v.dm.M; e += nthr) dst[N * 16 + e] = v.rho[(size_t)cur * v.dm.M + e];
             }
         }
-        if (tid == 0) *cg = *c;
+        if (tid < (int)(sizeof(Ctrl) / sizeof(double))) reinterpret_cast<double *>(cg)[tid] = reinterpret_cast<const double *>(c)[tid];
         return;
-    }
-    // y solves (S + mu D^2) y = rhs_s ; step direction y' = -y ; gn = D y'
-    {
-        double s_g2 = 0, s_gn2 = 0, s_gd = 0, s_qvy = 0, s_gy = 0;
-        for (int a = tid; a < P; a += nthr) {
-            const double yp = act[a] != 0.0 ? -ysol[a] : 0.0;
-            const double Da = v.Dp[a], gh = v.ghp[a], gn = Da * yp;
-            v.ystep[a] = cpl[a] * yp;
-            v.vstep[a] = act[a] != 0.0 ? cpl[a] * vv[a] : 0.0;
-            s_g2 += gh * gh, s_gn2 += gn * gn, s_gd += gh * gn;
-            s_qvy += act[a] != 0.0 ? vv[a] * (mu * Da * Da * ysol[a] - diagH[a]) : 0.0; // v^T S y' = -v^T (rhs_s - mu D^2 y), S y = rhs_s - mu D^2 y
-            s_gy += act[a] != 0.0 ? cpl[a] * gtot[a] * yp : 0.0;
-        }
-        // y'^T S y' = |z|^2 - mu sum D_a^2 y'_a^2 = |z|^2 - mu |gn_p|^2
-        double sc[5] = {s_g2, s_gn2, s_gd, s_qvy, s_gy};
-        block_sum<5>(sc, red_scratch);
-        if (tid == 0) {
-            c->pose_g2 = sc[0], c->pose_gn2 = sc[1], c->pose_gdot = sc[2], c->pose_qvy = sc[3], c->pose_gy = sc[4];
-            c->pose_qyy = c->pose_qyy - mu * sc[1];
-        }
     }
     if (v.dm.fuse_backsub) {
         // small windows: the landmark back-substitution runs right here (one launch less per iteration); the step
@@ -2522,7 +2523,8 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
         }
     }
     __syncthreads();
-    if (tid == 0) *cg = *c;
+    // the control block goes back as one store per thread (a struct copy by thread 0 is 24 dependent LDS reads and stores)
+    if (tid < (int)(sizeof(Ctrl) / sizeof(double))) reinterpret_cast<double *>(cg)[tid] = reinterpret_cast<const double *>(c)[tid];
     PV_STAMP(2, 7);
     if (v.dbg && threadIdx.x == 0) v.dbg[2 * 32 + 31] = wall_clock64();
 }
