@@ -2697,11 +2697,15 @@ __global__ void k_prior_prep(const double *S, const double *s, int D, double *La
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < D * (D + 1); e += gridDim.x * blockDim.x) {
         const int a = e / (D + 1), b = e - a * (D + 1);
         double acc = 0;
+        // D dependent trips through L2 when the loop is left rolled (63 us at D = 150): fifteen rows requested at a time, summed
+        // in the same order
         if (b < D) {
+#pragma unroll 15
             for (int r = 0; r < D; ++r) acc += S[(size_t)r * D + a] * S[(size_t)r * D + b];
             Lambda[(size_t)a * D + b] = acc;
             ST[(size_t)a * D + b] = S[(size_t)b * D + a];
         } else {
+#pragma unroll 15
             for (int r = 0; r < D; ++r) acc += S[(size_t)r * D + a] * s[r];
             eta[a] = acc;
         }
