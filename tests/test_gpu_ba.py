@@ -153,22 +153,36 @@ def test_gpu_both_linearize_modes_agree_on_a_large_window(oracle):
     np.testing.assert_allclose(out[0][3], out[1][3], rtol=1e-9)
 
 
-def test_gpu_full_size_window_matches_the_oracle_golden(oracle):
-    """BASELINE.json configs[4] at full size against the oracle's states: the oracle's solve of the same (regenerated,
-    fingerprinted) window was run once offline and frozen in tests/golden/ba_vio_30x50000.npz (make_golden_large.py): same
+@pytest.mark.parametrize("shape,sharded", [((30, 50000), False), ((10, 50000), False), ((10, 50000), True)], ids=["30x50000", "10x50000", "10x50000_one_rank_sharded"])
+def test_gpu_full_size_window_matches_the_oracle_golden(oracle, shape, sharded):
+    """BASELINE.json configs[4] (30 KF x 50 000) and the window north_star states the multi-GPU target on (10 KF x 50 000, what
+    `bench.py --gpus N` shards) at full size against the oracle's states: the oracle's solves of the same (regenerated,
+    fingerprinted) windows were run once offline and frozen in tests/golden/ba_vio_<shape>.npz (make_golden_large.py): same
     accept / reject trace and termination, costs and trust-region radii, frame states after EVERY iteration and the final
-    50 000 inverse depths within the 1e-6 bar of north_star."""
+    50 000 inverse depths within the 1e-6 bar of north_star.  The 10 x 50 000 window also goes through the landmark-sharded
+    code path (one-rank RCCL communicator, graph-captured collectives) -- the multi-GPU headline's path minus a second rank."""
+    import ctypes as C
     import os
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
     import make_golden_large
+    from pvio_amd import capi
     from pvio_amd.solver import HipContext
-    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ba_vio_30x50000.npz"))
-    pb = ba_compare.make(oracle, n_frames=30, n_landmarks=50000, use_inertial=True)
+    n_frames, n_landmarks = shape
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ba_vio_%dx%d.npz" % shape))
+    pb = ba_compare.make(oracle, n_frames=n_frames, n_landmarks=n_landmarks, use_inertial=True)
     assert make_golden_large.fingerprint(pb) == str(g["inputs_sha256"]), "the regenerated window is not the one the golden was computed on"
-    ctx = HipContext(device=0)
-    st, sm = ctx.solve(pb)
-    ctx.close()
+    if sharded:
+        lib = capi.load()
+        ctx = HipContext(device=0, rank=0, world_size=1, force_sharded=True)
+        uid = (C.c_uint8 * 128)()
+        assert lib.pvio_hip_comm_unique_id(uid) == 0 and lib.pvio_hip_comm_init(ctx.ctx, uid, 0, 1) == 0
+    else:
+        ctx = HipContext(device=0)
+    try:
+        st, sm = ctx.solve(pb)
+    finally:
+        ctx.close()
     tr = sm.trace()
     assert sm.termination == int(g["termination"]) and sm.num_iterations == int(g["num_iterations"]) and len(tr) == len(g["costs"])
     assert ([t["step_is_successful"] for t in tr] == g["successful"]).all()
@@ -182,7 +196,8 @@ def test_gpu_full_size_window_matches_the_oracle_golden(oracle):
         assert d <= ba_compare.STATE_TOL, (k, d)
     np.testing.assert_allclose(st.frame_state, g["final_frame_state"], rtol=0, atol=ba_compare.STATE_TOL)
     np.testing.assert_allclose(st.lm_inv_depth, g["final_inv_depth"], rtol=0, atol=ba_compare.STATE_TOL)
-    print("30x50000 vs the oracle golden: max frame-state difference over all iterations %.2e, inverse depths %.2e" % (worst, np.abs(st.lm_inv_depth - g["final_inv_depth"]).max()))
+    print("%dx%d%s vs the oracle golden: max frame-state difference over all iterations %.2e, inverse depths %.2e"
+          % (n_frames, n_landmarks, " (sharded path, one rank)" if sharded else "", worst, np.abs(st.lm_inv_depth - g["final_inv_depth"]).max()))
 
 
 def test_gpu_full_size_window_properties(oracle):
