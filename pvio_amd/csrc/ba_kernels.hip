@@ -34,10 +34,18 @@ namespace pvba {
 
 using namespace pv;
 
-// phase timestamps for the profiling entry point (View::dbg != nullptr): block 0 / thread 0 only
-#define PV_STAMP(kern, idx)                                                                      \
-    do {                                                                                         \
-        if (v.dbg && blockIdx.x == 0 && threadIdx.x == 0) v.dbg[(kern)*32 + (idx)] = clock64(); \
+// phase timestamps for the profiling entry point (View::dbg != nullptr): block 0 / thread 0 only, ticks since the start of the
+// SAME launch (the launch that ends a solve overwrites the first sites; absolute stamps of different launches do not subtract).
+// A stamp is an s_memtime behind an s_waitcnt and a store: with all sites active the dense kernel takes 63 us instead of 50 and
+// the phases do not keep their proportions -- View::dbg_sel >= 0 leaves ONE site active per run (tests/prof_phases.py sweeps it).
+__device__ long long g_stamp_t0[4], g_stamp_w0[4]; // shader clock / 100 MHz wall clock at the start of the launch
+#define PV_STAMP_BEGIN(kern)                                                                   \
+    do {                                                                                       \
+        if (v.dbg && blockIdx.x == 0 && threadIdx.x == 0) g_stamp_t0[kern] = clock64(), g_stamp_w0[kern] = wall_clock64(); \
+    } while (0)
+#define PV_STAMP(kern, idx)                                                                                                   \
+    do {                                                                                                                      \
+        if (v.dbg && (v.dbg_sel < 0 || v.dbg_sel == (idx)) && blockIdx.x == 0 && threadIdx.x == 0) v.dbg[(kern)*32 + (idx)] = clock64() - g_stamp_t0[kern]; \
     } while (0)
 
 #ifdef PV_HIPEMU
@@ -1020,8 +1028,8 @@ template <int T> struct TilesPerWave { static constexpr int value = T <= 1 ? 3 :
 template <int T, bool MM>
 __global__ void __launch_bounds__(kLinThreads) k_linearize(View v) {
     HIP_DYNAMIC_SHARED(double, lds)
+    PV_STAMP_BEGIN(0);
     PV_STAMP(0, 0);
-    if (v.dbg && blockIdx.x == 0 && threadIdx.x == 0) v.dbg[30] = wall_clock64();
     Pro *pro;
     lin_prologue(v, lds, pro);
     PV_STAMP(0, 1);
@@ -1052,7 +1060,7 @@ __global__ void __launch_bounds__(kLinThreads) k_linearize(View v) {
     const int g0 = v.dm.G_lm, g1 = g0 + v.dm.G_plane, g2 = g1 + v.dm.G_pre, naux = v.dm.G_pre + v.dm.G_prior;
     const int bx = blockIdx.x;
     const int b = bx < naux ? g1 + bx : (bx < naux + v.dm.G_plane ? g0 + (bx - naux) : bx - naux - v.dm.G_plane);
-    if (v.dbg && threadIdx.x == 0 && (b == g1 || b == g2)) v.dbg[b == g1 ? 10 : 12] = clock64(); // first IMU / prior workgroup
+    if (v.dbg && v.dbg_sel < 0 && threadIdx.x == 0 && (b == g1 || b == g2)) v.dbg[b == g1 ? 10 : 12] = clock64(); // first IMU / prior workgroup (absolute)
     if (b < g0) role_landmarks<T, MM, MM ? TilesPerWave<T>::value : 1>(v, lds, pro, b, g0);
     else if (b < g1) {
         if (pro->mode != MODE_MARG) role_planes<T>(v, lds, pro, b - g0, v.dm.G_plane, b);
@@ -1063,9 +1071,9 @@ __global__ void __launch_bounds__(kLinThreads) k_linearize(View v) {
         const int vic = v.ctrl->marg_victim;
         if (v.pre_valid[j] && (pro->mode != MODE_MARG || j == vic || j == vic + 1)) role_preint(v, lds, pro, j);
     } else role_prior(v, lds, pro, b - g2, v.dm.G_prior);
-    if (v.dbg && threadIdx.x == 0 && (b == g1 || b == g2)) v.dbg[b == g1 ? 11 : 13] = clock64();
+    if (v.dbg && v.dbg_sel < 0 && threadIdx.x == 0 && (b == g1 || b == g2)) v.dbg[b == g1 ? 11 : 13] = clock64();
     PV_STAMP(0, 9);
-    if (v.dbg && blockIdx.x == 0 && threadIdx.x == 0) v.dbg[31] = wall_clock64();
+    if (v.dbg && blockIdx.x == 0 && threadIdx.x == 0) v.dbg[30] = 0, v.dbg[31] = wall_clock64() - g_stamp_w0[0]; // 10 ns units
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1202,7 +1210,9 @@ struct DenseShared {
     int do_solve, do_trace, trace_slot, accepted, first;
     int replay_first, replay_count; // trace slots written by the linear-solver-failure replay
     double x_cost_new;
+    long long stamp1, stamp2; // profiling: the two stamp sites every launch passes, published only by launches that go on to factor
 };
+static_assert(sizeof(DenseShared) <= 16 * sizeof(double), "LDS header layout");
 
 // per-landmark back-substitution for landmarks l = first, first + stride, ...; vs / ys = C_p v_p, C_p y'_p (any memory)
 __device__ __forceinline__ void backsub_landmarks(const View &v, int lin, double mu, const double *vs, const double *ys, int first, int stride, double *s) {
@@ -1586,8 +1596,8 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
         }
     }
 
+    PV_STAMP_BEGIN(2);
     PV_STAMP(2, 0);
-    if (v.dbg && threadIdx.x == 0) v.dbg[2 * 32 + 30] = wall_clock64();
     // Touch everything the assembly reads, one load per 128-byte line: the sources were produced on other XCDs and a first
     // touch costs a trip through the fabric -- paid once here, all lines in flight, overlapped with the control section.
     double pf = 0;
@@ -1699,7 +1709,7 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
         if (tid == 0) c->mode = MODE_DONE, *cg = *c;
         return;
     }
-    PV_STAMP(2, 1);
+    if (v.dbg && tid == 0) sh.stamp1 = clock64() - g_stamp_t0[2];
     if (pf == 1.2345678901234567e301) v.vstep[0] = pf; // keeps the prefetch loads alive (never true for finite data)
     const bool need_build = sh.accepted || sh.do_solve; // a new accepted linearization (or RELIN) is in `red`
     // ---------------- assemble the unscaled vectors: diag(J^T J), gradient, Schur rhs ----------------
@@ -1761,7 +1771,7 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
         }
         __syncthreads();
     }
-    PV_STAMP(2, 2);
+    if (v.dbg && tid == 0) sh.stamp2 = clock64() - g_stamp_t0[2];
     // ---------------- Finalize: record, state-updating callback, termination tests ----------------
     if (tid == 0 && sh.do_trace) {
         const int lr = c->lin_result;
@@ -1811,6 +1821,7 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
     }
 
     PV_STAMP(2, 3);
+    if (v.dbg && tid == 0 && (v.dbg_sel < 0 || v.dbg_sel == 1 || v.dbg_sel == 2)) v.dbg[2 * 32 + 1] = sh.stamp1, v.dbg[2 * 32 + 2] = sh.stamp2;
     // ---------------- Jacobi scaling (once), dogleg diagonal, scaled system ----------------
     const bool first_scaling = !c->scaling_ready;
     const double mu = c->mu;
@@ -2526,7 +2537,7 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
     // the control block goes back as one store per thread (a struct copy by thread 0 is 24 dependent LDS reads and stores)
     if (tid < (int)(sizeof(Ctrl) / sizeof(double))) reinterpret_cast<double *>(cg)[tid] = reinterpret_cast<const double *>(c)[tid];
     PV_STAMP(2, 7);
-    if (v.dbg && threadIdx.x == 0) v.dbg[2 * 32 + 31] = wall_clock64();
+    if (v.dbg && threadIdx.x == 0) v.dbg[2 * 32 + 30] = 0, v.dbg[2 * 32 + 31] = wall_clock64() - g_stamp_w0[2]; // 10 ns units
 }
 
 // ------------------------------------------------------------------------------------------------------

@@ -525,7 +525,10 @@ int BASolver::solve(pvio_ba_summary *sum, pvio_ba_kernel_times *prof) {
         long long *dbg = nullptr;
         if (!dev(pool_, "dbg", 4 * 32, &dbg, &grew)) return fail(PVIO_ERR_OUT_OF_MEMORY, "dbg");
         (void)hipMemsetAsync(dbg, 0, 4 * 32 * sizeof(long long), stream_);
-        v_.dbg = dbg;
+        // PVIO_HIP_STAMP_SEL: -1 (default) every stamp site stores, k >= 0 only site k (one store per launch), -2 none (events only)
+        const char *sel = std::getenv("PVIO_HIP_STAMP_SEL");
+        v_.dbg_sel = sel ? std::atoi(sel) : -1;
+        v_.dbg = v_.dbg_sel == -2 ? nullptr : dbg;
     }
     for (;;) {
         int rc;
@@ -560,7 +563,7 @@ int BASolver::solve(pvio_ba_summary *sum, pvio_ba_kernel_times *prof) {
     }
     if (prof) {
         for (auto &e : pev) (void)hipEventDestroy(e);
-        (void)hipMemcpy(prof->phase_ticks, v_.dbg, 4 * 32 * sizeof(long long), hipMemcpyDeviceToHost);
+        if (v_.dbg) (void)hipMemcpy(prof->phase_ticks, v_.dbg, 4 * 32 * sizeof(long long), hipMemcpyDeviceToHost);
         v_.dbg = dbg_saved;
     }
     ++solves_since_upload_;

@@ -139,7 +139,8 @@ struct View { // passed by value to every kernel
     double *trace_states;
     double *lm_quality;
     uint8_t *lm_valid;
-    long long *dbg; // optional phase timestamps (profiling builds): [kernel 0..3][32] shader-clock ticks, block 0 / thread 0
+    long long *dbg; // optional phase timestamps (profiling entry point): [kernel 0..3][32] shader-clock ticks since the launch's start, block 0 / thread 0
+    int dbg_sel;    // -1: every stamp site stores; k >= 0: only site k does (one store per launch: the stamps' own s_waitcnt / store do not add up)
 };
 
 inline int lin_set_stride_M() { return 1; }
