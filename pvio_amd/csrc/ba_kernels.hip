@@ -1583,17 +1583,8 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
             sbk[i] = valid ? nbk - 1 - g : -1;
             sbi[i] = valid ? nbk - 1 - h : 0;
         }
-        // issue the loads of this wave's tiles now: their latency (a trip through the fabric, k_reduce ran on other XCDs)
-        // is covered by the control section and the vector assembly
 #pragma unroll
-        for (int i = 0; i < kSlots; ++i) {
-            raw[i][0][0] = 0.0, raw[i][0][1] = 0.0, raw[i][1][0] = 0.0, raw[i][1][1] = 0.0;
-            if (from_images && sbk[i] >= 0) {
-                const double *T = v.img + ((size_t)(((sbi[i] * (sbi[i] + 1)) >> 1) + sbk[i]) << 8) + 4 * lane;
-                raw[i][0] = *reinterpret_cast<const lds_d2 *>(T);
-                raw[i][1] = *reinterpret_cast<const lds_d2 *>(T + 2);
-            }
-        }
+        for (int i = 0; i < kSlots; ++i) raw[i][0][0] = 0.0, raw[i][0][1] = 0.0, raw[i][1][0] = 0.0, raw[i][1][1] = 0.0;
     }
 
     PV_STAMP_BEGIN(2);
@@ -1712,6 +1703,21 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
     if (v.dbg && tid == 0) sh.stamp1 = clock64() - g_stamp_t0[2];
     if (pf == 1.2345678901234567e301) v.vstep[0] = pf; // keeps the prefetch loads alive (never true for finite data)
     const bool need_build = sh.accepted || sh.do_solve; // a new accepted linearization (or RELIN) is in `red`
+    if constexpr (LDSMAT) {
+        // The loads of this wave's tiles are issued here, by the launches that go on to factor (a rejected step reuses the last
+        // Gauss-Newton step: three launches in ten at 10 x 1000 would pull the 112 KB image through this CU for nothing): their
+        // latency -- a trip through the fabric, k_reduce ran on other XCDs -- is covered by the vector assembly, the finalize
+        // pass and the scaling below.
+        if (need_build) {
+#pragma unroll
+            for (int i = 0; i < kSlots; ++i)
+                if (from_images && sbk[i] >= 0) {
+                    const double *T = v.img + ((size_t)(((sbi[i] * (sbi[i] + 1)) >> 1) + sbk[i]) << 8) + 4 * lane;
+                    raw[i][0] = *reinterpret_cast<const lds_d2 *>(T);
+                    raw[i][1] = *reinterpret_cast<const lds_d2 *>(T + 2);
+                }
+        }
+    }
     // ---------------- assemble the unscaled vectors: diag(J^T J), gradient, Schur rhs ----------------
     if (need_build) {
         if (tid < N) {
@@ -1815,8 +1821,8 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
         if (tid == 0) c->mode = MODE_DONE, *cg = *c;
         return;
     }
-    if (!sh.do_solve) {
-        if (tid == 0) *cg = *c;
+    if (!sh.do_solve) { // a rejected or invalid step: nothing to factor (one store per thread, see the end of the kernel)
+        if (tid < (int)(sizeof(Ctrl) / sizeof(double))) reinterpret_cast<double *>(cg)[tid] = reinterpret_cast<const double *>(c)[tid];
         return;
     }
 

@@ -512,12 +512,15 @@ int BASolver::solve(pvio_ba_summary *sum, pvio_ba_kernel_times *prof) {
     h_ctrl_->dbg_fail_left = dbg_fail_, h_ctrl_->dbg_invalid_left = dbg_invalid_;
     if (check(hipMemcpyAsync(v_.ctrl, h_ctrl_, sizeof(Ctrl), hipMemcpyHostToDevice, stream_), "reset ctrl")) return PVIO_ERR_HIP;
     if (check(hipEventRecord(ev0_, stream_), "event")) return PVIO_ERR_HIP;
-    // every slot = one pass of [linearize, reduce, dense, backsub]; iteration 0 + max_iter iterations (+ slack for
-    // mu escalations); relaunch while the device has not reported done
-    const int n_slots = dm.max_iter + 2;
+    // every slot = one pass of [linearize, reduce, dense, backsub]; iteration 0 + max_iter iterations; relaunch while the device
+    // has not reported done
+    // (no slack slot: a solve whose mu escalates needs more slots than iterations and simply gets a second replay from the loop below;
+    // every other solve saved four no-op launches per replay)
+    const int n_slots = dm.max_iter + 1;
     int rounds = 0;
     hipEvent_t pev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     long long *dbg_saved = v_.dbg;
+    bool prof_graph = false;
     if (prof) {
         std::memset(prof, 0, sizeof *prof);
         for (auto &e : pev) (void)hipEventCreate(&e);
@@ -529,10 +532,14 @@ int BASolver::solve(pvio_ba_summary *sum, pvio_ba_kernel_times *prof) {
         const char *sel = std::getenv("PVIO_HIP_STAMP_SEL");
         v_.dbg_sel = sel ? std::atoi(sel) : -1;
         v_.dbg = v_.dbg_sel == -2 ? nullptr : dbg;
+        // PVIO_HIP_PROFILE_GRAPH=1: the stamps are taken inside a REPLAY of the slot graph (kernels back to back, as in a normal
+        // solve) instead of eager launches with a host synchronization per slot; no per-launch events then
+        prof_graph = std::getenv("PVIO_HIP_PROFILE_GRAPH") != nullptr && std::atoi(std::getenv("PVIO_HIP_PROFILE_GRAPH")) != 0;
+        if (prof_graph) invalidate_graph(); // the graph bakes the View in: capture one that carries the stamp buffer
     }
     for (;;) {
         int rc;
-        if (prof) { // one slot at a time, events around every launch; counts only slots that did work
+        if (prof && !prof_graph) { // one slot at a time, events around every launch; counts only slots that did work
             rc = enqueue_slot(pev);
             if (rc == PVIO_OK && check(hipStreamSynchronize(stream_), "profile sync")) rc = PVIO_ERR_HIP;
             if (rc == PVIO_OK) {
@@ -565,6 +572,7 @@ int BASolver::solve(pvio_ba_summary *sum, pvio_ba_kernel_times *prof) {
         for (auto &e : pev) (void)hipEventDestroy(e);
         if (v_.dbg) (void)hipMemcpy(prof->phase_ticks, v_.dbg, 4 * 32 * sizeof(long long), hipMemcpyDeviceToHost);
         v_.dbg = dbg_saved;
+        if (prof_graph) invalidate_graph(); // the next solve captures a graph without the stamp buffer again
     }
     ++solves_since_upload_;
     if (!h_ctrl_->done) return fail(PVIO_ERR_HIP, "device state machine did not terminate");

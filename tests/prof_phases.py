@@ -14,8 +14,9 @@ LIN_SITES = [(1, "prologue done"), (2, "first chunk: cleared"), (3, "factors eva
              (7, "tiles accumulated"), (8, "partial row flushed"), (9, "end")]
 
 
-def run(pb, sel):
+def run(pb, sel, graph=False):
     os.environ["PVIO_HIP_STAMP_SEL"] = str(sel)
+    os.environ["PVIO_HIP_PROFILE_GRAPH"] = "1" if graph else "0"
     ctx = HipContext(device=0)
     ctx.upload(pb)
     for _ in range(3):
@@ -50,10 +51,11 @@ for vio in (True, False):
         row = []
         for idx, name in sites:
             _, t = run(pb, idx)
-            row.append((name, t[kern][idx], allt[kern][idx]))
-        print('  %s: ticks since the launch started, one site per run | all sites in one run' % kern)
-        for name, one, al in row:
-            print('    %-36s %8d | %8d' % (name, one, al))
+            _, tg = run(pb, idx, graph=True)
+            row.append((name, t[kern][idx], allt[kern][idx], tg[kern][idx]))
+        print('  %s: ticks since the launch started.  eager launches: one site per run | all sites in one run || inside a graph replay, one site per run' % kern)
+        for name, one, al, gr in row:
+            print('    %-36s %8d | %8d || %8d' % (name, one, al, gr))
         wall_us = (allt[kern][31] - allt[kern][30]) * 0.01
         print('    wall clock of the last launch that reached the end (a factoring launch for k_dense; all sites active): %.1f us -> %.0f ticks/us'
               % (wall_us, row[-1][2] / wall_us if wall_us > 0 else 0))
