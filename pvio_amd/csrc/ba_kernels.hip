@@ -1589,14 +1589,16 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
 
     PV_STAMP_BEGIN(2);
     PV_STAMP(2, 0);
-    // Touch everything the assembly reads, one load per 128-byte line: the sources were produced on other XCDs and a first
-    // touch costs a trip through the fabric -- paid once here, all lines in flight, overlapped with the control section.
+    // Touch what the assembly reads, one load per 128-byte line: the sources were produced on other XCDs and a first touch
+    // costs a trip through the fabric -- paid once here, all lines in flight, overlapped with the control section.  When the
+    // reduced system arrives as a tile image this workgroup reads only the pose VECTORS and scalars of `red` and the
+    // DIAGONALS of the IMU / prior blocks (requested individually below): not the 250 KB of full blocks.
     double pf = 0;
     {
         const size_t nR = nS + (size_t)kNumPoseVec * P6 + kNumLinScal;
 #pragma unroll 4
-        for (size_t e = (size_t)tid * 16; e < nR; e += (size_t)nthr * 16) pf += v.red[e];
-        if (d == 15) {
+        for (size_t e = (from_images ? nS : 0) + (size_t)tid * 16; e < nR; e += (size_t)nthr * 16) pf += v.red[e];
+        if (d == 15 && !from_images) {
             if (v.dm.G_pre) {
                 const size_t nH = (size_t)N * 900, nG = (size_t)N * 30;
 #pragma unroll 4
@@ -1611,11 +1613,58 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
             }
         }
     }
+    // static per-frame data of the vector assembly (prior slot, IMU factor present) and both state buffers (the gradient-max
+    // pass reads the accepted iterate; which buffer that is, is decided by the control section): staged with the control inputs.
+    // Lp is free until the factorization starts.
+    if (tid < N) {
+        int slot = -1;
+        for (int q = 0; q < v.dm.prior_n; ++q)
+            if (v.prior_frames[q] == tid) slot = q;
+        pslot[tid] = slot;
+        pvalid[tid] = (v.dm.G_pre && v.pre_valid[tid]) ? 1 : 0;
+        if (tid < v.dm.prior_n) pframe[tid] = v.prior_frames[tid];
+    }
+    for (int e = tid; e < 32 * N; e += nthr) Lp[e] = v.fs[e];
+    const bool f_pose_active = tid < N ? v.pose_active[tid] != 0 : false, f_motion_active = tid < N ? v.motion_active[tid] != 0 : false;
     // every thread takes the termination flag from its own load: thread 0 may set the LDS copy's `done` in the control
     // section below while slower waves are still on their way to this test
     const int was_done = cg->done;
     __syncthreads(); // the staged control inputs are in LDS (global loads stay in flight across the barrier)
     if (was_done) return; // nothing was modified
+    // ---------------- unscaled vectors, part 1: diag(J^T J), gradient, Schur rhs of coordinate a = tid ----------------
+    // requested and summed while thread 0 runs the control section below (P <= 15 * kMaxFrames <= nthr: one coordinate per
+    // thread); written to LDS afterwards if the control section says that `red` holds a new accepted linearization
+    static_assert(15 * kMaxFrames <= 2 * kDenseThreads, "one coordinate per thread");
+    double as_dg = 0, as_g = 0, as_r = 0, as_act = 0;
+    if (tid < P) {
+        const int a = tid;
+        const int f = d == 15 ? a / 15 : a / 6, k = a - d * f;
+        double dg = 0, g = 0, rs = 0;
+        if (k < 6) dg = redV[2 * P6 + 6 * f + k], g = redV[6 * f + k], rs = redV[P6 + 6 * f + k];
+        double r = g - rs; // rhs_u = g_total - sum_l w_l W_l^T b_l
+        if (d == 15) {
+            if (v.dm.G_pre) {
+                const int jA = f, jB = f + 1;
+                const bool vA = jA >= 1 && pvalid[jA], vB = jB < N && pvalid[jB];
+                const double hA = vA ? v.pre_H[(size_t)jA * 900 + (15 + k) * 31] : 0.0, gA = vA ? v.pre_g[(size_t)jA * 30 + 15 + k] : 0.0;
+                const double hB = vB ? v.pre_H[(size_t)jB * 900 + k * 31] : 0.0, gB = vB ? v.pre_g[(size_t)jB * 30 + k] : 0.0;
+                if (jA & 1) dg = (dg + hA) + hB, g = (g + gA) + gB, r = (r + gA) + gB;
+                else dg = (dg + hB) + hA, g = (g + gB) + gA, r = (r + gB) + gA;
+            }
+            const int ps = pslot[f];
+            if (ps >= 0) {
+                const int D = 15 * v.dm.prior_n, pa = 15 * ps + k;
+                const double pg = v.prior_g[pa];
+                dg += v.prior_H[(size_t)pa * D + pa], g += pg, r += pg;
+            }
+        }
+        if (v.dm.n_rot > 0 && k < 3) {
+            const double rg = v.rot_g[3 * f + k];
+            dg += v.rot_H[9 * f + 4 * k], g += rg, r += rg;
+        }
+        as_act = (k < 6 ? v.pose_active[f] : v.motion_active[f]) ? 1.0 : 0.0;
+        as_dg = dg, as_g = g, as_r = r;
+    }
     // ---------------- control (thread 0): Finalize the iteration in flight, decide what comes next ----------------
     if (tid == 0) {
         const int lr = c->lin_result;
@@ -1718,57 +1767,21 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
                 }
         }
     }
-    // ---------------- assemble the unscaled vectors: diag(J^T J), gradient, Schur rhs ----------------
+    // ---------------- unscaled vectors, part 2 ----------------
     if (need_build) {
-        if (tid < N) {
-            int slot = -1;
-            for (int q = 0; q < v.dm.prior_n; ++q)
-                if (v.prior_frames[q] == tid) slot = q;
-            pslot[tid] = slot;
-            pvalid[tid] = (v.dm.G_pre && v.pre_valid[tid]) ? 1 : 0;
-            if (tid < v.dm.prior_n) pframe[tid] = v.prior_frames[tid];
-        }
-        __syncthreads();
-        for (int a = tid; a < P; a += nthr) {
-            const int f = d == 15 ? a / 15 : a / 6, k = a - d * f;
-            double dg = 0, g = 0, rs = 0;
-            if (k < 6) dg = redV[2 * P6 + 6 * f + k], g = redV[6 * f + k], rs = redV[P6 + 6 * f + k];
-            double r = g - rs; // rhs_u = g_total - sum_l w_l W_l^T b_l
-            if (d == 15) {
-                if (v.dm.G_pre) {
-                    const int jA = f, jB = f + 1;
-                    const bool vA = jA >= 1 && v.pre_valid[jA], vB = jB < N && v.pre_valid[jB];
-                    const double hA = vA ? v.pre_H[(size_t)jA * 900 + (15 + k) * 31] : 0.0, gA = vA ? v.pre_g[(size_t)jA * 30 + 15 + k] : 0.0;
-                    const double hB = vB ? v.pre_H[(size_t)jB * 900 + k * 31] : 0.0, gB = vB ? v.pre_g[(size_t)jB * 30 + k] : 0.0;
-                    if (jA & 1) dg = (dg + hA) + hB, g = (g + gA) + gB, r = (r + gA) + gB;
-                    else dg = (dg + hB) + hA, g = (g + gB) + gA, r = (r + gB) + gA;
-                }
-                const int ps = pslot[f];
-                if (ps >= 0) {
-                    const int D = 15 * v.dm.prior_n, pa = 15 * ps + k;
-                    const double pg = v.prior_g[pa];
-                    dg += v.prior_H[(size_t)pa * D + pa], g += pg, r += pg;
-                }
-            }
-            if (v.dm.n_rot > 0 && k < 3) {
-                const double rg = v.rot_g[3 * f + k];
-                dg += v.rot_H[9 * f + 4 * k], g += rg, r += rg;
-            }
-            act[a] = (k < 6 ? v.pose_active[f] : v.motion_active[f]) ? 1.0 : 0.0;
-            diagH[a] = dg, gtot[a] = g, rhs[a] = r;
-        }
+        if (tid < P) diagH[tid] = as_dg, gtot[tid] = as_g, rhs[tid] = as_r, act[tid] = as_act;
         __syncthreads();
         // gradient_max_norm = max | x - (x (+) -g) | over the free blocks (ambient coordinates)
         double gm = 0;
         if (tid < N) {
-            const double *x = v.fs + ((size_t)c->cur * N + tid) * 16;
-            if (v.pose_active[tid]) {
+            const double *x = Lp + ((size_t)c->cur * N + tid) * 16; // staged copy of v.fs
+            if (f_pose_active) {
                 double ng[6], y[7];
                 for (int k = 0; k < 6; ++k) ng[k] = -gtot[d * tid + k];
                 pose_plus(y, x, ng, ng + 3);
                 for (int k = 0; k < 7; ++k) gm = fmax(gm, fabs(x[k] - y[k]));
             }
-            if (d == 15 && v.motion_active[tid])
+            if (d == 15 && f_motion_active)
                 for (int k = 0; k < 9; ++k) gm = fmax(gm, fabs(gtot[15 * tid + 6 + k]));
         }
         if (tid < 64) {
