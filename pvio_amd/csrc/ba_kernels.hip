@@ -1615,7 +1615,7 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
     }
     // static per-frame data of the vector assembly (prior slot, IMU factor present) and both state buffers (the gradient-max
     // pass reads the accepted iterate; which buffer that is, is decided by the control section): staged with the control inputs.
-    // Lp is free until the factorization starts.
+    // Lp is free until the factorization starts (48 N <= 8 LDV doubles).
     if (tid < N) {
         int slot = -1;
         for (int q = 0; q < v.dm.prior_n; ++q)
@@ -1625,6 +1625,7 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
         if (tid < v.dm.prior_n) pframe[tid] = v.prior_frames[tid];
     }
     for (int e = tid; e < 32 * N; e += nthr) Lp[e] = v.fs[e];
+    for (int e = tid; e < 16 * N; e += nthr) Lp[32 * N + e] = v.fs_user[e]; // the user state the finalize pass takes the old biases from
     const bool f_pose_active = tid < N ? v.pose_active[tid] != 0 : false, f_motion_active = tid < N ? v.motion_active[tid] != 0 : false;
     // every thread takes the termination flag from its own load: thread 0 may set the LDS copy's `done` in the control
     // section below while slower waves are still on their way to this test
@@ -1816,16 +1817,16 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
         const int cur = c->cur;
         if (sh.accepted && !sh.first) {
             // the accepted linearization was evaluated with the OLD user biases: keep them for a later RELIN
-            for (int e = tid; e < N * 6; e += nthr) v.bias0_lin[e] = v.fs_user[(e / 6) * 16 + 10 + e % 6];
+            for (int e = tid; e < N * 6; e += nthr) v.bias0_lin[e] = Lp[32 * N + (e / 6) * 16 + 10 + e % 6]; // staged v.fs_user
         }
         __syncthreads();
         if (sh.accepted)
-            for (int e = tid; e < N * 16; e += nthr) v.fs_user[e] = v.fs[(size_t)cur * N * 16 + e];
+            for (int e = tid; e < N * 16; e += nthr) v.fs_user[e] = Lp[(size_t)cur * N * 16 + e]; // staged v.fs
         if (sh.first)
-            for (int e = tid; e < N * 6; e += nthr) v.bias0_lin[e] = v.fs[(size_t)cur * N * 16 + (e / 6) * 16 + 10 + e % 6];
+            for (int e = tid; e < N * 6; e += nthr) v.bias0_lin[e] = Lp[(size_t)cur * N * 16 + (e / 6) * 16 + 10 + e % 6];
         if (v.trace_states && sh.trace_slot >= 0) {
             double *dst = v.trace_states + (size_t)sh.trace_slot * (N * 16 + v.dm.M);
-            for (int e = tid; e < N * 16; e += nthr) dst[e] = v.fs[(size_t)cur * N * 16 + e];
+            for (int e = tid; e < N * 16; e += nthr) dst[e] = Lp[(size_t)cur * N * 16 + e];
             for (int e = tid; e < v.dm.M; e += nthr) dst[N * 16 + e] = v.rho[(size_t)cur * v.dm.M + e];
         }
     }
@@ -1844,6 +1845,7 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
     // ---------------- Jacobi scaling (once), dogleg diagonal, scaled system ----------------
     const bool first_scaling = !c->scaling_ready;
     const double mu = c->mu;
+    double keep_Da = 0, keep_gh = 0; // dogleg diagonal and scaled gradient of coordinate a = tid (LDV <= nthr), for the output section
     for (int a = tid; a < LDV; a += nthr) {
         if (a >= P) {
             vv[a] = 0.0, cpl[a] = 0.0, tmp[a] = 0.0, yv[a] = 0.0; // padding (act[] is only read below P)
@@ -1859,9 +1861,8 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
         cpl[a] = act[a] != 0.0 ? cpa : 0.0; // LDS copy: 0 marks an inactive coordinate
         const double d2 = cpa * cpa * diagH[a];
         const double Da = sqrt(fmin(fmax(d2, 1e-6), 1e32));
-        v.Dp[a] = Da;
         const double gh = act[a] != 0.0 ? cpa * gtot[a] / Da : 0.0;
-        v.ghp[a] = gh;
+        keep_Da = Da, keep_gh = gh;
         vv[a] = gh / Da;                                  // v = g^ / D
         tmp[a] = Da;
         yv[a] = act[a] != 0.0 ? cpa * rhs[a] : 0.0;       // scaled reduced rhs -> augmented row P
@@ -2458,7 +2459,7 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
             for (int a = tid; a < P; a += nthr) {
                 nbad += isfinite(ysol[a]) ? 0.0 : 1.0;
                 const double yp = act[a] != 0.0 ? -ysol[a] : 0.0;
-                const double Da = v.Dp[a], gh = v.ghp[a], gn = Da * yp;
+                const double Da = keep_Da, gh = keep_gh, gn = Da * yp;
                 v.ystep[a] = cpl[a] * yp;
                 v.vstep[a] = act[a] != 0.0 ? cpl[a] * vv[a] : 0.0;
                 s_g2 += gh * gh, s_gn2 += gn * gn, s_gd += gh * gn;
