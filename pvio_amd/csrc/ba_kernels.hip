@@ -2107,8 +2107,9 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
                     hq[q] = dense_row_of(wv, q);
                     opA[q] = *reinterpret_cast<const lds_d2 *>(Lpan + 128 * (hq[q] < R ? nbk - 1 - hq[q] : b0));
                 }
+                // (the column that is factored next, g = R - 1, is updated first: its operand is requested first -- LDS answers in order)
 #pragma unroll
-                for (int g = 0; g < kDenseCols; ++g)
+                for (int g = kDenseCols - 1; g >= 0; --g)
                     if (g < R) opB[g] = *reinterpret_cast<const lds_d2 *>(Lpan + 128 * (nbk - 1 - g)); // live columns only
                 // a column's slots, unconditionally: a slot that holds no tile of this wave (its q-th row lies outside the column)
                 // costs two MFMAs on registers nobody reads -- cheaper than a uniform branch per slot, which splits the MFMA
@@ -2188,7 +2189,10 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
             const int lc = lane >> 3, lrr = lane & 7;
             for (int p = npan - 1; p >= 0; --p) {
                 const int jb0 = p * kPanel;
-                double lrow[kPanel]; // L(jb0 + cc, a) for this thread's row a (independent of y: issued first)
+                // the two reads the dependent chain starts from go first (LDS answers in order), the L row of this thread's
+                // row a -- independent of y, needed only after the lane reads -- behind them
+                const double li = Li[p * 64 + lane], zr = yv[jb0 + lrr]; // Li[p][c][r] = (L_pp^-1)[r][c]
+                double lrow[kPanel]; // L(jb0 + cc, a)
                 const int a = tid;
                 double ya = 0;
                 if (a < jb0) {
@@ -2197,17 +2201,17 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
                     for (int cc = 0; cc < kPanel; ++cc) lrow[cc] = T[8 * cc];
                     ya = yv[a];
                 }
-                double part = Li[p * 64 + lane] * yv[jb0 + lrr]; // Li[p][c][r] = (L_pp^-1)[r][c]
+                double part = li * zr;
                 part = group8_sum(part);
                 double yb[kPanel];
 #pragma unroll
                 for (int cc = 0; cc < kPanel; ++cc) yb[cc] = readlane_f64(part, 8 * cc);
                 if (wv == 0 && lrr == 0) ysol[jb0 + lc] = part;
                 if (a < jb0) {
-                    double acc2 = 0;
+                    double acc2 = 0, acc3 = 0; // (two chains of four)
 #pragma unroll
-                    for (int cc = 0; cc < kPanel; ++cc) acc2 += lrow[cc] * yb[cc];
-                    yv[a] = ya - acc2;
+                    for (int cc = 0; cc < kPanel / 2; ++cc) acc2 += lrow[cc] * yb[cc], acc3 += lrow[cc + 4] * yb[cc + 4];
+                    yv[a] = ya - (acc2 + acc3);
                 }
                 __syncthreads();
             }
