@@ -2107,9 +2107,11 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
                     hq[q] = dense_row_of(wv, q);
                     opA[q] = *reinterpret_cast<const lds_d2 *>(Lpan + 128 * (hq[q] < R ? nbk - 1 - hq[q] : b0));
                 }
-                // (the column that is factored next, g = R - 1, is updated first: its operand is requested first -- LDS answers in order)
+                // (ascending on purpose.  Requesting the operand of the column that is updated first, g = R - 1, first -- a descending
+                // loop -- compiled to code whose results were WRONG on the GPU while the emulated kernels passed: tests/test_gpu_ba.py
+                // caught it, the cause in the generated code was not found; measured gain of that order: none.)
 #pragma unroll
-                for (int g = kDenseCols - 1; g >= 0; --g)
+                for (int g = 0; g < kDenseCols; ++g)
                     if (g < R) opB[g] = *reinterpret_cast<const lds_d2 *>(Lpan + 128 * (nbk - 1 - g)); // live columns only
                 // a column's slots, unconditionally: a slot that holds no tile of this wave (its q-th row lies outside the column)
                 // costs two MFMAs on registers nobody reads -- cheaper than a uniform branch per slot, which splits the MFMA
