@@ -9,9 +9,9 @@ import sys
 import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-# (the slice grew with the suite: it is kept to what exercises every kernel once -- both window kinds, the rotation-prior
-# role, one fault path, marginalization -- so that the two reruns stay under half a minute each)
-SLICE = "vio_small or vision_small or vio_rot_prior or fail1_invalid0 or marginalize_matches_oracle"
+# (the slice grew with the suite: it is kept to what exercises every kernel once -- both window kinds, plane and rotation-prior
+# roles, marginalization (the fault paths are single-thread control code) -- so that the two reruns stay under half a minute each)
+SLICE = "vio_small or vision_small or vio_plane or vio_rot_prior or marginalize_matches_oracle"
 
 
 @pytest.mark.parametrize("order", ["reverse", "interleave"])
