@@ -276,3 +276,25 @@ def test_gpu_random_windows_match_oracle(gpu_ctx, oracle, seed):
     if rng.random() < 0.4:
         pb.frame_fixed[int(rng.integers(0, n))] = 1
     print(kw, ba_compare.check_against_oracle(gpu_ctx, oracle, pb))
+
+
+@pytest.mark.parametrize("poison", [float("nan"), 1e300], ids=["nan", "1e300"])
+def test_gpu_solver_reads_nothing_it_did_not_write(oracle, poison):
+    """A fresh context on device memory that a previous owner left full of NaN (or 1e300): 4 GB are filled and handed back to the
+    driver right before the solver allocates, so that its buffers are carved from them.  Any scratch / padding / second-buffer
+    word read before it is written would end in a different trace; the solves must equal the oracle's as usual.  (Fresh pages
+    from the driver are zeroed, which is the other thing a first solve may meet: every other GPU test starts that way.)"""
+    import torch
+    from pvio_amd.solver import HipContext
+    for name in ("vio_small", "vision_partial", "vio_plane"):
+        pb = ba_compare.make(oracle, **ba_compare.CASES[name])
+        xs = [torch.full((64 * 1024 * 1024,), poison, dtype=torch.float64, device="cuda") for _ in range(8)]
+        torch.cuda.synchronize()
+        del xs
+        torch.cuda.empty_cache()
+        torch.cuda.synchronize()
+        ctx = HipContext(device=0)
+        try:
+            ba_compare.check_against_oracle(ctx, oracle, pb)
+        finally:
+            ctx.close()
