@@ -413,7 +413,7 @@ def main():
                                    % (n_frames, n_lm, "full VIO factor set (IMU pre-integration + gauge prior)" if vio else "reprojection only",
                                       pb_full.n_obs, pb_full.max_iterations),
                        "parallelism": "landmark shards x%d, RCCL all-reduce of the reduced pose system" % world if sharded else "single GPU",
-                       "graph": (not args.no_graph) and not sharded},
+                       "graph": not args.no_graph},  # sharded solves are graph-captured too (collectives included) unless PVIO_HIP_SHARDED_GRAPH=0
             "iterations_per_solve": iters / args.steps,
             "device_ms_per_step": 1e3 * dev_s / args.steps,
             "api": api,
