@@ -74,3 +74,31 @@ def check_against_oracle(ctx, oracle, pb, state_tol=STATE_TOL, cost_rtol=1e-7):
     np.testing.assert_allclose(st1.lm_quality, st0.lm_quality, rtol=0, atol=1e-5)
     worst = max(np.abs(sm1.trace_states[k] - sm0.trace_states[k]).max() for k in range(len(t0)))
     return dict(worst_state_diff=worst, iterations=sm1.num_iterations, device_seconds=sm1.device_seconds)
+
+
+def check_against_reference(ctx, ref, pb, state_tol=STATE_TOL):
+    """A C-ABI solve against the REFERENCE'S OWN BundleAdjustorSolver::solve (oracle/_ref: bundle_adjustor.cpp + cost functions +
+    map layer compiled unedited, mini-Ceres loop underneath): same accept / reject / termination trace, states after every
+    iteration within north_star's 1e-6, landmark validity and quality of the post-solve pass."""
+    fs, trk, rs = ref.solve(pb)
+    st1, sm1 = ctx.solve(pb)
+    M, N16 = pb.n_landmarks, 16 * pb.n_frames
+    t0, t1 = rs.trace(), sm1.trace()
+    assert (sm1.termination, sm1.num_iterations, sm1.num_successful_steps) == (rs.termination, rs.num_iterations, rs.num_successful_steps)
+    assert len(t1) == len(t0)
+    np.testing.assert_allclose(t1[0]["cost"], t0[0]["cost"], rtol=1e-12)  # same problem: the initial cost at rounding level
+    worst = 0.0
+    for k, (a, b) in enumerate(zip(t0, t1)):
+        assert (a["step_is_valid"], a["step_is_successful"]) == (b["step_is_valid"], b["step_is_successful"]), (k, a, b)
+        np.testing.assert_allclose(b["cost"], a["cost"], rtol=1e-5)
+        np.testing.assert_allclose(b["trust_region_radius"], a["trust_region_radius"], rtol=1e-5)
+        assert a["mu"] == b["mu"]
+        worst = max(worst, np.abs(sm1.trace_states[k][:N16] - rs.trace_states[k][:N16]).max(),
+                    np.abs(sm1.trace_states[k][N16:] - rs.trace_states[k][N16:N16 + M]).max() if M else 0.0)
+    assert worst <= state_tol, worst
+    np.testing.assert_allclose(st1.frame_state, fs, rtol=0, atol=state_tol)
+    np.testing.assert_allclose(st1.lm_inv_depth, trk.inv_depth[:M], rtol=0, atol=state_tol)
+    assert (st1.lm_valid == trk.valid[:M]).all()
+    ok = st1.lm_valid.astype(bool)
+    np.testing.assert_allclose(st1.lm_quality[ok], trk.quality[:M][ok], rtol=0, atol=1e-5)
+    return dict(worst_state_diff=worst, iterations=sm1.num_iterations)

@@ -1,0 +1,368 @@
+"""The oracle pinned to the REFERENCE'S OWN source (oracle/_ref/libpvio_ref.so, built by oracle/ref/Makefile from the files
+under /root/reference, unedited; only Eigen and Ceres are stand-ins -- oracle/ref/eigen, oracle/ref/ceres).
+
+Per factor >= 1000 random inputs: residuals AND Jacobians of oracle/oracle_factors.h against the reference's
+  reprojection_error_cost.h:40-120, preintegration_error_cost.h:40-160, marginalization_error_cost.h:53-94,
+  augmented_plane_distance_error_cost.h:53-136, quaternion_parameterization.h:28-41, lie_algebra.{h,cpp}, preintegrator.cpp:39-100;
+then marginalize_frame (bundle_adjustor.cpp:348-599), compute_reprojection_error (:321-336) and the whole
+BundleAdjustorSolver::solve (:63-299: which blocks are added / constant, the live-bias read through the state-updating callback,
+the post-solve quality pass) on windows.  What stays unpinned: the trust-region loop itself (ceres::Solve is a restatement on
+both sides) and the OpenCV stages (rows K*).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from pvio_amd import synth
+from pvio_amd.problem import BAState, BASummary
+
+dp = C.POINTER(C.c_double)
+N_RANDOM = 1000
+REL = 1e-13  # bar of VERDICT r2 item 1: 1e-13 relative (scale = the largest entry of the compared array)
+
+
+def _d(a):
+    return a.ctypes.data_as(dp)
+
+
+@pytest.fixture(scope="module")
+def ref():
+    from oracle import ref_py
+    if not ref_py.available():
+        pytest.skip("oracle/_ref/libpvio_ref.so not built and /root/reference absent")
+    ref_py.lib()
+    return ref_py
+
+
+def close(a, b, rel=REL, what=""):
+    a, b = np.asarray(a), np.asarray(b)
+    scale = max(np.abs(b).max(), 1e-300)
+    err = np.abs(a - b).max() / scale
+    assert err <= rel, "%s: %.3e relative (bar %.1e)" % (what, err, rel)
+    return err
+
+
+def rand_q(rng, scale=None):
+    if scale is not None:
+        return synth.qexp(rng.normal(size=3) * scale)
+    q = rng.normal(size=4)
+    return q / np.linalg.norm(q)
+
+
+def rand_state(rng, rot=None, pos=1.0):
+    s = np.zeros(16)
+    s[0:4] = rand_q(rng, rot)
+    s[4:7] = rng.normal(size=3) * pos
+    s[7:10] = rng.normal(size=3)
+    s[10:13] = rng.normal(size=3) * 1e-2
+    s[13:16] = rng.normal(size=3) * 1e-1
+    return s
+
+
+def test_ref_library_is_the_reference(ref):
+    v = ref.lib().ref_version().decode()
+    assert v.startswith("pvio v0.3.0")
+
+
+def test_lie_helpers_equal_reference(ref, oracle):
+    """expmap / logmap / right_jacobian / QuaternionParameterization::Plus -- lie_algebra.h:25-42, lie_algebra.cpp:22-59,
+    quaternion_parameterization.h:28-32 -- incl. tiny angles (Taylor branches), angles near pi, and w < 0 quaternions"""
+    rng = np.random.default_rng(11)
+    L, R = oracle.lib(), ref.lib()
+    worst = dict(exp=0, log=0, jr=0, plus=0)
+    scales = [1e-12, 1e-9, 1e-6, 1e-4, 1e-3, 1e-2, 0.1, 1.0, 3.0, 3.14159]
+    for trial in range(N_RANDOM):
+        w = rng.normal(size=3)
+        w *= scales[trial % len(scales)] / np.linalg.norm(w) * (0.5 + rng.uniform())
+        a, b = np.zeros(4), np.zeros(4)
+        L.oracle_expmap(_d(w), _d(a)), R.ref_expmap(_d(w), _d(b))
+        worst["exp"] = max(worst["exp"], close(a, b, what="expmap"))
+        q = rand_q(rng) if trial % 3 else rand_q(rng, scales[trial % len(scales)])
+        if trial % 5 == 0:
+            q = -q
+        a3, b3 = np.zeros(3), np.zeros(3)
+        L.oracle_logmap(_d(q), _d(a3)), R.ref_logmap(_d(q), _d(b3))
+        worst["log"] = max(worst["log"], close(a3, b3, what="logmap"))
+        A, B = np.zeros(9), np.zeros(9)
+        L.oracle_right_jacobian(_d(w), _d(A)), R.ref_right_jacobian(_d(w), _d(B))
+        worst["jr"] = max(worst["jr"], close(A, B, what="right_jacobian"))
+        s, d15 = rand_state(rng), rng.normal(size=15) * scales[trial % len(scales)]
+        oa, ob = np.zeros(16), np.zeros(16)
+        L.oracle_plus(_d(s), _d(d15), _d(oa)), R.ref_plus(_d(s), _d(d15), _d(ob))
+        worst["plus"] = max(worst["plus"], close(oa, ob, what="plus"))
+    print("worst relative differences:", worst)
+
+
+def test_reprojection_factor_equals_reference(ref, oracle):
+    rng = np.random.default_rng(12)
+    L, R = oracle.lib(), ref.lib()
+    wr = wj = 0
+    for trial in range(N_RANDOM):
+        st, sr = rand_state(rng, 0.3, 0.3), rand_state(rng, 0.3, 0.3)
+        cam_r = np.concatenate([rand_q(rng, 0.2), rng.normal(size=3) * 0.05])
+        cam_t = np.concatenate([rand_q(rng, 0.2), rng.normal(size=3) * 0.05])
+        z_ref, z_tgt = rng.normal(size=2) * 0.3, rng.normal(size=2) * 0.3
+        W = np.array([400.0, 3.0, -2.0, 380.0]) * (0.5 + rng.uniform())
+        rho = 0.05 + rng.uniform() * 0.8
+        ra, rb, Ja, Jb = np.zeros(2), np.zeros(2), np.zeros((2, 13)), np.zeros((2, 13))
+        L.oracle_eval_reprojection(_d(st), _d(sr), rho, _d(z_ref), _d(z_tgt), _d(cam_r), _d(cam_t), _d(W), _d(ra), _d(Ja))
+        R.ref_eval_reprojection(_d(st), _d(sr), rho, _d(z_ref), _d(z_tgt), _d(cam_r), _d(cam_t), _d(W), _d(rb), _d(Jb))
+        wr, wj = max(wr, close(ra, rb, what="residual")), max(wj, close(Ja, Jb, what="jacobian"))
+    print("reprojection: worst residual %.2e, Jacobian %.2e relative" % (wr, wj))
+
+
+def _random_preint(rng, ref, n_s=40):
+    """a pre-integration block from the REFERENCE's integrator over random IMU samples"""
+    dt = 0.005
+    t = np.arange(n_s) * dt
+    w = rng.normal(size=(n_s, 3)) * 0.3
+    a = rng.normal(size=(n_s, 3)) * 2.0 + np.array([0, 0, 9.8])
+    noise = dict(cov_w=np.eye(3) * synth.COV_G, cov_a=np.eye(3) * synth.COV_A, cov_bg=np.eye(3) * synth.COV_BG, cov_ba=np.eye(3) * synth.COV_BA)
+    bg, ba = rng.normal(size=3) * 1e-2, rng.normal(size=3) * 1e-1
+    return (t, w, a, n_s * dt, bg, ba, noise)
+
+
+def test_preintegrator_equals_reference(ref, oracle):
+    """PreIntegrator::integrate -- preintegrator.cpp:39-100: delta, covariance, bias Jacobians, sqrt_inv_cov element-wise.
+    The 15 x 15 covariance of a 0.2 s block has a condition number of ~1e12 (bias random walk ~1e-12 next to ~1e-3 velocity
+    terms): cov.inverse() and its Cholesky factor amplify rounding differences of the two inverse algorithms by that, so
+    sqrt_inv_cov is held to 1e-13 * cond -- and, independently of conditioning, to U^T U cov = I."""
+    rng = np.random.default_rng(13)
+    worst = dict(delta=0, cov=0, jac=0, U=0)
+    for trial in range(200):
+        args = _random_preint(rng, ref, n_s=int(rng.integers(2, 60)))
+        da, ca, Ua, ja = oracle.preintegrate(*args)
+        db, cb, Ub, jb = ref.preintegrate(*args)
+        worst["delta"] = max(worst["delta"], close(da, db, what="delta"))
+        worst["cov"] = max(worst["cov"], close(ca, cb, what="cov"))
+        worst["jac"] = max(worst["jac"], close(ja, jb, what="bias jacobians"))
+        cond = np.linalg.cond(cb.reshape(15, 15))
+        worst["U"] = max(worst["U"], close(Ua, Ub, rel=max(REL, 1e-15 * cond), what="sqrt_inv_cov (cond %.1e)" % cond) / cond)
+        for U, c in ((Ua, ca), (Ub, cb)):
+            U, c = U.reshape(15, 15), c.reshape(15, 15)
+            assert np.abs(U.T @ U @ c - np.eye(15)).max() < 1e-15 * cond * 50
+    print("preintegrator worst relative differences (U: per unit of cond(cov)):", worst)
+
+
+def test_preintegration_factor_equals_reference(ref, oracle):
+    rng = np.random.default_rng(14)
+    L, R = oracle.lib(), ref.lib()
+    wr = wj = 0
+    for trial in range(N_RANDOM):
+        if trial % 20 == 0:
+            delta, cov, U, jac = ref.preintegrate(*_random_preint(rng, ref))
+        si, sj = rand_state(rng), rand_state(rng)
+        sj[0:4] = synth.qmul(synth.qmul(si[0:4], delta[1:5]), rand_q(rng, 0.05))  # a residual rotation of a few degrees
+        sj[4:7] = si[4:7] + si[7:10] * delta[0] + rng.normal(size=3) * 0.05
+        bias0 = np.concatenate([si[10:13], si[13:16]]) + rng.normal(size=6) * 1e-3  # live biases differ from the parameter block
+        imu_i = np.concatenate([rand_q(rng, 0.1), rng.normal(size=3) * 0.05])
+        imu_j = np.concatenate([rand_q(rng, 0.1), rng.normal(size=3) * 0.05])
+        ra, rb, Ja, Jb = np.zeros(15), np.zeros(15), np.zeros((15, 30)), np.zeros((15, 30))
+        L.oracle_eval_preintegration(_d(si), _d(sj), _d(bias0), _d(delta), _d(U), _d(jac), _d(imu_i), _d(imu_j), _d(ra), _d(Ja))
+        R.ref_eval_preintegration(_d(si), _d(sj), _d(bias0), _d(delta), _d(U), _d(jac), _d(imu_i), _d(imu_j), _d(rb), _d(Jb))
+        wr, wj = max(wr, close(ra, rb, what="residual")), max(wj, close(Ja, Jb, what="jacobian"))
+    print("preintegration factor: worst residual %.2e, Jacobian %.2e relative" % (wr, wj))
+
+
+def test_marginalization_factor_equals_reference(ref, oracle):
+    rng = np.random.default_rng(15)
+    L, R = oracle.lib(), ref.lib()
+    wr = wj = 0
+    for trial in range(N_RANDOM // 4):
+        n = int(rng.integers(1, 6))
+        D = 15 * n
+        lin = np.stack([rand_state(rng) for _ in range(n)])
+        states = lin.copy()
+        for i in range(n):
+            states[i, 0:4] = synth.qmul(lin[i, 0:4], rand_q(rng, 10.0 ** rng.uniform(-8, -0.5)))
+            states[i, 4:16] += rng.normal(size=12) * 0.05
+        S, s = rng.normal(size=(D, D)) * 10.0 ** rng.uniform(0, 3), rng.normal(size=D)
+        if trial % 7 == 0:  # the first-time gauge prior (sliding_window_tracker.cpp:100-112)
+            S[:] = 0
+            S[0:6, 0:6] = 1e15 * np.eye(6)
+        ra, rb, Ja, Jb = np.zeros(D), np.zeros(D), np.zeros((D, D)), np.zeros((D, D))
+        L.oracle_eval_prior(n, _d(states), _d(lin), _d(S), _d(s), _d(ra), _d(Ja))
+        R.ref_eval_prior(n, _d(states), _d(lin), _d(S), _d(s), _d(rb), _d(Jb))
+        wr, wj = max(wr, close(ra, rb, what="residual")), max(wj, close(Ja, Jb, what="jacobian"))
+    print("marginalization factor: worst residual %.2e, Jacobian %.2e relative" % (wr, wj))
+
+
+def test_plane_factor_equals_reference(ref, oracle):
+    """AugmentedPlaneDistanceErrorCost -- the 3 x 3 pseudo-inverse goes through an eigendecomposition on both sides (different
+    algorithms: closed form / Jacobi), so the bar is 1e-13 times the conditioning of A^T A, floor 1e-11"""
+    rng = np.random.default_rng(16)
+    L, R = oracle.lib(), ref.lib()
+    wr = wj = 0
+    for trial in range(N_RANDOM):
+        K = int(rng.integers(2, 9))
+        nrm = rng.normal(size=3)
+        nrm /= np.linalg.norm(nrm)
+        dist = rng.normal()
+        point = nrm * dist + np.cross(nrm, rng.normal(size=3)) * 2.0  # a point on the plane
+        states, cams, z = np.zeros((K, 16)), np.zeros((K, 7)), np.zeros((K, 2))
+        for i in range(K):
+            states[i] = rand_state(rng, 0.3, 0.5)
+            cams[i] = np.concatenate([rand_q(rng, 0.1), rng.normal(size=3) * 0.05])
+            states[i, 4:7] = point + synth.qmat(states[i, 0:4]) @ np.array([0, 0, -3.0]) + rng.normal(size=3) * 0.3
+            qc = synth.qmul(states[i, 0:4], cams[i, 0:4])
+            y = synth.qmat(qc).T @ (point - (states[i, 4:7] + synth.qmat(states[i, 0:4]) @ cams[i, 4:7]))
+            z[i] = y[:2] / y[2] + rng.normal(size=2) * 1e-3
+        sic = 100.0
+        ra, rb, Ja, Jb = np.zeros(1), np.zeros(1), np.zeros((K, 6)), np.zeros((K, 6))
+        L.oracle_eval_plane(K, _d(states), _d(cams), _d(z), _d(nrm), dist, sic, _d(ra), _d(Ja))
+        R.ref_eval_plane(K, _d(states), _d(cams), _d(z), _d(nrm), dist, sic, _d(rb), _d(Jb))
+        wr, wj = max(wr, np.abs(ra - rb).max() / max(np.abs(rb).max(), sic * 1e-3)), max(wj, close(Ja, Jb, rel=1e-10, what="jacobian"))
+    assert wr < 1e-10
+    print("plane factor: worst residual %.2e, Jacobian %.2e relative" % (wr, wj))
+
+
+# ---- window level --------------------------------------------------------------------------------------------------------
+
+def _window(kind, oracle):
+    if kind == "vision":
+        return synth.make_window(n_frames=5, n_landmarks=60, visibility=4, seed=701)
+    if kind == "vio":
+        return synth.make_window(n_frames=6, n_landmarks=80, use_inertial=True, visibility=4, seed=702, preintegrate=oracle.preintegrate)
+    if kind == "vio_zero_bias":
+        return synth.make_window(n_frames=5, n_landmarks=60, use_inertial=True, visibility=4, seed=703, preintegrate=oracle.preintegrate, bias_init="zero")
+    if kind == "vio_plane":
+        return synth.make_window(n_frames=6, n_landmarks=100, use_inertial=True, visibility=5, seed=704, preintegrate=oracle.preintegrate, plane_fraction=0.3)
+    if kind == "plane":
+        return synth.make_window(n_frames=5, n_landmarks=80, visibility=4, seed=705, plane_fraction=0.4)
+    raise KeyError(kind)
+
+
+@pytest.mark.parametrize("kind", ["vision", "vio", "vio_zero_bias", "vio_plane", "plane"])
+def test_solve_equals_reference(ref, oracle, kind):
+    """The reference's BundleAdjustorSolver::solve (its own problem construction, cost functions, callbacks and post-solve pass,
+    mini-Ceres underneath) against oracle_ba_solve: same accept / reject trace, states after every iteration, final states,
+    landmark quality and validity."""
+    pb = _window(kind, oracle)
+    st, sm = BAState(pb), BASummary(pb)
+    oracle.solve(pb, st, sm)
+    fs, trk, rs = ref.solve(pb)
+    M = pb.n_landmarks
+    ta, tb = sm.trace(), rs.trace()
+    assert sm.num_iterations == rs.num_iterations and sm.termination == rs.termination and len(ta) == len(tb)
+    # iteration 0 is the same point on both sides: cost and gradient of the whole problem as the reference assembles it (which
+    # residual blocks, which parameter blocks constant, robust loss, local parameterization) at rounding level
+    assert abs(ta[0]["cost"] - tb[0]["cost"]) <= 1e-13 * tb[0]["cost"], (ta[0]["cost"], tb[0]["cost"])
+    assert abs(ta[0]["gradient_max_norm"] - tb[0]["gradient_max_norm"]) <= 1e-11 * tb[0]["gradient_max_norm"]
+    # later iterates differ by the linear solver (oracle: Schur complement on the inverse depths; mini-Ceres: one dense Cholesky
+    # of the full normal equations, whose entries span 1e30 with the 1e15 gauge prior): ~1e-9 in the states, times the gradient in the cost
+    for a, b in zip(ta, tb):
+        assert (a["step_is_valid"], a["step_is_successful"]) == (b["step_is_valid"], b["step_is_successful"]), (a, b)
+        assert abs(a["cost"] - b["cost"]) <= 1e-6 * abs(b["cost"]) + 1e-12
+        assert abs(a["trust_region_radius"] - b["trust_region_radius"]) <= 1e-6 * b["trust_region_radius"]
+        assert a["mu"] == b["mu"]
+    N16 = 16 * pb.n_frames
+    worst = 0.0
+    for k in range(len(ta)):
+        worst = max(worst, np.abs(sm.trace_states[k, :N16] - rs.trace_states[k, :N16]).max(), np.abs(sm.trace_states[k, N16:] - rs.trace_states[k, N16:N16 + M]).max())
+    assert worst < 5e-8, worst  # bar of north_star: 1e-6 per iteration
+    np.testing.assert_allclose(st.frame_state, fs, atol=5e-8, rtol=0)
+    np.testing.assert_allclose(st.lm_inv_depth, trk.inv_depth[:M], atol=5e-8, rtol=0)
+    np.testing.assert_array_equal(st.lm_valid, trk.valid[:M])
+    ok = st.lm_valid.astype(bool)
+    np.testing.assert_allclose(st.lm_quality[ok], trk.quality[:M][ok], rtol=1e-7, atol=1e-9)
+    print("%s: %d iterations, per-iteration states within %.2e of the reference's solve" % (kind, sm.num_iterations, worst))
+
+
+@pytest.mark.parametrize("kind,victim", [("vio", 0), ("vio", 2), ("vio", 5), ("vio_zero_bias", 0)])
+def test_marginalize_equals_reference(ref, oracle, kind, victim):
+    """marginalize_frame -- bundle_adjustor.cpp:348-599: the information matrix / vector S^T S, S^T s of the new prior (eigenvector
+    signs cancel) and the reprojection error pass (:321-336), after a solve"""
+    pb = _window(kind, oracle)
+    st, sm = BAState(pb), BASummary(pb)
+    oracle.solve(pb, st, sm)
+    Sa, sa, IMa, iva = oracle.marginalize(pb, st, victim)
+    trk, _ = ref.tracks_of_problem(pb, inv_depth=st.lm_inv_depth)
+    Sb, sb, IMb, ivb = ref.marginalize(pb, st.frame_state, trk, victim)
+    e1 = close(Sa.T @ Sa, IMb, rel=1e-9, what="S^T S")
+    e2 = close(Sa.T @ sa, ivb, rel=1e-9, what="S^T s")
+    # rows of S are sqrt(lambda_k) v_k^T: compare up to the sign of every row, after pairing rows by eigenvalue order
+    for k in range(Sa.shape[0]):
+        ra, rb = Sa[k], Sb[k]
+        if np.abs(rb).max() < 1e-9 * np.abs(Sb).max():
+            continue
+        sgn = np.sign(ra @ rb)
+        if abs(ra @ rb) > 0.999 * np.linalg.norm(ra) * np.linalg.norm(rb):  # a simple eigenvalue: same direction
+            np.testing.assert_allclose(sgn * ra, rb, atol=1e-6 * np.abs(Sb).max())
+            assert abs(sgn * sa[k] - sb[k]) <= 1e-6 * max(1.0, np.abs(sb).max())
+    ea = oracle.reprojection_error(pb, st)
+    eb = ref.reprojection_error(pb, st.frame_state, trk)
+    assert abs(ea - eb) <= 1e-12 * eb
+    print("%s victim %d: S^T S %.2e, S^T s %.2e relative; mean reprojection error %.6f px on both" % (kind, victim, e1, e2, eb))
+
+
+def test_post_solve_passes_equal_reference(ref, oracle):
+    """bundle_adjustor.cpp:251-296 inside the reference's own solve(): plane-track re-validation (Track::try_triangulate ->
+    triangulate_point_checked with Eigen's JacobiSVD stand-in, 0.1 m gate, plane erase, re-promotion) and the depth gate / quality
+    pass, against the oracle's solve + oracle_post.cpp on the same track table (12-frame VIO window, two planes of 40 tracks, five
+    tracks per plane 0.3 m off their plane)"""
+    import ba_compare
+    import host_compare
+    pb = ba_compare.make(oracle, n_frames=12, n_landmarks=200, use_inertial=True, plane_fraction=0.4, plane_outliers=5)
+    st, sm = BAState(pb), BASummary(pb)
+    oracle.solve(pb, st, sm)
+    exp = host_compare.flat_tracks(pb, st)
+    t0 = host_compare.flat_tracks(pb, BAState(pb))  # the table BEFORE the solve, for the reference
+    oracle.post_passes(pb, st.frame_state, exp)
+    M = pb.n_landmarks
+    best = np.r_[np.full(M, -1), np.argmax(t0["membership"][:, M:], axis=0)]
+    trk = ref.Tracks(t0["ptr"], t0["frame"], t0["z"], t0["inv_depth"], t0["valid"], t0["plane"], t0["life"], best, t0["normal"], t0["distance"], t0["membership"])
+    fs, trk, rs = ref.solve(pb, tracks=trk)
+    np.testing.assert_allclose(st.frame_state, fs, atol=5e-8, rtol=0)
+    np.testing.assert_array_equal(trk.valid, exp["valid"])
+    np.testing.assert_array_equal(trk.plane, exp["plane"])
+    np.testing.assert_array_equal(trk.membership, exp["membership"])
+    np.testing.assert_allclose(trk.inv_depth, exp["inv_depth"], rtol=1e-6, atol=1e-9)
+    ok = exp["valid"] == 1
+    np.testing.assert_allclose(trk.quality[ok], exp["quality"][ok], rtol=0, atol=1e-6)
+    moved = (exp["plane"][M:] == 0) & (exp["valid"][M:] == 1)
+    assert moved[:5].all() and moved[40:45].all()
+    print("post passes: %d plane tracks re-promoted, %d memberships left, quality within %.1e px" % (
+        moved.sum(), exp["membership"].sum(), np.abs(trk.quality[ok] - exp["quality"][ok]).max()))
+
+
+@pytest.mark.parametrize("use_inertial", [False, True])
+def test_pnp_equals_reference(ref, oracle, use_inertial):
+    """visual_inertial_pnp -- pnp.cpp:32-100 (PoseOnlyReprojectionErrorCost, PreIntegrationPriorCost, mini-Ceres underneath)
+    against oracle_pnp_flat on the same factors"""
+    import test_host_pnp as hp
+    from pvio_amd.problem import BAProblem
+    pb, T, Lf, fac = hp.make_case(use_inertial)
+    x0 = pb.frame_state[T].copy()
+    x0[4:7] += [0.05, -0.04, 0.03]
+    d, tmp = np.zeros(15), np.zeros(16)
+    d[0:3] = [0.02, -0.015, 0.01]
+    oracle.lib().oracle_plus(_d(np.ascontiguousarray(x0)), _d(d), _d(tmp))
+    x0[0:4] = tmp[0:4]
+    xo, ito, tmo, costso = hp.run_flat(hp._OracleAsHost(), pb, T, Lf, fac, use_inertial, x0)
+    # the window without the new frame, every landmark with its observations in frames < T
+    win = BAProblem(T)
+    for name in ("frame_fixed", "cam_extrinsic", "imu_extrinsic", "sqrt_inv_cov", "intrinsics"):
+        setattr(win, name, getattr(pb, name)[:T].copy())
+    win.max_iterations = 10
+    ptr, frame, z, rho, index = [0], [], [], [], {}
+    for l in range(pb.n_landmarks):
+        a = int(pb.lm_anchor_frame[l])
+        if a >= T:
+            continue
+        frame.append(a), z.append(pb.lm_anchor_z[l])
+        for o in range(pb.lm_obs_ptr[l], pb.lm_obs_ptr[l + 1]):
+            if pb.obs_frame[o] < T:
+                frame.append(int(pb.obs_frame[o])), z.append(pb.obs_z[o])
+        index[l] = len(ptr) - 1
+        ptr.append(len(frame)), rho.append(pb.lm_inv_depth[l])
+    nt = len(ptr) - 1
+    trk = ref.Tracks(ptr, frame, np.array(z), np.array(rho), np.ones(nt, np.uint8), np.zeros(nt, np.uint8))
+    obs_track = [index[l] for (l, _, _) in fac]
+    obs_z = np.array([pb.obs_z[o] for (_, _, o) in fac])
+    xr, itr = ref.pnp(win, pb.frame_state[:T], trk, x0, pb.cam_extrinsic[T], pb.imu_extrinsic[T], pb.sqrt_inv_cov[T], pb.intrinsics[T], obs_track, obs_z,
+                      pb.preint_delta[T], pb.preint_sqrt_inv_cov[T], pb.preint_jacobian[T], use_inertial)
+    assert itr == ito, (itr, ito)
+    na = 16 if use_inertial else 7
+    assert np.abs(xr[:na] - xo[:na]).max() < 1e-9, np.abs(xr[:na] - xo[:na]).max()
+    print("pnp (inertial=%s): %d iterations, state within %.2e of the reference" % (use_inertial, itr, np.abs(xr[:na] - xo[:na]).max()))
