@@ -194,10 +194,10 @@ __device__ __forceinline__ void lin_prologue(const View &v, double *lds, Pro *&p
         const double c_g2 = c->pose_g2, c_lm_g2 = c->lm_g2, c_gn2 = c->pose_gn2, c_gdot = c->pose_gdot, c_qvv = c->pose_qvv, c_qvy = c->pose_qvy,
                      c_qyy = c->pose_qyy, c_gy = c->pose_gy;
         // (2) partial sums of the landmark back-substitution (<= 64 rows unless the window is large)
-        double b[6] = {0, 0, 0, 0, 0, 0};
+        double b[7] = {0, 0, 0, 0, 0, 0, 0}; // [6]: pose part of v^T H v when k_backsub forms it (Dims::qvv_back; zero otherwise)
         for (int row = lane; row < v.dm.n_back_rows; row += 64)
 #pragma unroll
-            for (int k = 0; k < 6; ++k) b[k] += v.back_part[row * kNumBackScal + k];
+            for (int k = 0; k < 7; ++k) b[k] += v.back_part[row * kNumBackScal + k];
         // (3) this lane's frame: both state buffers, both step vectors, activity flags, camera / weight records
         double x0[16], x1[16], vs[15], ys[15];
 #pragma unroll
@@ -226,10 +226,10 @@ __device__ __forceinline__ void lin_prologue(const View &v, double *lds, Pro *&p
         if (mode == MODE_CANDIDATE) {
             // ---- DoglegStrategy::ComputeTraditionalDoglegStep on the scalars of the accepted linearization ----
 #pragma unroll
-            for (int k = 0; k < 6; ++k) b[k] = wave_sum(b[k]);
+            for (int k = 0; k < 7; ++k) b[k] = wave_sum(b[k]);
             if (lane == 0) {
                 const double g2 = c_g2 + c_lm_g2, gn2 = c_gn2 + b[0], gdot = c_gdot + b[1];
-                const double qvv = c_qvv + b[2], qvy = c_qvy + b[3], qyy = c_qyy + b[4], gy = c_gy + b[5];
+                const double qvv = (c_qvv + b[6]) + b[2], qvy = c_qvy + b[3], qyy = c_qyy + b[4], gy = c_gy + b[5];
                 const double gradient_norm = sqrt(g2), gauss_newton_norm = sqrt(gn2);
                 const double alpha = g2 / qvv; // |g^|^2 / |J (g^/D)|^2
                 double sn;
@@ -1094,11 +1094,8 @@ __device__ __forceinline__ double reduced_entry_terms(const View &v, double val,
         const double hB = (same && fa + 1 < N && v.pre_valid[fa + 1]) ? v.pre_H[(size_t)(fa + 1) * 900 + ka * 30 + kb] : 0.0;
         val = (fa & 1) ? (val + hA) + hB : (val + hB) + hA;
     }
-    int pa = -1, pb = -1;
-    for (int q = 0; q < v.dm.prior_n; ++q) {
-        const int f = v.prior_frames[q];
-        pa = f == fa ? q : pa, pb = f == fb ? q : pb;
-    }
+    if (v.dm.prior_n <= 0) return val;
+    const int pa = v.prior_slot[fa], pb = v.prior_slot[fb];
     if (pa >= 0 && pb >= 0) val += v.prior_H[(size_t)(15 * pa + ka) * (15 * v.dm.prior_n) + 15 * pb + kb];
     return val;
 }
@@ -1544,23 +1541,26 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
            *tmp = vec + 6 * LDV, *cpl = vec + 7 * LDV;
     double *ysol = rhs; // solution of the reduced system (rhs is dead once the augmented row has been written)
     // Everything the control section reads comes in with one round of parallel loads (a dependent chain of single-thread
-    // global loads costs a trip through the fabric each: the producers ran on other XCDs).
+    // global loads costs a trip through the fabric each: the producers ran on other XCDs).  The values are REQUESTED here and
+    // stored to LDS further down, behind the requests for the tiles: a store waits for its load, and loads retire in order, so
+    // storing first would put a whole trip between these loads and the tile loads (and requesting the tiles first would make
+    // the control inputs wait for 112 KB of tiles).
+    double in_val = 0.0;
     {
         constexpr int nw = (int)(sizeof(Ctrl) / sizeof(double));
         const double *src = reinterpret_cast<const double *>(cg);
-        if (tid < nw) reinterpret_cast<double *>(c)[tid] = src[tid];
+        if (tid < nw) in_val = src[tid];
         else if (tid < 64 + kNumLinScal && tid >= 64) {
             const size_t base = nS + (size_t)kNumPoseVec * P6;
-            double val = v.red[base + (tid - 64)];
+            in_val = v.red[base + (tid - 64)];
             if (tid - 64 == 4 && v.dm.world > 1) { // max |b_l|: one slot per rank behind the scalars (see k_reduce); all >= 0
-                val = 0.0;
-                for (int w = 0; w < v.dm.world; ++w) val = fmax(val, v.red[base + kNumLinScal + w]);
+                in_val = 0.0;
+                for (int w = 0; w < v.dm.world; ++w) in_val = fmax(in_val, v.red[base + kNumLinScal + w]);
             }
-            redS[tid - 64] = val;
         }
-        else if (tid >= 128 && tid < 128 + N) aux_costs[tid - 128] = (tid - 128 >= 1 && v.dm.G_pre && v.pre_valid[tid - 128]) ? v.pre_cost[tid - 128] : 0.0;
-        else if (tid >= 192 && tid < 192 + v.dm.prior_n) aux_costs[N + tid - 192] = v.prior_cost[tid - 192];
-        else if (tid == 255) aux_costs[N + v.dm.prior_n] = v.dm.n_rot > 0 ? v.rot_cost[0] : 0.0;
+        else if (tid >= 128 && tid < 128 + N) in_val = (tid - 128 >= 1 && v.dm.G_pre && v.pre_valid[tid - 128]) ? v.pre_cost[tid - 128] : 0.0;
+        else if (tid >= 192 && tid < 192 + v.dm.prior_n) in_val = v.prior_cost[tid - 192];
+        else if (tid == 255) in_val = v.dm.n_rot > 0 ? v.rot_cost[0] : 0.0;
     }
     // Tile ownership of the register-resident factorization (LDSMAT).  Tile (g, h): g = tile column, h <= g = tile row, both
     // counted from the LAST one.  Rows are dealt to the waves in a zigzag (dense_row_of: rows w, 7 - w, 8 + w -> 15 / 14 / 13 / 13
@@ -1587,6 +1587,7 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
         for (int i = 0; i < kSlots; ++i) raw[i][0][0] = 0.0, raw[i][0][1] = 0.0, raw[i][1][0] = 0.0, raw[i][1][1] = 0.0;
     }
 
+    const bool split = v.dm.split_fin != 0; // gradient max-norm, state / trace copies (and v^T S v: qvv_back) are finished by k_backsub
     PV_STAMP_BEGIN(2);
     PV_STAMP(2, 0);
     // Touch what the assembly reads, one load per 128-byte line: the sources were produced on other XCDs and a first touch
@@ -1596,8 +1597,12 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
     double pf = 0;
     {
         const size_t nR = nS + (size_t)kNumPoseVec * P6 + kNumLinScal;
+        if (from_images) {
+            // (a dozen lines, one per thread, requested behind the tile loads below)
+        } else {
 #pragma unroll 4
-        for (size_t e = (from_images ? nS : 0) + (size_t)tid * 16; e < nR; e += (size_t)nthr * 16) pf += v.red[e];
+            for (size_t e = (size_t)tid * 16; e < nR; e += (size_t)nthr * 16) pf += v.red[e];
+        }
         if (d == 15 && !from_images) {
             if (v.dm.G_pre) {
                 const size_t nH = (size_t)N * 900, nG = (size_t)N * 30;
@@ -1616,20 +1621,52 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
     // static per-frame data of the vector assembly (prior slot, IMU factor present) and both state buffers (the gradient-max
     // pass reads the accepted iterate; which buffer that is, is decided by the control section): staged with the control inputs.
     // Lp is free until the factorization starts (48 N <= 8 LDV doubles).
+    int in_slot = -1, in_valid = 0, in_frame = 0;
     if (tid < N) {
-        int slot = -1;
-        for (int q = 0; q < v.dm.prior_n; ++q)
-            if (v.prior_frames[q] == tid) slot = q;
-        pslot[tid] = slot;
-        pvalid[tid] = (v.dm.G_pre && v.pre_valid[tid]) ? 1 : 0;
-        if (tid < v.dm.prior_n) pframe[tid] = v.prior_frames[tid];
+        in_slot = v.dm.prior_n > 0 ? v.prior_slot[tid] : -1;
+        in_valid = (v.dm.G_pre && v.pre_valid[tid]) ? 1 : 0;
+        if (tid < v.dm.prior_n) in_frame = v.prior_frames[tid];
     }
-    for (int e = tid; e < 32 * N; e += nthr) Lp[e] = v.fs[e];
-    for (int e = tid; e < 16 * N; e += nthr) Lp[32 * N + e] = v.fs_user[e]; // the user state the finalize pass takes the old biases from
     const bool f_pose_active = tid < N ? v.pose_active[tid] != 0 : false, f_motion_active = tid < N ? v.motion_active[tid] != 0 : false;
     // every thread takes the termination flag from its own load: thread 0 may set the LDS copy's `done` in the control
     // section below while slower waves are still on their way to this test
     const int was_done = cg->done;
+    if constexpr (LDSMAT) {
+        // split: with the finalize work off this kernel's critical path nothing is left to cover the latency of the tile loads -- a
+        // trip through the fabric, k_reduce ran on other XCDs -- so they are requested here, behind the control inputs and whatever
+        // the control section will decide (a rejected step wastes 112 KB of L2 traffic; round 2 issued them after the decision,
+        // hidden behind the vector assembly and the finalize pass that no longer run in this kernel)
+        if (split) {
+#pragma unroll
+            for (int i = 0; i < kSlots; ++i)
+                if (from_images && sbk[i] >= 0) {
+                    const double *T = v.img + ((size_t)(((sbi[i] * (sbi[i] + 1)) >> 1) + sbk[i]) << 8) + 4 * lane;
+                    raw[i][0] = *reinterpret_cast<const lds_d2 *>(T);
+                    raw[i][1] = *reinterpret_cast<const lds_d2 *>(T + 2);
+                }
+        }
+    }
+    if (from_images) { // first touch of the pose vectors of `red` (the value is only looked at when the kernel ends: nothing waits for it here)
+        const size_t nR = nS + (size_t)kNumPoseVec * P6 + kNumLinScal;
+        if (nS + (size_t)tid * 16 < nR) pf = v.red[nS + (size_t)tid * 16];
+    }
+    // the control inputs go to LDS (each store waits for its own load only: the tile loads behind it stay in flight)
+    {
+        constexpr int nw = (int)(sizeof(Ctrl) / sizeof(double));
+        if (tid < nw) reinterpret_cast<double *>(c)[tid] = in_val;
+        else if (tid < 64 + kNumLinScal && tid >= 64) redS[tid - 64] = in_val;
+        else if (tid >= 128 && tid < 128 + N) aux_costs[tid - 128] = in_val;
+        else if (tid >= 192 && tid < 192 + v.dm.prior_n) aux_costs[N + tid - 192] = in_val;
+        else if (tid == 255) aux_costs[N + v.dm.prior_n] = in_val;
+        if (tid < N) {
+            pslot[tid] = in_slot, pvalid[tid] = in_valid;
+            if (tid < v.dm.prior_n) pframe[tid] = in_frame;
+        }
+    }
+    if (!split) { // (split: the passes that read these copies run in k_backsub)
+        for (int e = tid; e < 32 * N; e += nthr) Lp[e] = v.fs[e];
+        for (int e = tid; e < 16 * N; e += nthr) Lp[32 * N + e] = v.fs_user[e]; // the user state the finalize pass takes the old biases from
+    }
     __syncthreads(); // the staged control inputs are in LDS (global loads stay in flight across the barrier)
     if (was_done) return; // nothing was modified
     // ---------------- unscaled vectors, part 1: diag(J^T J), gradient, Schur rhs of coordinate a = tid ----------------
@@ -1758,7 +1795,7 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
         // Gauss-Newton step: three launches in ten at 10 x 1000 would pull the 112 KB image through this CU for nothing): their
         // latency -- a trip through the fabric, k_reduce ran on other XCDs -- is covered by the vector assembly, the finalize
         // pass and the scaling below.
-        if (need_build) {
+        if (need_build && !split) {
 #pragma unroll
             for (int i = 0; i < kSlots; ++i)
                 if (from_images && sbk[i] >= 0) {
@@ -1769,7 +1806,14 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
         }
     }
     // ---------------- unscaled vectors, part 2 ----------------
-    if (need_build) {
+    if (need_build && split) {
+        // every thread only ever reads back the entries it writes here (the scaling loop below walks a = tid): no barrier.  The
+        // gradient max-norm of an accepted linearization is formed by k_backsub's finalize workgroup from the copy in HBM.
+        if (tid < P) {
+            diagH[tid] = as_dg, gtot[tid] = as_g, rhs[tid] = as_r, act[tid] = as_act;
+            if (sh.accepted) v.gtot[tid] = as_g;
+        }
+    } else if (need_build) {
         if (tid < P) diagH[tid] = as_dg, gtot[tid] = as_g, rhs[tid] = as_r, act[tid] = as_act;
         __syncthreads();
         // gradient_max_norm = max | x - (x (+) -g) | over the free blocks (ambient coordinates)
@@ -1796,10 +1840,17 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
     if (tid == 0 && sh.do_trace) {
         const int lr = c->lin_result;
         if (c->it_success) c->num_success++;
-        sh.trace_slot = record_trace(v, c, c->iter);
+        sh.trace_slot = record_trace(v, c, c->iter); // (split + accepted: gradient_max_norm is patched in by k_backsub's finalize workgroup)
+        if (split) {
+            c->fin_flags = kFinTrace | (sh.accepted ? kFinAccepted : 0) | (sh.first ? kFinFirst : 0);
+            c->fin_trace_slot = sh.trace_slot;
+            c->fin_lm_gmax = redS[4];
+        }
         bool stop = false;
         if (c->iter >= v.dm.max_iter) c->termination = 1, stop = true;                           // MaxSolverIterationsReached
-        else if (c->it_success && c->grad_max <= 1e-10) c->termination = 0, stop = true;         // GradientToleranceReached
+        // (split: the gradient of a linearization accepted in THIS launch is not known here -- the finalize workgroup applies the test
+        // and takes the iteration back; a rejected step keeps the old gradient, whose test did not fire when it was accepted)
+        else if (!(split && sh.accepted) && c->it_success && c->grad_max <= 1e-10) c->termination = 0, stop = true; // GradientToleranceReached
         else if (c->radius <= 1e-32) c->termination = 0, stop = true;                            // MinTrustRegionRadiusReached
         if (stop) {
             c->done = 1;
@@ -1813,7 +1864,7 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
     }
     __syncthreads();
     // trace states + StateUpdatingCallback (update_state_every_iteration): user state <- accepted iterate
-    if (sh.do_trace) {
+    if (sh.do_trace && !split) {
         const int cur = c->cur;
         if (sh.accepted && !sh.first) {
             // the accepted linearization was evaluated with the OLD user biases: keep them for a later RELIN
@@ -1974,17 +2025,25 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
                     // the real rows: one formula for every entry, the structural entries are patched below
                     double val[4] = {raw[i][0][0], raw[i][0][1], raw[i][1][0], raw[i][1][1]};
                     const double vk2 = 2.0 * ck[1];
+                    if (v.dm.qvv_back) { // v^T S v comes from k_backsub (same image, C v from HBM): scaling only
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const lds_d2 ci = rowop[kSlotQ[i]][r];
-                        val[r] *= ci[0] * ck[0];
-                        q += val[r] * (ci[1] * vk2);
+                        for (int r = 0; r < 4; ++r) val[r] *= rowop[kSlotQ[i]][r][0] * ck[0];
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const lds_d2 ci = rowop[kSlotQ[i]][r];
+                            val[r] *= ci[0] * ck[0];
+                            q += val[r] * (ci[1] * vk2);
+                        }
                     }
                     if (bi == bk) { // diagonal tile: its diagonal counts once in v^T S v; unit / mu D^2 diagonal
                         const double dgk = dgv[16 * bk + lr];
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            if (lk + 4 * r == lr) q -= val[r] * (rowop[kSlotQ[i]][r][1] * ck[1]), val[r] += dgk;
+                            if (lk + 4 * r == lr) {
+                                if (!v.dm.qvv_back) q -= val[r] * (rowop[kSlotQ[i]][r][1] * ck[1]);
+                                val[r] += dgk;
+                            }
                     }
                     if (bi == brow) { // the scaled rhs in row Pp
                         const double rk = diagH[16 * bk + lr];
@@ -1997,9 +2056,13 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
                 }
             }
             PV_STAMPV(2, 22, q);
-            double s1[1] = {q};
-            block_sum<1>(s1, red_scratch);
-            if (tid == 0) c->pose_qvv = s1[0];
+            if (v.dm.qvv_back) {
+                if (tid == 0) c->pose_qvv = 0.0; // the whole v^T S v arrives through back_part[.][6]
+            } else {
+                double s1[1] = {q};
+                block_sum<1>(s1, red_scratch);
+                if (tid == 0) c->pose_qvv = s1[0];
+            }
             PV_STAMP(2, 23);
         }
         // columns [o2, o2 + 8) of slot i's tile -> Xs (row-major, 8 per row; still negated)
@@ -2107,12 +2170,15 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
                     hq[q] = dense_row_of(wv, q);
                     opA[q] = *reinterpret_cast<const lds_d2 *>(Lpan + 128 * (hq[q] < R ? nbk - 1 - hq[q] : b0));
                 }
-                // (ascending on purpose.  Requesting the operand of the column that is updated first, g = R - 1, first -- a descending
-                // loop -- compiled to code whose results were WRONG on the GPU while the emulated kernels passed: tests/test_gpu_ba.py
-                // caught it, the cause in the generated code was not found; measured gain of that order: none.)
+                // Every column's operand is requested UNCONDITIONALLY (dead columns read row block b0 like dead rows do).  Round 2 had
+                // eleven uniform `if (g < R)` branches around these loads; with them, the DEscending request order compiled to a
+                // k_dense whose results were wrong on the GPU (emulator fine).  Round 3 characterized it (DESIGN.md section 4,
+                // tests/micro/order_probe.py, profiles/r3_kdense_order_probe_*.txt): deterministic, independent of LDS / register
+                // contents, gone when SGPRs spill to scratch instead of VGPR lanes and gone -- in BOTH orders -- without the
+                // branches.  The branch-free form is what ships; it also drops eleven scalar branches per panel.
 #pragma unroll
                 for (int g = 0; g < kDenseCols; ++g)
-                    if (g < R) opB[g] = *reinterpret_cast<const lds_d2 *>(Lpan + 128 * (nbk - 1 - g)); // live columns only
+                    opB[g] = *reinterpret_cast<const lds_d2 *>(Lpan + 128 * (g < R ? nbk - 1 - g : b0));
                 // a column's slots, unconditionally: a slot that holds no tile of this wave (its q-th row lies outside the column)
                 // costs two MFMAs on registers nobody reads -- cheaper than a uniform branch per slot, which splits the MFMA
                 // sequence into basic blocks (measured: 54.4 against 49.7 us)
@@ -2567,6 +2633,82 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
 }
 
 // ------------------------------------------------------------------------------------------------------
+// split finalize (Dims::split_fin): the part of Ceres' FinalizeIterationAndCheckIfMinimizerCanContinue that does not decide what
+// k_dense factors -- run by one extra workgroup of k_backsub, beside the landmark back-substitution instead of in front of the
+// factorization: the gradient max-norm of the linearization just accepted (patched into the iteration's trace record; the
+// gradient-tolerance exit takes the iteration k_dense has started back), the state-updating callback's copies
+// (update_state_every_iteration: user state <- accepted iterate, the biases the linearization was evaluated with) and the trace
+// states.  Runs whenever k_dense left fin_flags set, also on the last launch of a solve.
+// ------------------------------------------------------------------------------------------------------
+__device__ void backsub_finalize(const View &v) {
+    Ctrl *c = v.ctrl;
+    const int N = v.dm.N, d = v.dm.d, tid = threadIdx.x, nthr = blockDim.x;
+    // one round of loads, whatever the flags turn out to be (every dependent round is a trip through the fabric, and this workgroup
+    // must not outlast the landmark workgroups beside it): control fields, and per frame thread the gradient, both state buffers
+    // and the user state's biases
+    const int flags = c->fin_flags, cur = c->cur, slot = c->fin_trace_slot, was_done = c->done;
+    const double lm_gmax = c->fin_lm_gmax;
+    const int f = tid < N ? tid : 0;
+    double g[15], x0[16], x1[16], ub[6];
+#pragma unroll
+    for (int k = 0; k < 15; ++k) g[k] = k < d ? v.gtot[d * f + k] : 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x0[k] = v.fs[(size_t)f * 16 + k], x1[k] = v.fs[((size_t)N + f) * 16 + k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) ub[k] = v.fs_user[(size_t)f * 16 + 10 + k];
+    const bool p_act = v.pose_active[f] != 0, m_act = v.motion_active[f] != 0;
+#ifdef PV_DEBUG_FIN
+    if (threadIdx.x == 0) printf("fin: flags %d slot %d cur %d done %d ts %p\n", flags, slot, cur, was_done, (void *)v.trace_states);
+#endif
+    if (!flags) return; // uniform
+    const bool accepted = (flags & kFinAccepted) != 0, first = (flags & kFinFirst) != 0;
+    double x[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x[k] = cur ? x1[k] : x0[k];
+    if (accepted) {
+        // gradient_max_norm = max | x - (x (+) -g) | over the free blocks (ambient coordinates)
+        double gm = 0;
+        if (tid < N) {
+            if (p_act) {
+                double ng[6], y[7];
+                for (int k = 0; k < 6; ++k) ng[k] = -g[k];
+                pose_plus(y, x, ng, ng + 3);
+                for (int k = 0; k < 7; ++k) gm = fmax(gm, fabs(x[k] - y[k]));
+            }
+            if (d == 15 && m_act)
+                for (int k = 0; k < 9; ++k) gm = fmax(gm, fabs(g[6 + k]));
+        }
+        if (tid < 64) {
+            gm = wave_max(gm); // N <= 32 < 64: wave 0 holds every frame
+            if (tid == 0) {
+                const double gmax = fmax(gm, lm_gmax);
+                c->grad_max = gmax;
+                if (slot >= 0) v.trace[slot].gradient_max_norm = gmax;
+                if (!was_done && gmax <= 1e-10) { // GradientToleranceReached: the iteration k_dense has started does not happen
+                    c->termination = 0, c->done = 1, c->mode = MODE_DONE, c->iter = c->iter - 1;
+                }
+            }
+        }
+        // StateUpdatingCallback (update_state_every_iteration), one frame per thread: user state <- accepted iterate.  The accepted
+        // linearization was evaluated with the OLD user biases: kept for a later RELIN (the first one with the initial state's own)
+        if (tid < N) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) v.bias0_lin[(size_t)tid * 6 + k] = first ? x[10 + k] : ub[k];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) v.fs_user[(size_t)tid * 16 + k] = x[k];
+        }
+    }
+    if (v.trace_states && slot >= 0) {
+        double *dst = v.trace_states + (size_t)slot * (N * 16 + v.dm.M);
+        if (tid < N)
+            for (int k = 0; k < 16; ++k) dst[(size_t)tid * 16 + k] = x[k];
+        for (int e = tid; e < v.dm.M; e += nthr) dst[N * 16 + e] = v.rho[(size_t)cur * v.dm.M + e];
+    }
+    __syncthreads(); // every thread has read the flags (and the control fields above) before they are cleared
+    if (tid == 0) c->fin_flags = 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
 // k_backsub: landmark back-substitution + landmark parts of the dogleg scalars; <= 64 WGs, one row each
 // ------------------------------------------------------------------------------------------------------
 // Sixteen lanes (one DPP row) per landmark: lane `sub` takes observations sub, sub + 16, ... so that the dependent
@@ -2580,9 +2722,13 @@ __global__ void __launch_bounds__(256) k_backsub(View v) {
     // round 2 = everything addressed by `lin` / the CSR offsets, including the per-landmark scalars of the lanes that
     // finish a landmark (requested before the sums they are combined with, not after).
     const Ctrl *c = v.ctrl;
+    if (v.dm.split_fin && (int)blockIdx.x == v.dm.G_back) { // the extra workgroup: what k_dense left to be finished (uniform)
+        backsub_finalize(v);
+        return;
+    }
     const int done = c->done, solve_ok = c->solve_ok, lin = c->lin;
     const double mu = c->mu;
-    __shared__ double scratch[6 * 16];
+    __shared__ double scratch[7 * 16];
     __shared__ double stepv[kMaxFrames * 15], stepy[kMaxFrames * 15];
     const int M = v.dm.M, d = v.dm.d, P = v.dm.P;
     const size_t Ms = (size_t)M, Fs = (size_t)v.dm.F;
@@ -2591,17 +2737,34 @@ __global__ void __launch_bounds__(256) k_backsub(View v) {
     const int lc_first = l_first < M ? l_first : M - 1;
     int o0n = v.lm_ptr[lc_first], o1n = v.lm_ptr[lc_first + 1], an = v.lm_anchor[lc_first];
     for (int e = threadIdx.x; e < P; e += blockDim.x) stepv[e] = v.vstep[e], stepy[e] = v.ystep[e];
+    // qvv_back: this workgroup's tiles of the reduced system's image (written by k_reduce, loaded by k_dense) for the pose part of
+    // v^T H v = (C v)^T H (C v): thread = one entry of a tile (MFMA accumulator order: entry e of lane e >> 2, r = e & 3)
+    const int n_lm_wg = v.dm.split_fin ? v.dm.G_back : (int)gridDim.x; // landmark workgroups (the finalize workgroup is not one)
+    double himg = 0;
+    int hi = 0, hk = 0;
+    const int n_img_tiles = v.dm.qvv_back ? v.dm.img_sz >> 8 : 0;
+    const int my_tile = (int)blockIdx.x;
+    if (my_tile < n_img_tiles) himg = v.img[((size_t)my_tile << 8) + threadIdx.x];
     if (done || !solve_ok) return; // uniform (the loads above were only issued)
     __syncthreads();
-    double s[6] = {0, 0, 0, 0, 0, 0};
-    for (int l0 = blockIdx.x * per_block; l0 < M; l0 += gridDim.x * per_block) { // uniform trip count per block
+    double s[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (int t = my_tile; t < n_img_tiles; t += n_lm_wg) {
+        if (t != my_tile) himg = v.img[((size_t)t << 8) + threadIdx.x];
+        int bi = (int)((sqrtf(8.0f * t + 1.0f) - 1.0f) * 0.5f);
+        while (((bi + 1) * (bi + 2)) >> 1 <= t) ++bi;
+        while (((bi * (bi + 1)) >> 1) > t) --bi;
+        const int bk = t - ((bi * (bi + 1)) >> 1), ln = threadIdx.x >> 2, r = threadIdx.x & 3;
+        hi = 16 * bi + (ln >> 4) + 4 * r, hk = 16 * bk + (ln & 15);
+        if (hi < P && hk <= hi) s[6] += (hi == hk ? himg : 2.0 * himg) * stepv[hi] * stepv[hk]; // the image is the lower triangle
+    }
+    for (int l0 = blockIdx.x * per_block; l0 < M; l0 += n_lm_wg * per_block) { // uniform trip count per block
         const int l = l0 + (threadIdx.x >> 4);
         const bool in = l < M;
         const int lc = in ? l : M - 1;
         const int o0 = o0n, o1 = o1n, a = an;
         {   // CSR entries of this thread's next landmark (large windows: several per thread)
-            const int ln = l + gridDim.x * per_block, lcn = ln < M ? ln : M - 1;
-            if (l0 + gridDim.x * per_block < M) o0n = v.lm_ptr[lcn], o1n = v.lm_ptr[lcn + 1], an = v.lm_anchor[lcn];
+            const int ln = l + n_lm_wg * per_block, lcn = ln < M ? ln : M - 1;
+            if (l0 + n_lm_wg * per_block < M) o0n = v.lm_ptr[lcn], o1n = v.lm_ptr[lcn + 1], an = v.lm_anchor[lcn];
         }
         const double *Wa = v.Wa + lin * Ms * 6, *Wt = v.Wt + lin * Fs * 6;
         const bool fin = sub == 0 && in && o1 != o0; // this lane finishes the landmark
@@ -2647,11 +2810,11 @@ __global__ void __launch_bounds__(256) k_backsub(View v) {
         }
     }
     if (done || !solve_ok) return;
-    block_sum<6>(s, scratch);
+    block_sum<7>(s, scratch);
     if (threadIdx.x == 0) {
         double *row = v.back_part + (size_t)blockIdx.x * kNumBackScal;
-        for (int k = 0; k < 6; ++k) row[k] = s[k];
-        row[6] = row[7] = 0;
+        for (int k = 0; k < 7; ++k) row[k] = s[k];
+        row[7] = 0;
     }
 }
 
@@ -2844,7 +3007,7 @@ hipError_t launch_dense(const View &v, hipStream_t st) {
 }
 
 hipError_t launch_backsub(const View &v, hipStream_t st) {
-    hipLaunchKernelGGL(k_backsub, dim3(v.dm.G_back), dim3(256), 0, st, v);
+    hipLaunchKernelGGL(k_backsub, dim3(v.dm.G_back + (v.dm.split_fin ? 1 : 0)), dim3(256), 0, st, v);
     return hipGetLastError();
 }
 hipError_t launch_back_reduce(const View &v, double *back_local, hipStream_t st) {

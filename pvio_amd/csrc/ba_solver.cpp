@@ -166,10 +166,12 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st) {
                 pre_valid[j] = 1;
                 pose_used[j - 1] = pose_used[j] = motion_used[j - 1] = motion_used[j] = 1;
             }
+    std::vector<int32_t> prior_slot(N, -1); // frame -> slot of the prior (the last one that names it, like the kernels' old search)
     for (int i = 0; i < dm.prior_n; ++i) {
         const int f = pb->prior_frames[i];
         if (f < 0 || f >= N) return fail(PVIO_ERR_INVALID_ARGUMENT, "prior frame out of range");
         pose_used[f] = motion_used[f] = 1;
+        prior_slot[f] = i;
     }
     // rotation priors: at most one per frame; one on a fixed frame is a constant block and is dropped
     std::vector<int32_t> rot_slot(N, -1);
@@ -243,7 +245,9 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st) {
     // 16 landmarks per workgroup pass (16 lanes each); <= 64 partial rows (one per lane of the wave that sums them) until a
     // large window needs the whole chip
     dm.G_back = M <= 4096 ? std::max(1, std::min(64, (M + 15) / 16)) : std::min(cus, (M + 63) / 64);
-    dm.fuse_backsub = (!sharded_ && M <= 256) ? 1 : 0; // beyond one landmark per thread the separate launch is faster
+    // (PVIO_HIP_FUSE_BACKSUB=0: tests -- small windows through the separate k_backsub launch, i.e. the split-finalize form)
+    static const bool fuse_off = std::getenv("PVIO_HIP_FUSE_BACKSUB") != nullptr && std::atoi(std::getenv("PVIO_HIP_FUSE_BACKSUB")) == 0;
+    dm.fuse_backsub = (!sharded_ && M <= 256 && !fuse_off) ? 1 : 0; // beyond one landmark per thread the separate launch is faster
     dm.n_back_rows = (sharded_ || dm.fuse_backsub) ? 1 : dm.G_back;
 
     // 3x3 tile tasks over the upper block triangle
@@ -297,6 +301,7 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st) {
     stage.add(pb->plane_distance, (size_t)dm.n_plane, &v.plane_dist);
     v.plane_sic = pb->plane_sqrt_inv_cov;
     stage.add(rot_slot.data(), Ns, &v.rot_slot);
+    stage.add(prior_slot.data(), Ns, &v.prior_slot);
     stage.add(pb->rot_prior_q0, (size_t)dm.n_rot * 4, &v.rot_q0);
     stage.add(pb->rot_prior_sqrt_info, (size_t)dm.n_rot * 9, &v.rot_W);
     // state + work
@@ -345,6 +350,13 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st) {
         v.dm.use_img = 1; // (landmark-sharded runs build it from the all-reduced `red`: k_reduce phase 2)
         v.dm.img_sz = (int)img_sz;
         dm.use_img = v.dm.use_img, dm.img_sz = v.dm.img_sz;
+        // split finalize: with a separate k_backsub launch on one GPU, k_dense leaves the gradient max-norm, the state / trace copies
+        // and (register-resident factorization: the image is what it factors) the pose part of v^T H v to that launch.
+        // PVIO_HIP_SPLIT_FIN=0 keeps everything in k_dense (A/B timing, tests of both forms).
+        static const bool split_off = std::getenv("PVIO_HIP_SPLIT_FIN") != nullptr && std::atoi(std::getenv("PVIO_HIP_SPLIT_FIN")) == 0;
+        dm.split_fin = (!sharded_ && !dm.fuse_backsub && !split_off) ? 1 : 0;
+        dm.qvv_back = (dm.split_fin && dm.use_img && lds_matrix) ? 1 : 0;
+        v.dm.split_fin = dm.split_fin, v.dm.qvv_back = dm.qvv_back;
         ok &= dev(pool_, "img", img_sz, &v.img, &grew);
         if (ok && v.dm.use_img && check(hipMemsetAsync(v.img, 0, img_sz * sizeof(double), stream_), "memset img")) return PVIO_ERR_HIP;
     }

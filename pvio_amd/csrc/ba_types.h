@@ -66,7 +66,14 @@ struct Ctrl {
     double it_cost, it_cost_change, it_step_norm, it_rel;
     int32_t it_valid, it_success;
     int32_t dbg_fail_left, dbg_invalid_left; // fault injection (pvio_hip_opts::debug_*), counted down by k_dense
+    // split finalize (Dims::split_fin): what k_dense leaves for the extra workgroup of k_backsub to finish, off the critical path
+    // -- the gradient max-norm of the linearization just accepted (trace record, gradient-tolerance exit), the state-updating
+    // callback's copies and the trace states
+    int32_t fin_flags;       // kFinTrace | kFinAccepted | kFinFirst; 0 = nothing pending
+    int32_t fin_trace_slot;  // trace record of the iteration (or -1)
+    double fin_lm_gmax;      // max |b_l| of the accepted linearization (landmark part of the gradient max-norm)
 };
+enum : int32_t { kFinTrace = 1, kFinAccepted = 2, kFinFirst = 4 };
 
 struct Dims {
     int32_t N, M, F;
@@ -88,6 +95,9 @@ struct Dims {
     int32_t use_img;      // k_reduce also assembles the reduced system as a tile image the dense kernel loads straight into registers
     int32_t img_sz;       // doubles in the image (tiles * 256)
     int32_t n_rot;        // rotation priors (RotationPriorFactor, no reference counterpart): evaluated by workgroup 0 of k_linearize
+    int32_t split_fin;    // single GPU, separate k_backsub launch: k_dense defers the gradient max-norm, the state / trace copies and
+                          // (qvv_back) the pose part of v^T H v to k_backsub, where they run beside the landmark back-substitution
+    int32_t qvv_back;     // v^T S v from the tile image in k_backsub (partials in back_part[.][6]) instead of k_dense
     int32_t lm_mm;        // landmark workgroups accumulate the Schur complement as 16x16 f64 MFMA tiles and walk a contiguous chunk range
 };
 
@@ -106,6 +116,7 @@ struct View { // passed by value to every kernel
     const uint8_t *pre_valid;     // [N]
     const double *pre_delta, *pre_U, *pre_jac;
     const int32_t *prior_frames;
+    const int32_t *prior_slot;    // [N] slot of the frame in the prior or -1
     const double *prior_S, *prior_s, *prior_lin, *prior_Lambda, *prior_eta, *prior_ST; // Lambda = S^T S, eta = S^T s, ST = S^T
     const int32_t *plane_ptr, *plane_frame, *plane_chunk; // CSR + chunk ranges
     const double *plane_z, *plane_normal, *plane_dist;

@@ -1,0 +1,54 @@
+"""Builds a VARIANT of libpvio_hip.so for same-box experiments (tests/prof_ab.py, tests/micro/order_probe.py): ba_kernels.hip with a
+list of textual substitutions applied, compiled with optional extra flags, linked with the product's other objects.
+usage: python tests/micro/build_variant.py NAME [--flag=...]* [--sub OLD NEW]* [--patch file.py]
+The output tests/micro/variants/NAME.so is git-ignored (it travels to the GPU box with the snapshot)."""
+import os, subprocess, sys, tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+CSRC = os.path.join(ROOT, "pvio_amd", "csrc")
+OUT = os.path.join(ROOT, "tests", "micro", "variants")
+
+
+def build(name, subs=(), flags=(), defines=()):
+    src = open(os.path.join(CSRC, "ba_kernels.hip")).read()
+    for old, new in subs:
+        assert src.count(old) == 1, "substitution target must occur exactly once: %r (%d)" % (old[:60], src.count(old))
+        src = src.replace(old, new)
+    os.makedirs(OUT, exist_ok=True)
+    with tempfile.TemporaryDirectory() as td:
+        p = os.path.join(td, "ba_kernels.hip")
+        open(p, "w").write(src)
+        obj = os.path.join(td, "ba_kernels.o")
+        cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function", "-Wno-unused-variable",
+               "-Wno-unused-but-set-variable", "-I" + CSRC, "-I" + os.path.join(ROOT, "include")] + list(flags) + ["-D" + d for d in defines] + ["-c", p, "-o", obj]
+        subprocess.check_call(cmd)
+        others = [os.path.join(CSRC, o) for o in ("klt.o", "ba_solver.o", "ba_comm.o", "capi.o", "preintegrator.o")]
+        out = os.path.join(OUT, name + ".so")
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-shared", "-fPIC", "--offload-arch=gfx950", "-o", out, obj] + others +
+                              ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"])
+    return out
+
+
+# the operand request of k_dense's rank-8 update as shipped (round 3: unconditional) and the round-2 forms it replaced
+OPB_SHIPPED = """                for (int g = 0; g < kDenseCols; ++g)
+                    opB[g] = *reinterpret_cast<const lds_d2 *>(Lpan + 128 * (g < R ? nbk - 1 - g : b0));"""
+OPB_R2_ASC = """                for (int g = 0; g < kDenseCols; ++g)
+                    if (g < R) opB[g] = *reinterpret_cast<const lds_d2 *>(Lpan + 128 * (nbk - 1 - g)); // live columns only"""
+OPB_R2_DESC = """                for (int g = kDenseCols - 1; g >= 0; --g)
+                    if (g < R) opB[g] = *reinterpret_cast<const lds_d2 *>(Lpan + 128 * (nbk - 1 - g)); // live columns only"""
+OPB_DESC_UNCOND = """                for (int g = kDenseCols - 1; g >= 0; --g)
+                    opB[g] = *reinterpret_cast<const lds_d2 *>(Lpan + 128 * (g < R ? nbk - 1 - g : b0));"""
+
+RECIPES = {
+    "shipped": dict(),
+    "r2_asc": dict(subs=[(OPB_SHIPPED, OPB_R2_ASC)]),                      # round 2's product: passes
+    "desc": dict(subs=[(OPB_SHIPPED, OPB_R2_DESC)]),                       # THE REPRODUCER: wrong results on the GPU
+    "desc_nospill": dict(subs=[(OPB_SHIPPED, OPB_R2_DESC)], flags=["-mllvm", "-amdgpu-spill-sgpr-to-vgpr=false"]),  # passes
+    "desc_wc0": dict(subs=[(OPB_SHIPPED, OPB_R2_DESC)], flags=["-mllvm", "-amdgpu-waitcnt-forcezero=1"]),           # fails, same numbers
+    "desc_mfmapad": dict(subs=[(OPB_SHIPPED, OPB_R2_DESC)], flags=["-mllvm", "-amdgpu-mfma-padding-ratio=100"]),    # fails, same numbers
+    "desc_uncond": dict(subs=[(OPB_SHIPPED, OPB_DESC_UNCOND)]),            # passes
+}
+
+if __name__ == "__main__":
+    for n in sys.argv[1:]:
+        print(build(n, **RECIPES[n]))
