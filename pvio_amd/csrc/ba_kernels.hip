@@ -24,6 +24,7 @@
 // solver_options.h:26-33); factor math in pv_factors.h.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <type_traits>
 
 #include <float.h>
 
@@ -1504,12 +1505,60 @@ __device__ constexpr int kColSlot[12] = {0, 1, 2, 3, 4, 6, 8, 10, 12, 15, 18, 21
 
 // q-th tile row (from the end) of wave w: 0..3 forwards, 4..7 backwards, 8..10 forwards again
 __device__ __forceinline__ int dense_row_of(int w, int q) { return q == 0 ? w : (q == 1 ? 7 - w : 8 + w); }
+// LOOK-AHEAD form of the register-resident factorization (template parameter LA): wave 0 owns no tiles and runs one panel AHEAD --
+// it factors the 8 x 8 diagonal block of panel p + 1 and turns the rows of that panel into L while waves 1..3 apply panel p to
+// the tiles; the two sides meet through two counters in LDS instead of two workgroup barriers per panel.  The tile rows
+// (counted from the last one) are dealt to the three update waves 0,5,6 / 1,4,7,10 / 2,3,8,9 (19 / 18 / 18 tiles at P = 150);
+// column g has max over the waves of #{rows <= g} slots: 1 1 1 2 2 2 3 3 3 4 4 = 26 slots (208 accumulator registers).
+__device__ constexpr int kLaSlotCol[26] = {0, 1, 2, 3, 3, 4, 4, 5, 5, 6, 6, 6, 7, 7, 7, 8, 8, 8, 9, 9, 9, 9, 10, 10, 10, 10};
+__device__ constexpr int kLaSlotQ[26] = {0, 0, 0, 0, 1, 0, 1, 0, 1, 0, 1, 2, 0, 1, 2, 0, 1, 2, 0, 1, 2, 3, 0, 1, 2, 3};
+__device__ constexpr int kLaColSlot[12] = {0, 1, 2, 3, 5, 7, 9, 12, 15, 18, 22, 26};
+__device__ __forceinline__ int dense_la_row_of(int w, int q) { // w = wave index (0 = the factoring wave: no rows)
+    return w == 1 ? (q == 0 ? 0 : (q == 1 ? 5 : (q == 2 ? 6 : 99)))
+                  : (w == 2 ? (q == 0 ? 1 : (q == 1 ? 4 : (q == 2 ? 7 : 10))) : (w == 3 ? (q == 0 ? 2 : (q == 1 ? 3 : (q == 2 ? 8 : 9))) : 99));
+}
+template <bool LA> __device__ __forceinline__ constexpr int dt_slots() { return LA ? 26 : 21; }
+template <bool LA> __device__ __forceinline__ constexpr int dt_nq() { return LA ? 4 : 3; }
+template <bool LA> __device__ __forceinline__ constexpr int dt_slot_col(int i) { return LA ? kLaSlotCol[i] : kSlotCol[i < 21 ? i : 0]; }
+template <bool LA> __device__ __forceinline__ constexpr int dt_slot_q(int i) { return LA ? kLaSlotQ[i] : kSlotQ[i < 21 ? i : 0]; }
+template <bool LA> __device__ __forceinline__ constexpr int dt_col_slot(int g) { return LA ? kLaColSlot[g] : kColSlot[g]; }
+template <bool LA> __device__ __forceinline__ int dt_row_of(int w, int q) { return LA ? dense_la_row_of(w, q) : (q < 3 ? dense_row_of(w, q) : 99); }
+// the two LDS counters of the look-ahead form: acquire loads / release stores at workgroup scope (what has been written to LDS
+// before a counter moves is visible to the wave that sees it move)
+__device__ __forceinline__ int dense_wait(int *flag, int target) { // spin until the counter reaches `target` (or goes negative: failed pivot)
+    int val;
+#ifdef PV_HIPEMU
+    while ((val = *reinterpret_cast<volatile int *>(flag)) >= 0 && val < target) hipemu::spin_yield();
+#else
+    while ((val = __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) >= 0 && val < target) __builtin_amdgcn_s_sleep(1);
+#endif
+    return val;
+}
+// (called by a whole wave: lane 0 moves the counter.  On the GPU the lanes of a wave run in lockstep, so everything the wave has
+// stored before is covered by the release; the fiber emulator runs the lanes one after another and needs them to meet first)
+__device__ __forceinline__ void dense_signal_set(int *flag, int val) {
+#ifdef PV_HIPEMU
+    (void)__shfl(0, 0);
+    if ((threadIdx.x & 63) == 0) *reinterpret_cast<volatile int *>(flag) = val;
+#else
+    if ((threadIdx.x & 63) == 0) __hip_atomic_store(flag, val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+}
+__device__ __forceinline__ void dense_signal_add(int *flag) {
+#ifdef PV_HIPEMU
+    (void)__shfl(0, 0);
+    if ((threadIdx.x & 63) == 0) *reinterpret_cast<volatile int *>(flag) = *reinterpret_cast<volatile int *>(flag) + 1;
+#else
+    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+}
 
 // compile-time storage choice: a runtime LDS-or-global pointer select degrades every access to FLAT.  The register-resident
 // form runs one wave per SIMD (its tiles live in the accumulators of exactly four waves); the HBM form runs two: its sweeps
 // and passes over the matrix wait on L2 round trips that a second wave fills.
-template <bool LDSMAT>
+template <bool LDSMAT, bool LA>
 __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_dense(View v) {
+    static_assert(LDSMAT || !LA, "the look-ahead form is a form of the register-resident factorization");
     // 256 threads = one wave per SIMD: the redundant 8 x 8 block factorization then costs each SIMD exactly once
     HIP_DYNAMIC_SHARED(double, lds)
     Ctrl *const cg = v.ctrl;
@@ -1570,7 +1619,8 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
     // per column whatever the wave: a wave with fewer rows in a column leaves a slot unused).  Only the offset nbk - 1 and
     // the wave index are runtime values, so the rank-8 update addresses accumulators and operands statically: one A operand
     // per q (3 per wave), one B operand per column, no per-slot address arithmetic, selects or slot-list branches.
-    constexpr int kSlots = LDSMAT ? 21 : 1; // sum over g < 11 of ceil((g + 1) / 4): LDV <= 176
+    constexpr int kSlots = LDSMAT ? dt_slots<LA>() : 1; // sum over g < 11 of ceil((g + 1) / 4): LDV <= 176 (look-ahead form: 26)
+    constexpr int kNQ = dt_nq<LA>();                      // tile rows a wave can own
     const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 15, lk = lane >> 4;
     const bool from_images = LDSMAT && v.dm.use_img; // the reduced system arrives as a tile image: loaded straight into registers
     int sbi[kSlots], sbk[kSlots];
@@ -1578,7 +1628,7 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
     if constexpr (LDSMAT) {
 #pragma unroll
         for (int i = 0; i < kSlots; ++i) {
-            const int g = kSlotCol[i], h = dense_row_of(wv, kSlotQ[i]);
+            const int g = dt_slot_col<LA>(i), h = dt_row_of<LA>(wv, dt_slot_q<LA>(i));
             const bool valid = g < nbk && h <= g;
             sbk[i] = valid ? nbk - 1 - g : -1;
             sbi[i] = valid ? nbk - 1 - h : 0;
@@ -2003,15 +2053,15 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
             // the {scale, v} pairs: a tile needs the pair of its column (one per lane) and of its four rows.  With the static
             // slot table they depend on the tile column g and on the wave's row index qq only: 11 + 3 * 4 reads for all 21
             // slots instead of five per slot (rows / columns outside the system read tile row / column 0: in range, never used)
-            lds_d2 colop[kDenseCols], rowop[3][4];
+            lds_d2 colop[kDenseCols], rowop[kNQ][4];
 #pragma unroll
             for (int g = 0; g < kDenseCols; ++g) {
                 const int bk = g < nbk ? nbk - 1 - g : 0;
                 colop[g] = *reinterpret_cast<const lds_d2 *>(cv + 2 * (16 * bk + lr));
             }
 #pragma unroll
-            for (int qq = 0; qq < 3; ++qq) {
-                const int h = dense_row_of(wv, qq), bi = h < nbk ? nbk - 1 - h : 0;
+            for (int qq = 0; qq < kNQ; ++qq) {
+                const int h = dt_row_of<LA>(wv, qq), bi = h < nbk ? nbk - 1 - h : 0;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) rowop[qq][r] = *reinterpret_cast<const lds_d2 *>(cv + 2 * (16 * bi + lk + 4 * r));
             }
@@ -2020,18 +2070,18 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
                 acc[i][0] = 0, acc[i][1] = 0, acc[i][2] = 0, acc[i][3] = 0;
                 if (sbk[i] >= 0) {
                     const int bi = sbi[i], bk = sbk[i];
-                    const lds_d2 ck = colop[kSlotCol[i]];
+                    const lds_d2 ck = colop[dt_slot_col<LA>(i)];
                     // C is 0 on inactive and padding coordinates, the image is 0 above the diagonal and outside
                     // the real rows: one formula for every entry, the structural entries are patched below
                     double val[4] = {raw[i][0][0], raw[i][0][1], raw[i][1][0], raw[i][1][1]};
                     const double vk2 = 2.0 * ck[1];
                     if (v.dm.qvv_back) { // v^T S v comes from k_backsub (same image, C v from HBM): scaling only
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) val[r] *= rowop[kSlotQ[i]][r][0] * ck[0];
+                        for (int r = 0; r < 4; ++r) val[r] *= rowop[dt_slot_q<LA>(i)][r][0] * ck[0];
                     } else {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const lds_d2 ci = rowop[kSlotQ[i]][r];
+                            const lds_d2 ci = rowop[dt_slot_q<LA>(i)][r];
                             val[r] *= ci[0] * ck[0];
                             q += val[r] * (ci[1] * vk2);
                         }
@@ -2041,7 +2091,7 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
                             if (lk + 4 * r == lr) {
-                                if (!v.dm.qvv_back) q -= val[r] * (rowop[kSlotQ[i]][r][1] * ck[1]);
+                                if (!v.dm.qvv_back) q -= val[r] * (rowop[dt_slot_q<LA>(i)][r][1] * ck[1]);
                                 val[r] += dgk;
                             }
                     }
@@ -2077,8 +2127,153 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
 #pragma unroll
         for (int i = 0; i < kSlots; ++i)
             if (sbk[i] == 0) PV_PUBLISH(i, 0);
+        int *const flag_L = reinterpret_cast<int *>(lds + 216), *const flag_pub = flag_L + 1; // look-ahead form: see below
+        if (LA && tid == 0) *flag_L = 0, *flag_pub = 3, sh_fail = 0; // (panel 0 has just been published by the three update waves)
         __syncthreads(); // every wave holds its tiles: the tile image may be overwritten from here on
         int lfo = 0;     // offset of the current panel in Lf (panel p keeps rows j0 .. LDV - 1, 8 doubles each)
+        if constexpr (LA) {
+            // ---------------- look-ahead form: no workgroup barrier inside the loop ----------------
+            // flag_pub counts the 8-column blocks published into Xs, one count per update wave and block (3 per panel);
+            // flag_L counts the panels whose L rows are complete in Lf (negative: a non-positive pivot, everybody leaves).
+            //   wave 0, panel p:   wait flag_pub >= 3 (p + 1) -> diagonal block + all rows of the panel from Xs -> L rows to Lf(p)
+            //                      -> flag_L = p + 1
+            //   waves 1..3, panel p: wait flag_L >= p + 1 -> operands from Lf(p) -> rank-8 update of the next tile column ->
+            //                      publish its 8 columns into Xs -> flag_pub += 1 -> rank-8 update of the other columns
+            // Xs is single-buffered: the update waves overwrite it only after flag_L = p + 1, i.e. after wave 0 has read every
+            // row of panel p; Lf(p) and Lf(p + 1) are different regions.
+            if (wv == 0) {
+                int pidx = 0;
+                for (int j0 = 0; j0 < Pp; j0 += kPanel, ++pidx) {
+                    if (j0 == 0) PV_STAMP(2, 8);
+                    if (j0 == 80) PV_STAMP(2, 13);
+                    dense_wait(flag_pub, 3 * (pidx + 1));
+                    double Ld[kPanel][kPanel], inv[kPanel];
+#pragma unroll
+                    for (int r = 0; r < kPanel; ++r)
+#pragma unroll
+                        for (int h = 0; h <= (r >> 1); ++h) {
+                            const lds_d2 g2 = *reinterpret_cast<const lds_d2 *>(Xs + (j0 + r) * 8 + 2 * h);
+                            Ld[r][2 * h] = -g2[0];
+                            if (2 * h + 1 <= r) Ld[r][2 * h + 1] = -g2[1];
+                        }
+                    // this wave owns EVERY row of the panel: rows j0 + lane + 64 t, t < 3 (LDV <= 176), carried through the pivot loop
+                    // (always three passes, rows past the end re-read the last one: skipping the empty passes was tried twice -- a uniform
+                    // branch per pass inside the pivot loop, and one straight-line copy of the body per pass count -- and both were
+                    // slower than carrying the dead rows: 12.0k / 12.1k against 12.6k iterations/s, profiles/r3_ab_lookahead.txt)
+                    constexpr int kPass = 3;
+                    double x[kPass][kPanel];
+#pragma unroll
+                    for (int t = 0; t < kPass; ++t) {
+                        const int irow = j0 + lane + 64 * t, ir = irow < LDV ? irow : LDV - 1;
+#pragma unroll
+                        for (int h = 0; h < 4; ++h) {
+                            const lds_d2 g2 = *reinterpret_cast<const lds_d2 *>(Xs + ir * 8 + 2 * h);
+                            x[t][2 * h] = -g2[0], x[t][2 * h + 1] = -g2[1];
+                        }
+                    }
+                    double Ls[kPanel][kPanel];
+#pragma unroll
+                    for (int cc = 0; cc < kPanel; ++cc) {
+                        const double dd = Ld[cc][cc];
+                        fail |= (!(dd > 0.0) || !isfinite(dd)) ? 1 : 0;
+                        inv[cc] = fast_rsqrt(dd);
+                        const double inv2 = inv[cc] * inv[cc];
+#pragma unroll
+                        for (int r = cc + 1; r < kPanel; ++r) Ls[r][cc] = Ld[r][cc] * inv2;
+#pragma unroll
+                        for (int r = cc + 1; r < kPanel; ++r)
+#pragma unroll
+                            for (int c2 = cc + 1; c2 <= r; ++c2) Ld[r][c2] -= Ld[r][cc] * Ls[c2][cc];
+#pragma unroll
+                        for (int t = 0; t < kPass; ++t)
+#pragma unroll
+                            for (int c2 = cc + 1; c2 < kPanel; ++c2) x[t][c2] -= x[t][cc] * Ls[c2][cc];
+                    }
+                    if (j0 == 0) PV_STAMP(2, 9);
+                    if (j0 == 80) PV_STAMP(2, 14);
+                    if (fail) { // uniform
+                        if (lane == 0) sh_fail = 1;
+                        dense_signal_set(flag_L, -1);
+                        break;
+                    }
+                    if (lane < kPanel) {
+                        double iv = inv[0];
+#pragma unroll
+                        for (int cc = 1; cc < kPanel; ++cc) iv = (lane == cc) ? inv[cc] : iv;
+                        tmp[j0 + lane] = iv; // 1 / L_jj for the back substitution
+                    }
+#pragma unroll
+                    for (int t = 0; t < kPass; ++t) {
+                        const int irow = j0 + lane + 64 * t;
+                        if (irow < LDV) {
+#pragma unroll
+                            for (int cc = 0; cc < kPanel; ++cc) x[t][cc] = (j0 + cc <= irow) ? x[t][cc] * inv[cc] : 0.0;
+                            lds_d2 *Lrow = reinterpret_cast<lds_d2 *>(Lf + lfo + 8 * (lane + 64 * t));
+#pragma unroll
+                            for (int h = 0; h < 4; ++h) {
+                                lds_d2 pr;
+                                pr[0] = x[t][h], pr[1] = x[t][h + 4]; // operand pair (k, k + 4) of the two MFMAs
+                                Lrow[h] = pr;
+                            }
+                        }
+                    }
+                    if (j0 == 0) PV_STAMP(2, 10);
+                    if (j0 == 80) PV_STAMP(2, 15);
+                    dense_signal_set(flag_L, pidx + 1); // (release: the rows above are in LDS before the counter moves)
+                    if (j0 == 0) { PV_STAMP(2, 11); PV_STAMP(2, 12); }
+                    if (j0 == 80) { PV_STAMP(2, 16); PV_STAMP(2, 17); }
+                    lfo += 8 * (LDV - j0);
+                }
+            } else {
+                int pidx = 0;
+                for (int j0 = 0; j0 < Pp; j0 += kPanel, ++pidx) {
+                    const int k0 = j0 + kPanel, b0 = k0 >> 4, o2 = k0 & 15;
+                    if (dense_wait(flag_L, pidx + 1) < 0) break;
+                    const int R = nbk - b0; // live tile columns g = 0 .. R - 1 (from the end); the one that is factored next is g = R - 1
+                    const double *Lpan = Lf + lfo - 8 * j0 + 2 * lk + 8 * lr; // + 128 * tile row -> this lane's operand pair
+                    lds_d2 opA[kNQ], opB[kDenseCols];
+                    int hq[kNQ]; // this wave's tile rows (uniform)
+#pragma unroll
+                    for (int q = 0; q < kNQ; ++q) {
+                        hq[q] = dt_row_of<LA>(wv, q);
+                        opA[q] = *reinterpret_cast<const lds_d2 *>(Lpan + 128 * (hq[q] < R ? nbk - 1 - hq[q] : b0));
+                    }
+#pragma unroll
+                    for (int g = 0; g < kDenseCols; ++g)
+                        opB[g] = *reinterpret_cast<const lds_d2 *>(Lpan + 128 * (g < R ? nbk - 1 - g : b0));
+#define PV_LA_COLUMN(g)                                                                                                \
+    do {                                                                                                               \
+        _Pragma("unroll") for (int q = 0; q < dt_col_slot<LA>((g) + 1) - dt_col_slot<LA>(g); ++q)                      \
+            acc[dt_col_slot<LA>(g) + q] = __builtin_amdgcn_mfma_f64_16x16x4f64(opA[q][0], opB[g][0], acc[dt_col_slot<LA>(g) + q], 0, 0, 0); \
+        _Pragma("unroll") for (int q = 0; q < dt_col_slot<LA>((g) + 1) - dt_col_slot<LA>(g); ++q)                      \
+            acc[dt_col_slot<LA>(g) + q] = __builtin_amdgcn_mfma_f64_16x16x4f64(opA[q][1], opB[g][1], acc[dt_col_slot<LA>(g) + q], 0, 0, 0); \
+    } while (0)
+#pragma unroll
+                    for (int g = kDenseCols - 1; g >= 0; --g)
+                        if (g < R) { // uniform
+                            PV_LA_COLUMN(g);
+                            if (g == R - 1) {
+#pragma unroll
+                                for (int q = 0; q < dt_col_slot<LA>(g + 1) - dt_col_slot<LA>(g); ++q)
+                                    if (hq[q] <= g) {
+                                        asm volatile("" ::: "memory"); // keep this a real (uniform) branch: nothing of the publish is hoisted
+                                        PV_PUBLISH_ROW(dt_col_slot<LA>(g) + q, nbk - 1 - hq[q], o2);
+                                    }
+                                dense_signal_add(flag_pub); // (release; one count per wave and panel, whether it owns a row here or not)
+                            }
+                        }
+#undef PV_LA_COLUMN
+                    lfo += 8 * (LDV - j0);
+                }
+            }
+            __syncthreads();
+            fail = sh_fail;
+            {
+                int lfo_end = 0; // every wave leaves with the offset behind the last panel (a failed pivot: unused)
+                for (int j0 = 0; j0 < Pp; j0 += kPanel) lfo_end += 8 * (LDV - j0);
+                lfo = lfo_end;
+            }
+        } else
         for (int j0 = 0; j0 < Pp; j0 += kPanel) {
             const int k0 = j0 + kPanel, b0 = k0 >> 4, o2 = k0 & 15;
             if (j0 == 0) PV_STAMP(2, 8);
@@ -2991,18 +3186,24 @@ hipError_t launch_dense(const View &v, hipStream_t st) {
 #ifndef PV_HIPEMU
     static size_t configured = 0, configured_g = 0;
     if (lm && lds > configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dense<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dense<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dense<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         configured = lds;
     }
     if (!lm && lds > configured_g) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dense<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dense<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         configured_g = lds;
     }
 #endif
-    if (lm) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_dense<true>), dim3(1), dim3(kDenseThreads), lds, st, v);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_dense<false>), dim3(1), dim3(2 * kDenseThreads), lds, st, v);
+    static const bool say = std::getenv("PVIO_HIP_DEBUG_LAUNCH") != nullptr;
+    static bool said = false;
+    if (say && !said) said = true, std::fprintf(stderr, "launch_dense: lds matrix %d, look-ahead %d, split finalize %d, qvv in backsub %d\n", lm, v.dm.dense_la, v.dm.split_fin, v.dm.qvv_back);
+    if (lm && v.dm.dense_la) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_dense<true, true>), dim3(1), dim3(kDenseThreads), lds, st, v);
+    else if (lm) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_dense<true, false>), dim3(1), dim3(kDenseThreads), lds, st, v);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_dense<false, false>), dim3(1), dim3(2 * kDenseThreads), lds, st, v);
     return hipGetLastError();
 }
 

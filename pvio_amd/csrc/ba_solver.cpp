@@ -16,6 +16,8 @@
 #include <cmath>
 
 namespace pvba {
+constexpr bool kDenseLookAheadDefault = true; // same-box A/B (profiles/r3_ab_lookahead.txt): 12 076 -> 12 678 iterations/s
+
 
 DevicePool::~DevicePool() { release(); }
 void DevicePool::release() {
@@ -357,6 +359,10 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st) {
         dm.split_fin = (!sharded_ && !dm.fuse_backsub && !split_off) ? 1 : 0;
         dm.qvv_back = (dm.split_fin && dm.use_img && lds_matrix) ? 1 : 0;
         v.dm.split_fin = dm.split_fin, v.dm.qvv_back = dm.qvv_back;
+        // look-ahead form of the register-resident factorization (PVIO_HIP_DENSE_LA=0 / 1 overrides the default)
+        static const int la_env = std::getenv("PVIO_HIP_DENSE_LA") ? std::atoi(std::getenv("PVIO_HIP_DENSE_LA")) : -1;
+        dm.dense_la = (lds_matrix && dm.use_img && (la_env < 0 ? kDenseLookAheadDefault : la_env != 0)) ? 1 : 0;
+        v.dm.dense_la = dm.dense_la;
         ok &= dev(pool_, "img", img_sz, &v.img, &grew);
         if (ok && v.dm.use_img && check(hipMemsetAsync(v.img, 0, img_sz * sizeof(double), stream_), "memset img")) return PVIO_ERR_HIP;
     }

@@ -98,6 +98,7 @@ struct Dims {
     int32_t split_fin;    // single GPU, separate k_backsub launch: k_dense defers the gradient max-norm, the state / trace copies and
                           // (qvv_back) the pose part of v^T H v to k_backsub, where they run beside the landmark back-substitution
     int32_t qvv_back;     // v^T S v from the tile image in k_backsub (partials in back_part[.][6]) instead of k_dense
+    int32_t dense_la;     // register-resident factorization in its look-ahead form (wave 0 factors panel p + 1 while waves 1..3 apply panel p)
     int32_t lm_mm;        // landmark workgroups accumulate the Schur complement as 16x16 f64 MFMA tiles and walk a contiguous chunk range
 };
 

@@ -47,6 +47,8 @@ void trampoline() {
 }
 } // namespace
 
+void spin_yield() { yield(); }
+
 void syncthreads() {
     if (n_done != 0) {
         std::fprintf(stderr, "hipemu: __syncthreads() reached after %d thread(s) of the block already returned\n", n_done);

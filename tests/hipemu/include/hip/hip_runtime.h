@@ -67,6 +67,7 @@ extern ThreadCtx *g_cur;
 extern char *g_dyn_smem;
 void launch(dim3 grid, dim3 block, size_t shmem, Stream *s, std::function<void()> body);
 void syncthreads();
+void spin_yield(); // a polling loop hands the processor to the other fibers of the block
 void wave_exchange(const void *in, void *out_all, size_t elem); // every lane contributes, receives all 64 values
 double now_ms();
 } // namespace hipemu
