@@ -11,14 +11,18 @@ factor set of a steady-state VIO window (9000 reprojection factors with Cauchy l
 the gauge/marginalization prior).  `--workload vision` gives the reprojection-only variant.
 
 With N > 1 the window is landmark-sharded over the ranks (contiguous CSR ranges); the reduced pose system and 8 scalars are
-all-reduced with RCCL once per linearization / back-substitution -> "scaling": "strong".  The N > 1 headline window is the
-one north_star states the multi-GPU target on, 10 KF x 50 000 landmarks (named in config.workload); the line also carries the
-same window's single-GPU rate measured in the same run (`single_gpu_same_workload`) and the sharded 10 x 1000 window
-(`small_window`).  Every N = 1 line carries the 50 000-landmark window as `scaling_window`.
+all-reduced with RCCL once per linearization / back-substitution -> "scaling": "strong".  `value` is the metric's window
+(10 KF x 1000 landmarks) at every N; the window north_star states the multi-GPU target on, 10 KF x 50 000 landmarks, is the
+`scaling_window` object of every line (sharded like the headline; for N > 1 with the same window's unsharded rate on rank 0
+from the same run and the ratio of the two).
 
 Extra objects on the JSON line:
-  roofline      dominant kernel (k_linearize): algorithmic bytes per launch / its average duration, measured here with
-                hipEvents on the solver's own stream (pvio_hip_ba_profile_resident), against the 8 TB/s HBM peak.
+  roofline      the kernel that moves the window's data (k_linearize): algorithmic bytes per launch / its average
+                duration, measured here with hipEvents on the solver's own stream (pvio_hip_ba_profile_resident), against the 8 TB/s
+                HBM peak; `traffic` = HBM bytes per launch from rocprofv3 counter passes run as children of THIS run (null
+                when the profiler is not there).
+  roofline_dense  the kernel that is longest by duration (k_dense, one workgroup): flops of the Cholesky + substitutions per
+                factoring launch / its duration against the FP64 peak.
   scaling_window  the 10 KF x 50 000 landmark VIO window (the one north_star states the 8-GPU target on), sharded the
                 same way, a few solves: its iterations/s at this N next to the headline value.
   api           the same window through pvio_hip_ba_solve (upload + iterations + download per solve): the H2D/D2H-inclusive rate.
@@ -39,27 +43,77 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
-def pmc_traffic(kernel, workload="vio"):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/*_pmc_hbm[_<workload>].json:
-    separate FETCH_SIZE / WRITE_SIZE runs of this same command, FETCH_SIZE doubled per the gfx950 correction).  None if
-    there is no pass for this workload (the headline file was collected on the default VIO window)."""
-    import glob
-    suffix = "" if workload == "vio" else "_" + workload
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm%s.json" % suffix)))
-    if not files:
+FP64_PEAK_TFLOPS = 78.6  # MI355X FP64 (vector = matrix) peak: 256 CUs x 4 SIMDs x 32 flop/clk x 2.4 GHz -- the rate of the measured
+                         # 64-cycle v_mfma_f64_16x16x4_f64 (profiles/r2_ubench_mfma_valu_overlap.txt); the guide lists no FP64 figure
+
+_PMC = {"done": False, "kernels": None, "note": None}
+
+
+def live_pmc(args):
+    """HBM bytes per launch and kernel, measured INSIDE this run: two child passes of this same script under
+    `rocprofv3 --kernel-trace --pmc <counter>` (FETCH_SIZE and WRITE_SIZE in separate passes, counters only -- no sys / runtime
+    traces), reduced as /opt/skills/guides/MI355X_MICROARCH.md prescribes (profiles/summarize_pmc.py: KiB units, FETCH_SIZE doubled
+    on gfx950).  Returns None (-> `traffic: null`) when rocprofv3 is missing, a pass fails or takes too long.  Nothing is read
+    from files committed earlier: the numbers belong to the binaries that are being timed."""
+    if _PMC["done"]:
+        return _PMC["kernels"]
+    _PMC["done"] = True
+    import shutil
+    import subprocess
+    import tempfile
+    if getattr(args, "no_pmc", False) or os.environ.get("PVIO_BENCH_NO_PMC") or shutil.which("rocprofv3") is None:
+        _PMC["note"] = "rocprofv3 not run"
         return None
     try:
         sys.path.insert(0, os.path.join(ROOT, "profiles"))
-        from summarize_pmc import source_sha256
-        with open(files[-1]) as f:
-            d = json.load(f)
-        # counters of OTHER kernel sources say nothing about this run: null unless the pass was collected on exactly these
-        # sources (profiles/collect.sh stamps the file with their fingerprint)
-        if d.get("source_sha256") != source_sha256():
-            return None
-        return d["kernels"][kernel]["hbm_bytes_per_launch"]
-    except Exception:
+        import summarize_pmc
+        res = {}
+        with tempfile.TemporaryDirectory(dir="/tmp") as td:
+            for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+                out = os.path.join(td, counter)
+                cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable,
+                       os.path.join(ROOT, "bench.py"), "--pmc-child", "--workload", args.workload]
+                env = dict(os.environ, TMPDIR="/tmp", PVIO_BENCH_NO_PMC="1")
+                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=150)
+                if r.returncode != 0:
+                    _PMC["note"] = "rocprofv3 --pmc %s failed (rc %d)" % (counter, r.returncode)
+                    return None
+                res[counter] = summarize_pmc.per_kernel(out, counter)
+        kernels = {}
+        for k in set(res["FETCH_SIZE"]) | set(res["WRITE_SIZE"]):
+            f, nf = res["FETCH_SIZE"].get(k, (0.0, 0))
+            w, nw = res["WRITE_SIZE"].get(k, (0.0, 0))
+            kernels[k] = {"hbm_bytes_per_launch": 2.0 * f * 1024.0 + w * 1024.0, "launches": [nf, nw]}
+        _PMC["kernels"] = kernels
+        _PMC["note"] = "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE child passes of this run; bytes = 2 x FETCH_SIZE KiB + WRITE_SIZE KiB (gfx950 correction)"
+        return kernels
+    except Exception as e:  # a profiler that is absent or hangs must not cost the bench line
+        _PMC["note"] = "pmc pass failed: %s" % type(e).__name__
         return None
+
+
+def pmc_traffic(kernel, args=None):
+    """`roofline.traffic` of `kernel`: live counters of this run (rank 0 of a single-GPU run) or None"""
+    if args is None or int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        return None
+    k = live_pmc(args)
+    return None if not k or kernel not in k else k[kernel]["hbm_bytes_per_launch"]
+
+
+def pmc_child(args):
+    """What the counter passes profile: a few resident solves of the headline window and a few LK launches, nothing else."""
+    from pvio_amd import BASummary, synth
+    from pvio_amd.solver import HipContext, HipImage, klt_track, preintegrate
+    pb, _ = build_window(args, preintegrate)
+    ctx = HipContext(device=0)
+    ctx.upload(pb)
+    for _ in range(6):
+        ctx.solve_resident(BASummary(pb, trace=False))
+    img0, img1, p, truth, init = synth.make_image_pair(512, 512, 1500)
+    A, B = HipImage(ctx, img0), HipImage(ctx, img1)
+    for _ in range(6):
+        klt_track(ctx, A, B, p, init)
+    ctx.close()
 
 
 def parse_workload(name):
@@ -122,7 +176,7 @@ def bench_klt(ctx, args, width=512, height=512, n_points=1500, reps=50):
            "workload": "%dx%d u8 pair, %d tracks, win 21x21, 4 levels, <=30 iterations, initial flow given" % (width, height, n_points),
            "tracked": int(st.sum()), "preprocess_ms_per_image": prep_ms, "preprocess_undistorted_ms_per_image": prep_ud_ms, "detect_ms_per_image": detect_ms, "detected_corners": int(len(corners)),
            "roofline": {"bound": "hbm", "kernel": "k_lk_track", "achieved": alg_bytes / (dev_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": alg_bytes / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic("k_lk_track"), "algorithmic_bytes_per_launch": alg_bytes,
+                        "frac": alg_bytes / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic("k_lk_track", args), "algorithmic_bytes_per_launch": alg_bytes,
                         "avg_launch_us": dev_ms * 1e3}}
     if not args.no_cpu_baseline:
         from oracle import oracle_py as O
@@ -178,6 +232,24 @@ def bench_scaling_window(ctx, args, rank, world, dist, barrier, preintegrate, n_
     import torch
     from pvio_amd import BASummary, synth
     pb_full = synth.make_window(n_frames=n_frames, n_landmarks=n_landmarks, use_inertial=True, preintegrate=preintegrate)
+    single = None
+    if world > 1:  # the same window unsharded on rank 0's GPU, in this run
+        if rank == 0:
+            from pvio_amd.solver import HipContext
+            c1 = HipContext(device=torch.cuda.current_device(), use_graph=not args.no_graph)
+            c1.upload(pb_full)
+            s1 = BASummary(pb_full, trace=False)
+            for _ in range(max(warmup, 3)):
+                c1.solve_resident(s1)
+            torch.cuda.synchronize()
+            t1, it1 = time.perf_counter(), 0
+            for _ in range(steps):
+                c1.solve_resident(s1)
+                it1 += s1.num_iterations
+            torch.cuda.synchronize()
+            single = {"value": it1 / (time.perf_counter() - t1), "unit": "iterations/s", "steps": steps, "what": "the same window unsharded on rank 0's GPU, this run"}
+            c1.close()
+        dist.barrier()
     pb = pb_full.shard(rank, world)
     ctx.upload(pb)
     sm = BASummary(pb, trace=False)
@@ -196,10 +268,16 @@ def bench_scaling_window(ctx, args, rank, world, dist, barrier, preintegrate, n_
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     prof = ctx.profile_resident(BASummary(pb, trace=False))
-    return {"workload": "%d KF x %d landmarks, full VIO factor set, %d reprojection factors (%d on this rank)" % (n_frames, n_landmarks, pb_full.n_obs, pb.n_obs),
-            "value": iters / elapsed, "unit": "iterations/s", "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
-            "iterations_per_solve": iters / steps, "final_cost": float(sm.final_cost),
-            "kernel_us_rank0": {k: (v[0] / max(v[1], 1)) * 1e3 for k, v in prof.items()}}
+    out = {"workload": "%d KF x %d landmarks, full VIO factor set, %d reprojection factors (%d on this rank)" % (n_frames, n_landmarks, pb_full.n_obs, pb.n_obs),
+           "value": iters / elapsed, "unit": "iterations/s", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
+           "iterations_per_solve": iters / steps, "final_cost": float(sm.final_cost),
+           "kernel_us_rank0": {k: (v[0] / max(v[1], 1)) * 1e3 for k, v in prof.items()}}
+    if world > 1 or args.force_sharded:  # the latency budget of an iteration, exchange steps included (eager launches, hipEvents)
+        out["exchange_us_rank0"] = {k: (v[0] / max(v[1], 1)) * 1e3 for k, v in ctx.last_comm.items()}
+    if single:
+        out["single_gpu_same_run"] = single
+        out["speedup_vs_single_gpu"] = out["value"] / single["value"]
+    return out
 
 
 def main():
@@ -216,7 +294,12 @@ def main():
     ap.add_argument("--force-sharded", action="store_true",
                     help="diagnostics: run the multi-GPU code path (process group, RCCL communicator, eager launches, all-reduces) with "
                          "however many ranks there are, also one")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter passes (roofline.traffic: null)")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.pmc_child:
+        pmc_child(args)
+        return
 
     # stdout carries exactly ONE line (the JSON): libraries that write to file descriptor 1 (RCCL prints its version banner
     # there at communicator creation) are sent to stderr for the duration of the run
@@ -248,13 +331,11 @@ def main():
     from pvio_amd.solver import HipContext, preintegrate
 
     lib = capi.load()
-    # N > 1: the headline is the window north_star states the multi-GPU target on (10 KF x 50 000 landmarks) -- the 10 x 1000
-    # window of the N = 1 line is latency-bound per iteration and cannot gain from landmark shards; it rides along as
-    # `small_window`.  The same window's single-GPU rate is measured in this run (rank 0, before the sharded solves) and is
-    # also what every N = 1 line carries as `scaling_window`.
-    multi_headline = world > 1 and args.workload == "vio"
-    if multi_headline:
-        args.workload = "10x50000_vio"
+    # `value` is the window the metric is quoted on (BASELINE.json: 10 KF x 1000 landmarks) at EVERY N, so that the driver's N = 1, 2,
+    # 4, 8 lines are one curve.  (Round 2 switched the headline to the 10 x 50 000 window for N > 1: lines of different workloads are not
+    # comparable -- ADVICE r2.)  That window is latency-bound per iteration and cannot gain from landmark shards; the window
+    # north_star states the multi-GPU target on -- 10 KF x 50 000 landmarks -- is reported by every line as `scaling_window`, with the
+    # same window's unsharded rate on rank 0 measured in the same run (`single_gpu_same_run`) and the ratio of the two.
     pb_full, (n_frames, n_lm, vio) = build_window(args, preintegrate)
     single_gpu = None
     if world > 1:
@@ -262,7 +343,7 @@ def main():
             c1 = HipContext(device=local_rank, use_graph=not args.no_graph)
             c1.upload(pb_full)
             s1 = BASummary(pb_full, trace=False)
-            for _ in range(2):
+            for _ in range(10):
                 c1.solve_resident(s1)
             torch.cuda.synchronize()
             t1, it1, n1 = time.perf_counter(), 0, max(5, min(args.steps, 20))
@@ -338,15 +419,28 @@ def main():
     achieved = alg_bytes / avg_s / 1e9 if avg_s > 0 else 0.0
     roofline = {
         "bound": "hbm", "kernel": "k_linearize", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("k_linearize", args.workload),
+        "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("k_linearize", args),
         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": avg_s * 1e6,
         "kernel_us": {k: (v[0] / max(v[1], 1)) * 1e3 for k, v in prof.items()},
+        "exchange_us": {k: (v[0] / max(v[1], 1)) * 1e3 for k, v in ctx.last_comm.items()} if sharded else None,
         "note": "working set < 1 MB: L2/Infinity-Cache resident, the iteration is launch/dependency-latency bound",
     }
     # the roofline above is for the kernel that moves the window's data (SURVEY 8d's per-iteration bytes); by DURATION the
     # longest launch of a small window is the one-workgroup dense solve, a serial FP64 chain with no bandwidth or matrix-core
     # roofline worth quoting (P^3/3 flops in its time is < 0.1 % of the FP64 peak)
     roofline["longest_kernel"] = max(roofline["kernel_us"], key=roofline["kernel_us"].get)
+    roofline["traffic_source"] = _PMC["note"]
+    # the dense kernel against the only roofline it has, FP64 arithmetic: P^3 / 3 + 2 P^2 flops (Cholesky of the reduced system with the
+    # right-hand side carried along + back substitution) per FACTORING launch.  Its average duration over all launches of a solve
+    # (rejected steps do not factor) is a lower bound of a factoring launch's: the fraction quoted is an upper bound -- and still
+    # ~1e-4: one workgroup on one CU, a chain of P dependent pivots.
+    Pd = (15 if vio else 6) * n_frames
+    dense_flops = Pd ** 3 / 3.0 + 2.0 * Pd ** 2
+    dense_s = roofline["kernel_us"]["k_dense"] * 1e-6
+    roofline_dense = {"bound": "mfma", "kernel": "k_dense", "achieved": dense_flops / dense_s / 1e12 if dense_s > 0 else 0.0, "peak": FP64_PEAK_TFLOPS,
+                      "unit": "TFLOP/s", "frac": (dense_flops / dense_s / 1e12) / FP64_PEAK_TFLOPS if dense_s > 0 else 0.0,
+                      "traffic": pmc_traffic("k_dense", args), "flops_per_factoring_launch": dense_flops, "avg_launch_us": dense_s * 1e6,
+                      "note": "dtype f64 on the FP64 matrix cores (v_mfma_f64_16x16x4_f64) + FP64 VALU; one workgroup: a serial dependency chain, not a throughput kernel"}
     if n_lm >= 10000:
         roofline["note"] = ("large window: k_linearize is FP64-issue bound (factor evaluation on the VALU + Schur complement on the f64 matrix "
                             "cores), not HBM bound; see DESIGN.md section 5")
@@ -359,13 +453,6 @@ def main():
             scaling_window = bench_scaling_window(ctx, args, rank, world, dist, barrier, preintegrate)
         except Exception as e:  # the headline line must still be printed
             scaling_window = {"error": repr(e)}
-    small_window = None
-    if multi_headline and not args.no_scaling_window:
-        try:
-            small_window = bench_scaling_window(ctx, args, rank, world, dist, barrier, preintegrate, n_frames=10, n_landmarks=1000, steps=50, warmup=5)
-        except Exception as e:
-            small_window = {"error": repr(e)}
-
     cpu = None
     if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
         from oracle import oracle_py as O
@@ -418,6 +505,7 @@ def main():
             "device_ms_per_step": 1e3 * dev_s / args.steps,
             "api": api,
             "roofline": roofline,
+            "roofline_dense": roofline_dense,
             "cpu_baseline": cpu,
             "klt": klt,
             "concurrent_windows": multi,
@@ -425,7 +513,6 @@ def main():
         }
         if world > 1:
             out["single_gpu_same_workload"] = single_gpu
-            out["small_window"] = small_window
             if single_gpu:
                 out["speedup_vs_single_gpu"] = value / single_gpu["value"]
         if cpu:

@@ -218,6 +218,11 @@ typedef struct pvio_ba_kernel_times {
     double total_ms[4];
     int32_t launches[4];
     int64_t phase_ticks[4][32]; /* shader-clock timestamps of the LAST working slot, block 0 (kernel phase breakdown) */
+    /* landmark-sharded solves: the two exchange steps of an iteration, same events.  [0] all-reduce of the reduced system (+ the
+     * k_reduce pass that turns it into the tile image), [1] the 8-double all-reduce behind the back-substitution (+ k_back_reduce).
+     * Zero on a single GPU. */
+    double comm_ms[2];
+    int32_t comm_launches[2];
 } pvio_ba_kernel_times;
 int32_t pvio_hip_ba_profile_resident(pvio_hip_ctx *ctx, pvio_ba_summary *summary, pvio_ba_kernel_times *times);
 

@@ -70,7 +70,8 @@ class BAPriorC(C.Structure):
 
 
 class BAKernelTimesC(C.Structure):
-    _fields_ = [("total_ms", C.c_double * 4), ("launches", C.c_int32 * 4), ("phase_ticks", (C.c_int64 * 32) * 4)]
+    _fields_ = [("total_ms", C.c_double * 4), ("launches", C.c_int32 * 4), ("phase_ticks", (C.c_int64 * 32) * 4),
+                ("comm_ms", C.c_double * 2), ("comm_launches", C.c_int32 * 2)]
 
 
 class ImuNoiseC(C.Structure):

@@ -450,6 +450,7 @@ int BASolver::enqueue_slot(hipEvent_t *ev) {
         if ((e = launch_back_reduce(v_, back_local, stream_)) != hipSuccess) return check(e, "k_back_reduce");
         if (comm_allreduce(comm_, v_.back_red, kNumBackScal, 0, stream_)) return fail(PVIO_ERR_COMM, "all-reduce failed");
     }
+    if (ev) (void)hipEventRecord(ev[6], stream_);
     return PVIO_OK;
 }
 
@@ -534,9 +535,12 @@ int BASolver::solve(pvio_ba_summary *sum, pvio_ba_kernel_times *prof) {
     // has not reported done
     // (no slack slot: a solve whose mu escalates needs more slots than iterations and simply gets a second replay from the loop below;
     // every other solve saved four no-op launches per replay)
-    const int n_slots = dm.max_iter + 1;
+    // A real-time configuration (a limit far below the reference's default of 1e6 s, config.cpp:86-88) looks at the clock every two
+    // slots instead of once per solve: Ceres tests its limit every iteration
+    const bool time_limited = max_solver_time_ > 0 && max_solver_time_ < 1.0e5;
+    const int n_slots = time_limited ? std::min(dm.max_iter + 1, 2) : dm.max_iter + 1;
     int rounds = 0;
-    hipEvent_t pev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t pev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     long long *dbg_saved = v_.dbg;
     bool prof_graph = false;
     if (prof) {
@@ -568,6 +572,15 @@ int BASolver::solve(pvio_ba_summary *sum, pvio_ba_kernel_times *prof) {
                     prof->total_ms[k] += ms1;
                     prof->launches[k] += 1;
                 }
+                if (sharded_) { // the two exchange steps: between k_reduce and k_dense, behind k_backsub
+                    const int ca[2] = {2, 5}, cb[2] = {3, 6};
+                    for (int k = 0; k < 2; ++k) {
+                        float ms1 = 0;
+                        (void)hipEventElapsedTime(&ms1, pev[ca[k]], pev[cb[k]]);
+                        prof->comm_ms[k] += ms1;
+                        prof->comm_launches[k] += 1;
+                    }
+                }
             }
             --rounds; // the round cap below is for graph replays
         } else {
@@ -577,13 +590,31 @@ int BASolver::solve(pvio_ba_summary *sum, pvio_ba_kernel_times *prof) {
         if (check(hipMemcpyAsync(h_ctrl_, v_.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, stream_), "ctrl D2H")) return PVIO_ERR_HIP;
         if (check(hipEventRecord(ev1_, stream_), "event")) return PVIO_ERR_HIP;
         if (check(hipStreamSynchronize(stream_), "solve sync")) return PVIO_ERR_HIP;
-        if (h_ctrl_->done || ++rounds > 16) break;
+        if (h_ctrl_->done || ++rounds > (time_limited ? 16 * (dm.max_iter + 1) : 16)) break;
         // max_solver_time_in_seconds (solver_options.h:30): the state machine runs on the device, so the wall clock is looked at
         // between replays of the slot graph only (one replay covers every iteration of an ordinary solve): NO_CONVERGENCE at
         // the iterate reached, like Ceres' time-limit exit
-        if (max_solver_time_ > 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > max_solver_time_) {
-            h_ctrl_->done = 1, h_ctrl_->termination = PVIO_TERM_NO_CONVERGENCE;
-            break;
+        if (max_solver_time_ > 0) {
+            int timed_out = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > max_solver_time_ ? 1 : 0;
+            // tests: only rank PVIO_HIP_DEBUG_TIMEOUT_RANK sees its clock run out (the ranks must still leave in the same round)
+            static const int dbg_timeout_rank = std::getenv("PVIO_HIP_DEBUG_TIMEOUT_RANK") ? std::atoi(std::getenv("PVIO_HIP_DEBUG_TIMEOUT_RANK")) : -1;
+            if (dbg_timeout_rank >= 0) timed_out = rank_ == dbg_timeout_rank ? 1 : 0;
+            if (sharded_) {
+                // every rank looks at its OWN clock, but the next replay contains collectives: a rank that left alone would leave the
+                // others waiting in an all-reduce for good.  `done` is identical on all ranks (identical all-reduced inputs),
+                // so they all arrive here in the same round; the decision is all-reduced (max) before anybody acts on it.
+                double *flag = static_cast<double *>(pool_.get("timeout_flag", sizeof(double)));
+                double hflag = timed_out;
+                if (!flag || check(hipMemcpyAsync(flag, &hflag, sizeof(double), hipMemcpyHostToDevice, stream_), "timeout flag H2D")) return PVIO_ERR_HIP;
+                if (comm_allreduce(comm_, flag, 1, 1, stream_)) return fail(PVIO_ERR_COMM, "all-reduce failed");
+                if (check(hipMemcpyAsync(&hflag, flag, sizeof(double), hipMemcpyDeviceToHost, stream_), "timeout flag D2H")) return PVIO_ERR_HIP;
+                if (check(hipStreamSynchronize(stream_), "timeout flag sync")) return PVIO_ERR_HIP;
+                timed_out = hflag > 0.0;
+            }
+            if (timed_out) {
+                h_ctrl_->done = 1, h_ctrl_->termination = PVIO_TERM_NO_CONVERGENCE;
+                break;
+            }
         }
     }
     if (prof) {

@@ -71,6 +71,8 @@ class HipContext:
         self._check(self.lib.pvio_hip_ba_profile_resident(self.ctx, C.byref(summary.c), C.byref(kt)), "pvio_hip_ba_profile_resident")
         names = ["k_linearize", "k_reduce", "k_dense", "k_backsub"]
         self.last_phase_ticks = {n: [int(x) for x in kt.phase_ticks[i]] for i, n in enumerate(names)}
+        # landmark-sharded solves: the two exchange steps of an iteration (zero on a single GPU)
+        self.last_comm = {"allreduce_system": (kt.comm_ms[0], kt.comm_launches[0]), "allreduce_backsub": (kt.comm_ms[1], kt.comm_launches[1])}
         return {n: (kt.total_ms[i], kt.launches[i]) for i, n in enumerate(names)}
 
     def download(self, state):

@@ -34,7 +34,11 @@ def main():
         return 0
 
     lib.hipemu_set_allreduce(allreduce)
+    timeout = case.endswith("@timeout")  # a time limit that only ONE rank's clock exceeds (PVIO_HIP_DEBUG_TIMEOUT_RANK): nobody may hang
+    case = case.split("@")[0]
     pb = ba_compare.make(O, **ba_compare.CASES[case])
+    if timeout:
+        pb.max_solver_time = 100.0  # a real-time style limit: the clock is looked at every two slots
     shard = pb.shard(rank, world)
     ctx = HipContext(lib=lib, rank=rank, world_size=world, use_graph=False, linearize_mode=linearize_mode)
     uid = (C.c_uint8 * 128)()
@@ -44,7 +48,7 @@ def main():
     l0, l1 = shard.meta["lm_range"] if world > 1 else (0, pb.n_landmarks)
     # marginalize_frame on the sharded window: every rank sums its landmarks' part, the reduced buffer is all-reduced
     marg = {}
-    if pb.use_inertial:
+    if pb.use_inertial and not timeout:
         S, s_, IM, iv = ctx.marginalize(shard, st, 0)
         marg = dict(marg_IM=IM, marg_iv=iv)
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), frame_state=st.frame_state, rho=st.lm_inv_depth, l0=l0, l1=l1,

@@ -45,3 +45,39 @@ def test_sharded_solve_matches_oracle(oracle, case, world, mode):
                 z = np.load(os.path.join(d, "rank%d.npz" % r))
                 np.testing.assert_allclose(z["marg_IM"], IM0, rtol=1e-5, atol=1e-7 * np.abs(IM0).max())
                 np.testing.assert_allclose(z["marg_iv"], iv0, rtol=1e-5, atol=1e-6 * np.abs(iv0).max())
+
+
+@pytest.mark.parametrize("slow_rank", [0, 1])
+def test_sharded_time_limit_is_agreed_across_ranks(oracle, slow_rank):
+    """max_solver_time in a landmark-sharded solve: only ONE rank's clock runs out (PVIO_HIP_DEBUG_TIMEOUT_RANK); the
+    decision is all-reduced, so both ranks stop in the same round -- with the same iteration count, state and NO_CONVERGENCE -- instead
+    of one rank leaving and the other waiting in the next replay's all-reduce for good (the worker would hit the 300 s timeout)."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "hipemu"), "libpvio_hipemu.so"])
+    case, world = "vio_partial", 2
+    with tempfile.TemporaryDirectory() as d:
+        port = 29500 + ((os.getpid() + 7 + slow_rank) % 2000)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(ROOT, "tests", "multi_rank_worker.py"), d, case + "@timeout", "0"]
+        env = dict(os.environ, OMP_NUM_THREADS="1", PVIO_HIP_DEBUG_TIMEOUT_RANK=str(slow_rank))
+        subprocess.run(cmd, check=True, timeout=300, env=env, capture_output=True)
+        z = [np.load(os.path.join(d, "rank%d.npz" % r)) for r in range(world)]
+        assert int(z[0]["iters"]) == int(z[1]["iters"]) and int(z[0]["term"]) == int(z[1]["term"]) == 1  # NO_CONVERGENCE on both
+        assert 1 <= int(z[0]["iters"]) <= 2  # the clock is looked at after the first two slots (iteration 0 + one step)
+        np.testing.assert_array_equal(z[0]["frame_state"], z[1]["frame_state"])
+
+
+def test_time_limit_single_gpu_stops_between_chunks(oracle):
+    """a real-time limit on one GPU (emulated): the slot graph is cut into two-slot chunks and the clock is looked at between them"""
+    from pvio_amd import capi
+    from pvio_amd.solver import HipContext
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "hipemu"), "libpvio_hipemu.so"])
+    lib = capi.load(os.path.join(ROOT, "tests", "hipemu", "libpvio_hipemu.so"))
+    ctx = HipContext(lib=lib, use_graph=True)
+    pb = ba_compare.make(oracle, **ba_compare.CASES["vio_partial"])
+    pb.max_solver_time = 1e-9
+    st, sm = ctx.solve(pb)
+    assert sm.termination == 1 and sm.is_usable and 1 <= sm.num_iterations <= 2
+    pb.max_solver_time = 1.0e6
+    st, sm = ctx.solve(pb)
+    assert sm.num_iterations == 10
+    ctx.close()
