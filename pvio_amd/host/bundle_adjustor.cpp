@@ -210,6 +210,9 @@ void put_m3(std::vector<double> &v, size_t off, const matrix<3> &m) { // -> row-
 // difference at rounding level only.)
 void flatten(Map *map, Config *config, bool use_inertial, bool for_marginalization, Flat &F, ObsCache *cache = nullptr) {
     const int N = (int)map->frame_num();
+    // the device path takes windows of at most PVIO_MAX_FRAMES frames (the reference's sliding window holds 10): say so before
+    // walking a larger map -- and before the pointer table below, which has no room for 256 frames
+    if (N > PVIO_MAX_FRAMES) throw std::out_of_range("window of " + std::to_string(N) + " frames: the HIP back-end takes at most " + std::to_string(PVIO_MAX_FRAMES));
     FrameIndex fidx;
     for (int i = 0; i < N; ++i) fidx.put(map->get_frame(i), i);
     F.frame_fixed.assign(N, 0), F.pre_valid.assign(N, 0);
@@ -552,6 +555,20 @@ struct BundleAdjustor::BundleAdjustorSolver { // the pimpl of bundle_adjustor.h:
     }
 
     void marginalize_frame(Map *map, size_t index) {
+        // Whatever goes wrong below, Map::marginalize_frame erases the victim right after this call (map.cpp:78-87): a prior that
+        // still names it would hold a dangling Frame* and make every later flatten fail or match a recycled address.
+        // So the map never keeps the old prior past a failed marginalization: it is dropped (the window loses its gauge prior
+        // until the next successful one -- the solve stays well-posed through the IMU factors, and says so on stderr).
+        struct DropStalePrior {
+            Map *map;
+            bool armed = true;
+            ~DropStalePrior() {
+                if (armed && map->get_marginalization_factor()) {
+                    std::fprintf(stderr, "[pvio-hip] marginalize_frame failed: the old prior is dropped (it names the frame that is being erased)\n");
+                    map->set_marginalization_factor(nullptr);
+                }
+            }
+        } guard{map};
         pvio_hip_ctx *ctx = process_ctx();
         if (!ctx || index >= map->frame_num() || map->frame_num() < 2) return;
         DefaultConfig dc;
@@ -577,6 +594,7 @@ struct BundleAdjustor::BundleAdjustorSolver { // the pimpl of bundle_adjustor.h:
         for (size_t i = 0; i < map->frame_num(); ++i)
             if (i != index) remaining.emplace_back(map->get_frame(i));
         map->set_marginalization_factor(Factor::create_marginalization_error(sqrt_infomat, sqrt_infovec, std::move(remaining)));
+        guard.armed = false;
     }
 
     double compute_reprojection_error(Map *map) {
@@ -597,7 +615,32 @@ BundleAdjustor::~BundleAdjustor() = default;
 // The reference's methods do not throw (Ceres reports failure through the summary); neither do these: anything the
 // flattening or the standard library raises (bad_alloc, a prior that names a frame outside the window) ends the call as
 // "not usable" / "no new prior" with one line on stderr.
+// The reference's forensics timers at the two seams (bundle_adjustor.cpp:308-319 running average of the solve time, :349-353
+// marginalization time: pvio-pc's "BA Time" graphs, main.cpp:165-167).  Inside the PVIO tree they are the reference's own
+// `forensics` / `make_timer` (forensics.h:96-101, utility/unique_timer.h) and obey PVIO_ENABLE_FORENSICS like there; the standalone
+// test build has neither header and no GUI to feed.
+#ifdef PVIO_HOST_USE_REFERENCE_TYPES
+#define PVIO_HOST_SOLVE_TIMER()                                              \
+    auto ba_timer = make_timer([](double t) {                                \
+        forensics(bundle_adjustor_solve_time, time) {                        \
+            static double avg_time = 0;                                      \
+            static double avg_count = 0;                                     \
+            avg_time = (avg_time * avg_count + t) / (avg_count + 1);         \
+            avg_count += 1.0;                                                \
+            time = avg_time;                                                 \
+        }                                                                    \
+    })
+#define PVIO_HOST_MARG_TIMER()                                               \
+    auto ba_timer = make_timer([](double t) {                                \
+        forensics(bundle_adjustor_marginalization_time, time) { time = t; }  \
+    })
+#else
+#define PVIO_HOST_SOLVE_TIMER() ((void)0)
+#define PVIO_HOST_MARG_TIMER() ((void)0)
+#endif
+
 bool BundleAdjustor::solve(Map *map, Config *config, bool use_inertial) {
+    PVIO_HOST_SOLVE_TIMER();
     try {
         return solver->solve(map, config, use_inertial);
     } catch (const std::exception &e) {
@@ -607,6 +650,7 @@ bool BundleAdjustor::solve(Map *map, Config *config, bool use_inertial) {
 }
 
 void BundleAdjustor::marginalize_frame(Map *map, size_t index) {
+    PVIO_HOST_MARG_TIMER();
     try {
         solver->marginalize_frame(map, index);
     } catch (const std::exception &e) {

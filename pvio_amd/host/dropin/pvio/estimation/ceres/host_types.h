@@ -5,6 +5,6 @@
 #include <pvio/estimation/factor.h>
 #include <pvio/estimation/state.h>
 #include <pvio/map/frame.h>
-#else // standalone: the look-alike declarations of pvio_amd/host/pvio_min.h
+#else // standalone: the look-alike declarations of tests/host/standin/pvio_min.h
 #include "pvio_min.h"
 #endif

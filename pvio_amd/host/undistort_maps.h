@@ -17,7 +17,7 @@
 #include <string>
 #include <vector>
 
-#include "pvio_min.h"
+#include "host_seam.h" // pvio::matrix / vector (the reference's value types, or the test stand-ins)
 
 namespace pvio {
 

@@ -1,11 +1,11 @@
-// headless_shim.cpp -- extern "C" handle on the headless pipeline (pvio_amd/host/headless.*) for the Python tests: feeds a
+// headless_shim.cpp -- extern "C" handle on the headless pipeline (tests/host/standin/headless.*) for the Python tests: feeds a
 // sequence that is already in memory (pinhole images + IMU samples) the way pvio-pc's loop feeds a dataset
 // (pvio-pc/src/main.cpp:207-258) and returns the poses the pipeline reports.
 #include <cstdint>
 #include <cstring>
 
 #include "../../pvio_amd/host/feature_front.h"
-#include "../../pvio_amd/host/headless.h"
+#include "standin/headless.h"
 
 using namespace pvio;
 

@@ -1,3 +1,8 @@
+// TEST SCAFFOLDING (tests/host/standin/, moved out of the product directory in round 3): NOT part of what a PVIO maintainer links.
+// Inside the PVIO tree the reference's own Core / SlidingWindowTracker / pvio-pc stay; this file exists so that the hot path can be
+// driven over a whole sequence in this repository, where the reference cannot be built.  The IMU pairing and the tracker steps
+// below restate reference control-plane code (out of scope) and are kept only as labelled scaffolding.
+//
 // headless.h -- a headless stand-in for pvio::PVIO so that sequences can be run end to end --
 // readers -> front end (GPU) -> PnP -> sliding-window BA (GPU) -> trajectory.tum -- without the reference's core, GUI,
 // OpenCV, Ceres or yaml-cpp.

@@ -9,7 +9,7 @@
 #include <iterator>
 #include <limits>
 
-#include "../../include/pvio_hip.h"
+#include "../../../include/pvio_hip.h"
 #include "dropin/pvio/estimation/ceres/marginalization_error_cost.h"
 #include "dropin/pvio/estimation/ceres/preintegration_error_cost.h"
 #include "dropin/pvio/estimation/ceres/reprojection_error_cost.h"

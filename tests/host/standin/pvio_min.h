@@ -1,3 +1,6 @@
+// TEST SCAFFOLDING (tests/host/standin/, moved out of the product directory in round 3): look-alike declarations so that the adapter
+// sources can RUN in the tests; inside the PVIO tree the reference's own headers are used and nothing here is compiled.
+//
 // pvio_min.h -- the part of the reference's class surface the host seam touches, for builds OUTSIDE the PVIO tree.
 //
 // The adapter sources (bundle_adjustor.cpp, pnp.cpp, feature_front.cpp, feature_tracker.cpp) are written against the

@@ -298,3 +298,52 @@ def test_gpu_solver_reads_nothing_it_did_not_write(oracle, poison):
             ba_compare.check_against_oracle(ctx, oracle, pb)
         finally:
             ctx.close()
+
+
+def test_gpu_dense_hundred_repeats_are_bit_identical(gpu_ctx, oracle):
+    """the 10 x 1000 VIO window solved a hundred times over from the same resident state -- every solve bit-identical to
+    the first (a timing-dependent variant of the dense kernel -- a race between its waves, in the look-ahead form the counters that
+    replaced its barriers -- would show up as a difference) and the first one equal to the oracle's."""
+    pb = ba_compare.make(oracle, **ba_compare.BIG_CASES["metric_10x1000_vio"])
+    ba_compare.check_against_oracle(gpu_ctx, oracle, pb)
+    gpu_ctx.upload(pb)
+    ref = None
+    for k in range(100):
+        sm = BASummary(pb, trace=False)
+        gpu_ctx.solve_resident(sm)
+        st = BAState(pb)
+        gpu_ctx.download(st)
+        cur = (st.frame_state.tobytes(), st.lm_inv_depth.tobytes(), sm.num_iterations, sm.final_cost)
+        if ref is None:
+            ref = cur
+        assert cur == ref, "solve %d differs from the first" % k
+
+
+def _poison_libs():
+    import ctypes as C
+    import os
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "micro")
+    lds, reg = os.path.join(d, "liblds_poison.so"), os.path.join(d, "libreg_poison.so")
+    if not (os.path.exists(lds) and os.path.exists(reg)):
+        pytest.skip("tests/micro/lib{lds,reg}_poison.so not built (build() makes them)")
+    L, R = C.CDLL(lds), C.CDLL(reg)
+    L.lds_poison.argtypes, R.reg_poison.argtypes = [C.c_uint64], [C.c_uint64]
+    return L, R
+
+
+@pytest.mark.parametrize("name", ["vision_small", "vio_partial", "config1_10x200"])
+def test_gpu_solver_reads_no_stale_lds_or_registers(gpu_ctx, oracle, name):
+    """LDS and registers are not cleared between kernels: a kernel that reads what it has not written sees the leftovers of whatever ran
+    before on that CU / SIMD.  Every CU's LDS and every SIMD's VGPRs / AGPRs / SGPRs are filled with NaN, then 1e300, then zero
+    (tests/micro/{lds,reg}_poison.hip) in front of a solve: the result must not move.  (Device MEMORY pre-filled the same way:
+    test_gpu_solver_reads_nothing_it_did_not_write.)"""
+    import struct
+    L, R = _poison_libs()
+    pb = ba_compare.make(oracle, **ba_compare.CASES[name])
+    base = ba_compare.check_against_oracle(gpu_ctx, oracle, pb)
+    st0, _ = gpu_ctx.solve(pb)
+    for val in (float("nan"), 1e300, 0.0):
+        pat = struct.unpack("<Q", struct.pack("<d", val))[0]
+        assert L.lds_poison(pat) == 0 and R.reg_poison(pat) == 0
+        st1, _ = gpu_ctx.solve(pb)
+        assert (st1.frame_state == st0.frame_state).all() and (st1.lm_inv_depth == st0.lm_inv_depth).all(), (name, val, base)

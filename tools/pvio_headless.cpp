@@ -2,7 +2,7 @@
 //   DatasetReader::next() -> read_gyroscope / read_accelerometer / read_image -> HeadlessVio::track_* -> trajectory.tum
 // Usage: pvio_headless <euroc://DIR | tum://DIR> <ground_truth.tum> [trajectory.tum] [max_frames]
 //   ground_truth.tum  "t px py pz qx qy qz qw" lines (body poses): used ONLY to bootstrap the first window, in place of the
-//                     reference's SfM initializer (see pvio_amd/host/headless.h)
+//                     reference's SfM initializer (see tests/host/standin/headless.h)
 // Camera / IMU constants are those of config/euroc.yaml and config/tum-vi.yaml, chosen by the URI scheme.
 #include <cstdio>
 #include <cstdlib>
@@ -12,7 +12,7 @@
 #include <string>
 
 #include "../pvio_amd/host/dataset_reader.h"
-#include "../pvio_amd/host/headless.h"
+#include "../tests/host/standin/headless.h"
 
 using namespace pvio;
 
