@@ -139,6 +139,14 @@ typedef struct pvio_ba_problem {
     const int32_t *rot_prior_frame;    /* [R]    window index                                            */
     const double *rot_prior_q0;        /* [R][4] x y z w                                                 */
     const double *rot_prior_sqrt_info; /* [R][9] W, row-major                                            */
+
+    /* Duplicate residual blocks (bundle_adjustor.cpp:165-179).  The reference adds the reprojection blocks of every track of a
+     * plane with fewer than 20 tracks a second time -- once more per such plane the track sits in -- on top of the blocks the track
+     * got at :142-161 as a VALID non-PLANE track.  Ceres sums duplicate blocks: a track listed m times weighs m times in the cost,
+     * the gradient and the normal equations (each copy robustified on its own, so the factor applies AFTER the loss function).
+     * lm_multiplicity[l] = m >= 1 for landmark l; NULL = every landmark once.  Not used by pvio_hip_ba_marginalize
+     * (marginalize_frame adds each block once, :455-510) nor by the quality pass. */
+    const int32_t *lm_multiplicity;    /* [M] or NULL                                                    */
 } pvio_ba_problem;
 
 /* In/out states, updated in place exactly like Frame::pose/motion and Track::landmark.inv_depth. */

@@ -196,11 +196,14 @@ struct Evaluator {
                                   pb.sqrt_inv_cov + 4 * t, r, lin ? J : nullptr);
                 double s = r[0] * r[0] + r[1] * r[1];
                 if (!std::isfinite(s)) ok = false;
-                cost += 0.5 * std::log(1.0 + s); // rho[0] = b log(1 + s c), a = 1
+                // duplicate residual blocks (bundle_adjustor.cpp:165-179): Ceres sums m identical blocks, each robustified on its own
+                const double mult = pb.lm_multiplicity ? (double)pb.lm_multiplicity[l] : 1.0;
+                cost += mult * (0.5 * std::log(1.0 + s)); // rho[0] = b log(1 + s c), a = 1
                 if (lin) {
                     for (int k = 0; k < 26; ++k)
                         if (!std::isfinite(J[k])) ok = false;
                     double sw = std::sqrt(std::max(DBL_MIN, 1.0 / (1.0 + s))); // Corrector: rho'' < 0 -> sqrt(rho')
+                    if (mult != 1.0) sw *= std::sqrt(mult);                       // m (J^T J), m (J^T r)
                     for (int k = 0; k < 26; ++k) J[k] *= sw;
                     r[0] *= sw;
                     r[1] *= sw;

@@ -56,6 +56,8 @@ typedef struct ref_tracks {
                                     tracks up to k members (the flat pvio_ba_problem lists plane FACTORS, i.e. tracks of planes the
                                     reference found >= 20 tracks in: bundle_adjustor.cpp:180) */
     int32_t reserved;
+    const uint8_t *keep_small;   /* [P] or NULL: 1 = this plane is NOT padded (a plane with < 20 tracks: its tracks get their reprojection
+                                    blocks a second time, bundle_adjustor.cpp:165-179) */
 } ref_tracks;
 
 // Raw IMU samples per frame (BundleAdjustorSolver::solve re-integrates them at :224): samples ptr[j] .. ptr[j+1]-1 lie between
@@ -244,6 +246,7 @@ int build_window(Window &W, const pvio_ba_problem *pb, const double *frame_state
             size_t members = 0;
             for (int t = 0; t < T; ++t)
                 if (trk->membership[(size_t)p * T + t]) W.planes[p]->tracks.insert(W.tracks[t]), ++members;
+            if (trk->keep_small && trk->keep_small[p]) continue;
             for (; members > 0 && members < (size_t)trk->pad_small_planes; ++members) W.planes[p]->tracks.insert(W.map->create_track());
         }
     }

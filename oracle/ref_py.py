@@ -25,7 +25,8 @@ u8p, i32p, i64p = C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.POINTER(C.c_int6
 class RefTracksC(C.Structure):
     _fields_ = [("n_tracks", C.c_int32), ("n_planes", C.c_int32), ("obs_ptr", i32p), ("obs_frame", i32p), ("obs_z", dp),
                 ("inv_depth", dp), ("valid", u8p), ("plane", u8p), ("life", i64p), ("best_plane", i32p), ("quality", dp),
-                ("plane_normal", dp), ("plane_distance", dp), ("membership", u8p), ("pad_small_planes", C.c_int32), ("reserved", C.c_int32)]
+                ("plane_normal", dp), ("plane_distance", dp), ("membership", u8p), ("pad_small_planes", C.c_int32), ("reserved", C.c_int32),
+                ("keep_small", u8p)]
 
 
 class RefImuC(C.Structure):
@@ -105,7 +106,7 @@ class Tracks:
     """The track table of a window (all observations of every track, anchor first)."""
 
     def __init__(self, ptr, frame, z, inv_depth, valid, plane, life=None, best_plane=None, normal=None, distance=None, membership=None,
-                 pad_small_planes=0):
+                 pad_small_planes=0, keep_small=None):
         T = len(ptr) - 1
         self.ptr = np.ascontiguousarray(ptr, np.int32)
         self.frame = np.ascontiguousarray(frame, np.int32)
@@ -121,6 +122,7 @@ class Tracks:
         P = len(self.distance)
         self.membership = np.ascontiguousarray(membership if membership is not None else np.zeros((P, T)), np.uint8).reshape(P, T).copy()
         self.pad_small_planes = int(pad_small_planes)
+        self.keep_small = np.ascontiguousarray(keep_small if keep_small is not None else np.zeros(P), np.uint8)
 
     def as_c(self):
         c = RefTracksC()
@@ -131,6 +133,7 @@ class Tracks:
         c.plane_normal, c.plane_distance = _d(self.normal), _d(self.distance)
         c.membership = self.membership.ctypes.data_as(u8p)
         c.pad_small_planes = self.pad_small_planes
+        c.keep_small = self.keep_small.ctypes.data_as(u8p)
         return c
 
 
@@ -165,11 +168,25 @@ def tracks_of_problem(pb, inv_depth=None):
     plane = 1 - valid
     life = np.concatenate([np.diff(np.asarray(ptr))[:M], np.zeros(Pn)]).astype(np.int64)
     keys = list(planes.keys())
-    membership = np.zeros((len(keys), T), np.uint8)
+    normals, dists = [k[0] for k in keys], [k[1] for k in keys]
+    rows = [np.zeros(T, np.uint8) for _ in keys]
     for k in range(Pn):
-        membership[best[M + k], M + k] = 1
-    t = Tracks(ptr, frame, np.array(z).reshape(-1, 2), rho, valid, plane, life, best, np.array([k[0] for k in keys]).reshape(-1, 3),
-               np.array([k[1] for k in keys]), membership, pad_small_planes=20)
+        rows[best[M + k]][M + k] = 1
+    keep_small = [0] * len(keys)
+    # lm_multiplicity (duplicate residual blocks, bundle_adjustor.cpp:165-179): a landmark listed m times is a VALID non-PLANE track
+    # that sits in m - 1 planes of fewer than 20 tracks -- groups of at most 19 such tracks per plane; where the plane lies does not
+    # enter the solve (a small plane has no plane-distance factor; its tracks are VALID, so the re-validation pass skips them)
+    mult = getattr(pb, "lm_multiplicity", None)
+    if mult is not None:
+        for level in range(2, int(np.max(mult)) + 1 if M else 2):
+            idx = np.nonzero(np.asarray(mult) >= level)[0]
+            for g in range(0, len(idx), 19):
+                row = np.zeros(T, np.uint8)
+                row[idx[g:g + 19]] = 1
+                rows.append(row), normals.append((0.0, 0.0, 1.0)), dists.append(100.0 + len(rows)), keep_small.append(1)
+    membership = np.stack(rows) if rows else np.zeros((0, T), np.uint8)
+    t = Tracks(ptr, frame, np.array(z).reshape(-1, 2), rho, valid, plane, life, best, np.array(normals).reshape(-1, 3),
+               np.array(dists), membership, pad_small_planes=20, keep_small=keep_small)
     return t, np.arange(M)
 
 

@@ -41,6 +41,7 @@ class BAProblemC(C.Structure):
         ("max_iterations", C.c_int32), ("reserved0", C.c_int32), ("max_solver_time", C.c_double),
         ("n_rot_priors", C.c_int32), ("reserved1", C.c_int32),
         ("rot_prior_frame", c_int32_p), ("rot_prior_q0", c_double_p), ("rot_prior_sqrt_info", c_double_p),
+        ("lm_multiplicity", c_int32_p),
     ]
 
 

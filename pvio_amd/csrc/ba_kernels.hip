@@ -479,10 +479,14 @@ __device__ __forceinline__ void role_landmarks(const View &v, double *lds, const
             reproj_eval<true>(frec + t * kFrameRec, frec + a * kFrameRec, rho_eval[s], v.lm_zref[2 * l], v.lm_zref[2 * l + 1],
                               v.obs_z[2 * (size_t)o], v.obs_z[2 * (size_t)o + 1], r, Jt, Jr, Jd);
             const double sq = r[0] * r[0] + r[1] * r[1];
-            s_cost += 0.5 * log(1.0 + sq);                                  // CauchyLoss(1): rho(s) = log(1 + s)
+            // duplicate residual blocks (bundle_adjustor.cpp:165-179): m copies of the block, each robustified on its own, summed by
+            // Ceres = the robustified block scaled by sqrt(m), its cost by m.  marginalize_frame lists every block once (:455-510).
+            const double mult = (v.lm_mult && !marg) ? v.lm_mult[l] : 1.0;
+            s_cost += mult * (0.5 * log(1.0 + sq));                         // CauchyLoss(1): rho(s) = log(1 + s)
             double bad = isfinite(sq) ? 0.0 : 1.0;
             // Corrector, rho'' < 0: sqrt(rho'); marginalization uses the un-robustified Jacobians (:487-510) of ALL blocks
-            const double sw = marg ? 1.0 : sqrt(fmax(DBL_MIN, 1.0 / (1.0 + sq)));
+            double sw = marg ? 1.0 : sqrt(fmax(DBL_MIN, 1.0 / (1.0 + sq)));
+            if (mult != 1.0) sw *= sqrt(mult);
             const bool tfix = !marg && v.frame_fixed[t] != 0, afix = !marg && v.frame_fixed[a] != 0;
             r[0] *= sw, r[1] *= sw, Jd[0] *= sw, Jd[1] *= sw;
 #pragma unroll

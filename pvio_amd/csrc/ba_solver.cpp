@@ -275,6 +275,19 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st) {
     stage.add(pb->lm_anchor_frame, (size_t)M, &v.lm_anchor);
     stage.add(pb->lm_obs_ptr, (size_t)M + 1, &v.lm_ptr);
     stage.add(pb->lm_anchor_z, (size_t)M * 2, &v.lm_zref);
+    std::vector<double> lm_mult; // duplicate residual blocks (bundle_adjustor.cpp:165-179); staged only when some landmark counts twice
+    if (pb->lm_multiplicity) {
+        bool any = false;
+        for (int l = 0; l < M; ++l) {
+            if (pb->lm_multiplicity[l] < 1) return fail(PVIO_ERR_INVALID_ARGUMENT, "lm_multiplicity must be >= 1");
+            any |= pb->lm_multiplicity[l] != 1;
+        }
+        if (any) {
+            lm_mult.resize((size_t)M);
+            for (int l = 0; l < M; ++l) lm_mult[(size_t)l] = (double)pb->lm_multiplicity[l];
+        }
+    }
+    stage.add(lm_mult.empty() ? (const double *)nullptr : lm_mult.data(), lm_mult.size(), &v.lm_mult);
     stage.add(pb->obs_frame, (size_t)F, &v.obs_frame);
     stage.add(pb->obs_z, (size_t)F * 2, &v.obs_z);
     stage.add(obs_lm.data(), (size_t)F, &v.obs_lm);
@@ -413,6 +426,7 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st) {
             if (it.src && it.bytes >= kDirect && check(hipMemcpyAsync(slab + it.off, it.src, it.bytes, hipMemcpyHostToDevice, stream_), "H2D inputs"))
                 return PVIO_ERR_HIP;
     }
+    if (lm_mult.empty()) v.lm_mult = nullptr; // no duplicates: the kernels take the unscaled path
     if (dm.prior_n > 0 && check(launch_prior_prep(v.prior_S, v.prior_s, (int)Dp, Lambda, eta, ST, stream_), "k_prior_prep")) return PVIO_ERR_HIP;
 
     const bool dims_changed = std::memcmp(&v.dm, &v_.dm, sizeof(Dims)) != 0;

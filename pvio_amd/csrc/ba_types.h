@@ -112,6 +112,7 @@ struct View { // passed by value to every kernel
     const double *cam_ext, *imu_ext, *sic, *intr;
     const int32_t *lm_anchor, *lm_ptr, *obs_frame, *obs_lm;
     const double *lm_zref, *obs_z;
+    const double *lm_mult; // [M] multiplicity of the landmark's residual blocks as a double, or null (every block once)
     const int32_t *chunk_lm;      // [n_chunks+1] landmark ranges
     const int32_t *task_desc;     // [n_tasks] packed fi | fj<<8 | si<<16 | sj<<17
     const uint8_t *pre_valid;     // [N]

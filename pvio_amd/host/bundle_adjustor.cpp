@@ -55,7 +55,7 @@ pvio_hip_ctx *process_ctx() {
 struct Flat { // owns the arrays a pvio_ba_problem points into
     std::vector<uint8_t> frame_fixed, pre_valid;
     std::vector<double> cam, imu, sic, intr, fstate, lm_z, obs_z, rho, pre_delta, pre_U, pre_jac, prior_S, prior_s, prior_lin, plane_z, plane_n, plane_d;
-    std::vector<int32_t> lm_anchor, lm_ptr, obs_frame, prior_frames, plane_ptr, plane_frame;
+    std::vector<int32_t> lm_anchor, lm_ptr, obs_frame, prior_frames, plane_ptr, plane_frame, lm_mult;
     std::vector<Track *> lm_track; // landmark index -> track (write-back)
     std::vector<double> quality;
     std::vector<uint8_t> valid;
@@ -319,9 +319,33 @@ void flatten(Map *map, Config *config, bool use_inertial, bool for_marginalizati
             add_landmark(track);
         }
     }
-    for (size_t i = 0; i < map->plane_num() && !for_marginalization; ++i)
-        if (map->get_plane(i)->tracks.size() < 20)
-            for (Track *t : map->get_plane(i)->tracks) add_landmark(t);
+    // Tracks of planes with fewer than 20 members get their reprojection blocks (again) at :165-179 -- whatever their flags, once per
+    // such plane.  A track that already has its blocks from the loop above (VALID, not PLANE), or from another small plane, is listed
+    // twice in the ceres::Problem and weighs twice: that is the landmark's multiplicity (include/pvio_hip.h).
+    F.lm_mult.clear();
+    if (!for_marginalization) {
+        bool any_small = false;
+        for (size_t i = 0; i < map->plane_num(); ++i) any_small |= map->get_plane(i)->tracks.size() < 20 && !map->get_plane(i)->tracks.empty();
+        if (any_small) {
+            std::unordered_map<const Track *, size_t> index;
+            for (size_t l = 0; l < F.lm_track.size(); ++l) index.emplace(F.lm_track[l], l);
+            F.lm_mult.assign(F.lm_track.size(), 1);
+            for (size_t i = 0; i < map->plane_num(); ++i) {
+                if (map->get_plane(i)->tracks.size() >= 20) continue;
+                for (Track *t : map->get_plane(i)->tracks) {
+                    auto it = index.find(t);
+                    if (it != index.end()) {
+                        F.lm_mult[it->second] += 1;
+                        continue;
+                    }
+                    const size_t before = F.lm_track.size();
+                    add_landmark(t);
+                    if (F.lm_track.size() > before) index.emplace(t, before), F.lm_mult.push_back(1);
+                }
+            }
+            if (std::all_of(F.lm_mult.begin(), F.lm_mult.end(), [](int32_t m) { return m == 1; })) F.lm_mult.clear();
+        }
+    }
     // plane-distance factors (:180-195)
     F.plane_ptr.assign(1, 0), F.plane_frame.clear(), F.plane_z.clear(), F.plane_n.clear(), F.plane_d.clear();
     for (auto &tp : plane_factors) {
@@ -390,6 +414,7 @@ void flatten(Map *map, Config *config, bool use_inertial, bool for_marginalizati
     pb.preint_valid = F.pre_valid.data(), pb.preint_delta = F.pre_delta.data(), pb.preint_sqrt_inv_cov = F.pre_U.data(), pb.preint_jacobian = F.pre_jac.data();
     pb.prior_n = (int32_t)F.prior_frames.size(), pb.prior_frames = F.prior_frames.data();
     pb.prior_S = F.prior_S.data(), pb.prior_s = F.prior_s.data(), pb.prior_lin_state = F.prior_lin.data();
+    pb.lm_multiplicity = F.lm_mult.empty() ? nullptr : F.lm_mult.data();
     pb.n_plane_factors = (int32_t)F.plane_d.size();
     pb.plane_obs_ptr = F.plane_ptr.data(), pb.plane_obs_frame = F.plane_frame.data(), pb.plane_obs_z = F.plane_z.data();
     pb.plane_normal = F.plane_n.data(), pb.plane_distance = F.plane_d.data();

@@ -53,6 +53,8 @@ class BAProblem:
         self.rot_prior_frame = np.zeros(0, np.int32)
         self.rot_prior_q0 = np.zeros((0, 4))
         self.rot_prior_sqrt_info = np.zeros((0, 9))
+        # duplicate residual blocks (bundle_adjustor.cpp:165-179): how often each landmark's blocks are listed; None = once
+        self.lm_multiplicity = None
         self.max_iterations = 10
         self.max_solver_time = 1.0e6
         # states (initial guess) and, for synthetic windows, the ground truth
@@ -94,6 +96,8 @@ class BAProblem:
             setattr(self, name, i32(getattr(self, name)))
         for name in ["frame_fixed", "preint_valid"]:
             setattr(self, name, u8(getattr(self, name)))
+        if self.lm_multiplicity is not None:
+            self.lm_multiplicity = i32(self.lm_multiplicity)
 
     def as_c(self):
         """Returns a `pvio_ba_problem` whose pointers alias this object's arrays (keep `self` alive)."""
@@ -134,6 +138,7 @@ class BAProblem:
         pb.rot_prior_frame = _p(self.rot_prior_frame, ip)
         pb.rot_prior_q0 = _p(self.rot_prior_q0, dp)
         pb.rot_prior_sqrt_info = _p(self.rot_prior_sqrt_info, dp)
+        pb.lm_multiplicity = _p(self.lm_multiplicity, ip)
         return pb
 
     def shard(self, rank, world):
@@ -157,6 +162,8 @@ class BAProblem:
         out.obs_frame = self.obs_frame[o0:o1].copy()
         out.obs_z = self.obs_z[o0:o1].copy()
         out.lm_inv_depth = self.lm_inv_depth[l0:l1].copy()
+        if self.lm_multiplicity is not None:
+            out.lm_multiplicity = self.lm_multiplicity[l0:l1].copy()
         if self.truth_inv_depth is not None:
             out.truth_inv_depth = self.truth_inv_depth[l0:l1].copy()
         Pn = self.n_plane_factors

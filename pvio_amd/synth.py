@@ -105,7 +105,7 @@ def _pose(t):
 
 def make_window(n_frames=10, n_landmarks=1000, use_inertial=False, visibility=None, plane_fraction=0.0,
                 seed=SEED, preintegrate=None, kf_dt=0.25, imu_rate=200.0, perturb=True, max_iterations=10,
-                bias_init="near_truth", perturb_scale=None, plane_outliers=0, plane_outlier_offset=0.3, rot_prior_frames=()):
+                bias_init="near_truth", perturb_scale=None, plane_outliers=0, plane_outlier_offset=0.3, rot_prior_frames=(), duplicate_fraction=0.0):
     """Builds a BAProblem.  `preintegrate(t, w, a, t_end, bg, ba, noise_dict) -> (delta11, cov225, U225, jac45)`
     is required when use_inertial (the product's pvio_preintegrate or the oracle's).
 
@@ -291,6 +291,12 @@ def make_window(n_frames=10, n_landmarks=1000, use_inertial=False, visibility=No
         pb.rot_prior_q0 = np.stack([qmul(truth[f, 0:4], qexp(noise_r[k])) for k, f in enumerate(rot_prior_frames)])
         pb.rot_prior_q0 /= np.linalg.norm(pb.rot_prior_q0, axis=1, keepdims=True)
         pb.rot_prior_sqrt_info = np.stack([(np.eye(3) + mix[k]) / np.deg2rad(0.3) for k in range(nrp)]).reshape(nrp, 9)
+    if duplicate_fraction > 0:
+        # duplicate residual blocks (bundle_adjustor.cpp:165-179): tracks of planes with fewer than 20 members get their reprojection
+        # blocks a second time (a third, when two such planes hold them).  Own random stream, like the rotation priors.
+        rd = Rng(seed + 7177)
+        u = rd.uniform(pb.n_landmarks)
+        pb.lm_multiplicity = (1 + (u < duplicate_fraction).astype(np.int32) + (u < 0.25 * duplicate_fraction).astype(np.int32)).astype(np.int32)
     pb.frame_state = init
     pb.lm_inv_depth = rho0
     pb.truth_frame_state = truth

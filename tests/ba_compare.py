@@ -18,6 +18,9 @@ CASES = {
     "vision_rot_prior": dict(n_frames=5, n_landmarks=40, visibility=4, rot_prior_frames=(0, 2, 4)),
     "vio_rot_prior": dict(n_frames=5, n_landmarks=40, use_inertial=True, visibility=4, rot_prior_frames=(1, 3, 4)),
     "vio_zero_bias_quirk": dict(n_frames=4, n_landmarks=30, use_inertial=True, bias_init="zero", perturb_scale=1.0),
+    # duplicate residual blocks (bundle_adjustor.cpp:165-179): tracks of planes with fewer than 20 members are listed twice / three times
+    "vision_duplicate_blocks": dict(n_frames=5, n_landmarks=50, visibility=4, duplicate_fraction=0.4),
+    "vio_duplicate_blocks": dict(n_frames=6, n_landmarks=70, use_inertial=True, visibility=4, duplicate_fraction=0.3),
     # BASELINE.json configs[1]: 10 KF x 200 landmarks, reprojection factors only
     "config1_10x200": dict(n_frames=10, n_landmarks=200),
     "vio_11_frames_lds_limit": dict(n_frames=11, n_landmarks=80, use_inertial=True, visibility=6),   # reduced system 165: largest that stays in LDS
@@ -36,6 +39,7 @@ BIG_CASES = {
     "metric_10x1000_vio": dict(n_frames=10, n_landmarks=1000, use_inertial=True),
     "vio_plane_10x600": dict(n_frames=10, n_landmarks=600, use_inertial=True, plane_fraction=0.4, visibility=6),
     "vio_rot_prior_10x1000": dict(n_frames=10, n_landmarks=1000, use_inertial=True, rot_prior_frames=(2, 5, 9)),
+    "vio_duplicates_10x1000": dict(n_frames=10, n_landmarks=1000, use_inertial=True, duplicate_fraction=0.1),
 }
 
 

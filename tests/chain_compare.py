@@ -1,0 +1,153 @@
+"""Comparison of chain record streams (tests/host/chain_log.h): the product chain against the oracle, record by record, in two ways.
+
+REPLAY (records 4 / 5 / 7 of the product chain's own log): every window solve, marginalization and PnP solve of the product chain is
+run again by the oracle ON THE SAME INPUTS.  This is the north_star's bar as it stands: identical accept / reject trace, iteration
+counts and termination, states after EVERY iteration within 1e-6 (observed ~1e-9), S^T S / S^T s of the new prior equal.
+
+FREE RUNNING (the product chain's log against the oracle chain's log): the two chains see different inputs from the first tracked
+frame on -- the LK tracker's float accumulators are reduced in another order on the device, its keypoints differ by up to 1e-3 px
+per call -- and nothing downstream is re-synchronized.  Required here:
+  per camera frame   IDENTICAL frame ids, track id and track length of every keypoint (= the same tracks survived LK, the 20 px border,
+                     the F-RANSAC and the Poisson-disk selection, the same corners were added, in the same order); new corners (integer
+                     pixels) bit-identical; tracked keypoints within FREE_KLT_PX
+  per window solve   IDENTICAL shapes (frames, landmarks, factors), termination, iteration counts, accept / reject trace, depth-gate mask;
+                     states after every iteration within FREE_STATE (inverse depths triangulated over a few pixels of parallax move by
+                     1e-5 when a keypoint moves by 1e-3 px: that, not the solver, sets this number)
+  per PnP / marginalization  identical shapes and iteration counts, results within the same tolerance
+  trajectory.tum     same poses at the same times within FREE_POSE."""
+import numpy as np
+
+from chain_run import parse_log
+
+REPLAY_STATE = 1.0e-6    # north_star: pose / landmark states after every trust-region iteration
+FREE_KLT_PX = 2.0e-2     # observed 4e-3 over 60 frames
+FREE_STATE = 5.0e-4      # observed 2e-5 .. 1e-4 (inverse depths)
+FREE_POSE = 5.0e-5       # observed 5e-6
+FREE_COST_RTOL, FREE_COST_ATOL = 2.0e-2, 1.0e-3  # a sum of squared residuals of a few hundredths of a pixel
+MARG_FLOOR = 1.0e-7      # absolute floor under the entries of S^T S / S^T s (the reference's own eigenvalue cut is 1e-8)
+
+
+def _solve(tag, k, Ia, Da, Ib, Db, state_tol, cost_rtol, cost_atol, info):
+    assert (Ia == Ib).all(), "%s window solve %d: shapes / termination / trace flags / depth gate differ:\n%s\n%s" % (tag, k, Ia[:10], Ib[:10])
+    N, M, ln = int(Ia[0]), int(Ia[1]), int(Ia[9])
+    S = 16 * N + M
+    np.testing.assert_allclose(Da[:2], Db[:2], rtol=cost_rtol, atol=cost_atol)
+    ta, tb = Da[2:2 + 7 * ln].reshape(ln, 7), Db[2:2 + 7 * ln].reshape(ln, 7)
+    np.testing.assert_allclose(ta[:, 0], tb[:, 0], rtol=cost_rtol, atol=cost_atol)  # cost
+    np.testing.assert_allclose(ta[:, 6], tb[:, 6], rtol=1e-12)                      # mu: powers of the same constants
+    if state_tol <= REPLAY_STATE:
+        np.testing.assert_allclose(ta[:, 5], tb[:, 5], rtol=1e-5)                   # trust-region radius
+    o = 2 + 7 * ln
+    sa, sb = Da[o:o + ln * S].reshape(ln, S), Db[o:o + ln * S].reshape(ln, S)
+    d = float(np.abs(sa - sb).max())
+    info["max_state_" + tag] = max(info.get("max_state_" + tag, 0.0), d)
+    assert d <= state_tol, "%s window solve %d: states differ by %.3g after iteration %d" % (tag, k, d, int(np.abs(sa - sb).max(1).argmax()))
+    o += ln * S
+    assert float(np.abs(Da[o:o + S] - Db[o:o + S]).max()) <= state_tol
+    qa, qb = Da[o + S:], Db[o + S:]
+    np.testing.assert_allclose(qa, qb, rtol=0, atol=1e-6 if state_tol <= REPLAY_STATE else 2e-2)  # mean pixel error of each track
+    flags = Ia[10:10 + 3 * ln].reshape(ln, 3)
+    return int(Ia[7]), int((flags[1:, 2] == 0).sum())
+
+
+def _marg(tag, k, Ia, Da, Ib, Db, rtol):
+    assert (Ia == Ib).all() and Ia[3] == 0, "%s marginalization %d: %s %s" % (tag, k, Ia, Ib)
+    D = 15 * int(Ia[2])
+    Sa, sa, Sb, sb = Da[:D * D].reshape(D, D), Da[D * D:], Db[:D * D].reshape(D, D), Db[D * D:]
+    Ha, Hb = Sa.T @ Sa, Sb.T @ Sb
+    # entry (i, j) against sqrt(H_ii H_jj); marginalize_frame zeroes eigenvalues below 1e-8 (bundle_adjustor.cpp:586-588), so entries of
+    # that size are whatever the eigen-solver's rounding left of them on either side: an absolute floor of a few 1e-8 goes with the ratio
+    scale = np.sqrt(np.outer(np.diag(Ha), np.diag(Ha)))
+    excess = np.abs(Ha - Hb) - MARG_FLOOR
+    d = float((excess / (scale + 1e-300)).max())
+    i, j = np.unravel_index(int((excess / (scale + 1e-300)).argmax()), Ha.shape)
+    assert d <= rtol, "%s marginalization %d: information matrix differs by %.3g of sqrt(H_ii H_jj) at (%d, %d): %.6e vs %.6e, diagonal %.3e %.3e" % (
+        tag, k, d, i, j, Ha[i, j], Hb[i, j], Ha[i, i], Ha[j, j])
+    ga, gb = Sa.T @ sa, Sb.T @ sb
+    gscale = np.sqrt(np.diag(Ha)) * max(1.0, float(np.linalg.norm(sa)))
+    dg = float(((np.abs(ga - gb) - MARG_FLOOR) / (gscale + 1e-300)).max())
+    assert dg <= rtol, "%s marginalization %d: information vector differs by %.3g" % (tag, k, dg)
+    return max(d, 0.0)
+
+
+def _pnp(tag, k, Ia, Da, Ib, Db, tol, same_inputs):
+    if same_inputs:
+        assert (Ia == Ib).all(), "%s PnP %d: %s %s" % (tag, k, Ia, Ib)
+        assert (Da[:16] == Db[:16]).all()
+    else:
+        assert (Ia[:3] == Ib[:3]).all(), "%s PnP %d: factor counts differ %s %s" % (tag, k, Ia, Ib)
+    d = float(np.abs(Da[16:32] - Db[16:32]).max())
+    assert d <= tol, "%s PnP %d: states differ by %.3g" % (tag, k, d)
+    return d
+
+
+def compare_replay(log):
+    """records 2/3/6 of the product chain against the oracle's replay 4/5/7 that follows each of them"""
+    R = parse_log(log)
+    info = dict(solves=0, iterations=0, rejected_steps=0, margs=0, pnps=0, max_marg=0.0, max_pnp=0.0)
+    pair = {2: 4, 3: 5, 6: 7}
+    i = 0
+    while i < len(R):
+        tag, Ia, Da = R[i]
+        assert tag > 0, "a call failed in the chain (tag %d)" % tag
+        if tag in pair:
+            assert i + 1 < len(R) and R[i + 1][0] == pair[tag], "record %d (tag %d) is not followed by its replay" % (i, tag)
+            _, Ib, Db = R[i + 1]
+            if tag == 2:
+                it, rej = _solve("replay", info["solves"], Ia, Da, Ib, Db, REPLAY_STATE, 1e-7, 1e-12, info)
+                info["solves"] += 1
+                info["iterations"] += it
+                info["rejected_steps"] += rej
+            elif tag == 3:
+                info["max_marg"] = max(info["max_marg"], _marg("replay", info["margs"], Ia, Da, Ib, Db, 1e-7))
+                info["margs"] += 1
+            else:
+                info["max_pnp"] = max(info["max_pnp"], _pnp("replay", info["pnps"], Ia, Da, Ib, Db, REPLAY_STATE, True))
+                info["pnps"] += 1
+            i += 2
+        else:
+            i += 1
+    return info
+
+
+def compare_free(log_product, log_oracle, fx, tum_product=None, tum_oracle=None):
+    A = [r for r in parse_log(log_product) if abs(r[0]) not in (4, 5, 7)]
+    B = parse_log(log_oracle)
+    assert [r[0] for r in A] == [r[0] for r in B], "the two chains did not make the same sequence of calls"
+    info = dict(frames=0, solves=0, margs=0, pnps=0, iterations=0, rejected_steps=0, tracked=0, new=0, max_kp_px=0.0, max_pose=0.0, max_marg=0.0, max_pnp=0.0)
+    for (tag, Ia, Da), (_, Ib, Db) in zip(A, B):
+        assert tag > 0, "a call failed in the chains (tag %d)" % tag
+        if tag == 1:
+            assert (Ia == Ib).all(), "frame %d: track ids / lengths differ" % Ia[0]
+            n = int(Ia[4])
+            ka, kb = Da[:2 * n].reshape(n, 2), Db[:2 * n].reshape(n, 2)
+            fresh = Ia[5:].reshape(n, 2)[:, 1] == 0  # a corner detected in this frame: no track yet (Frame::detect_keypoints only appends keypoints)
+            assert (ka[fresh] == kb[fresh]).all(), "frame %d: new corners differ" % Ia[0]
+            if (~fresh).any():
+                d = float(np.abs(ka[~fresh] - kb[~fresh]).max() * fx)
+                info["max_kp_px"] = max(info["max_kp_px"], d)
+                assert d <= FREE_KLT_PX, "frame %d: tracked keypoints differ by %.3g px" % (Ia[0], d)
+            d = float(np.abs(Da[2 * n:] - Db[2 * n:]).max())
+            info["max_pose"] = max(info["max_pose"], d)
+            assert d <= FREE_POSE, "frame %d: reported pose differs by %.3g" % (Ia[0], d)
+            info["frames"] += 1
+            info["tracked"] += int((~fresh).sum())
+            info["new"] += int(fresh.sum())
+        elif tag == 2:
+            it, rej = _solve("free", info["solves"], Ia, Da, Ib, Db, FREE_STATE, FREE_COST_RTOL, FREE_COST_ATOL, info)
+            info["solves"] += 1
+            info["iterations"] += it
+            info["rejected_steps"] += rej
+        elif tag == 3:
+            info["max_marg"] = max(info["max_marg"], _marg("free", info["margs"], Ia, Da, Ib, Db, 1e-2))
+            info["margs"] += 1
+        elif tag == 6:
+            info["max_pnp"] = max(info["max_pnp"], _pnp("free", info["pnps"], Ia, Da, Ib, Db, FREE_STATE, False))
+            info["pnps"] += 1
+    if tum_product and tum_oracle:
+        ta, tb = np.loadtxt(tum_product, ndmin=2), np.loadtxt(tum_oracle, ndmin=2)
+        assert ta.shape == tb.shape and ta.shape[0] > 0 and (ta[:, 0] == tb[:, 0]).all()
+        info["tum_max_diff"] = float(np.abs(ta - tb).max())
+        info["tum_poses"] = int(ta.shape[0])
+        assert info["tum_max_diff"] <= FREE_POSE, "trajectory.tum files differ by %.3g" % info["tum_max_diff"]
+    return info

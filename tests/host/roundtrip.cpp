@@ -114,6 +114,26 @@ void build_map(const pvio_ba_problem *pb, const pvio_ba_state *st, Map &map, std
         pl->tracks.insert(t);
         if (plane_tracks) plane_tracks->push_back(t);
     }
+    // lm_multiplicity -> planes with fewer than 20 tracks (bundle_adjustor.cpp:165-179): a landmark listed m times sits in m - 1 of
+    // them, at most 19 landmarks per plane (same construction as oracle/ref_py.py::tracks_of_problem).  Put into the map empty, like
+    // every plane here: Map::put_plane of the reference merges planes that share tracks (map.cpp:140-160).
+    if (pb->lm_multiplicity) {
+        int top = 1;
+        for (int l = 0; l < pb->n_landmarks; ++l) top = std::max(top, (int)pb->lm_multiplicity[l]);
+        for (int level = 2; level <= top; ++level) {
+            std::vector<int> idx;
+            for (int l = 0; l < pb->n_landmarks; ++l)
+                if (pb->lm_multiplicity[l] >= level) idx.push_back(l);
+            for (size_t g = 0; g < idx.size(); g += 19) {
+                auto p = std::make_unique<Plane>();
+                p->parameter.normal[0] = 0, p->parameter.normal[1] = 0, p->parameter.normal[2] = 1;
+                p->parameter.distance = 100.0 + (double)map.plane_num();
+                Plane *pl = p.get();
+                map.put_plane(std::move(p));
+                for (size_t k = g; k < std::min(idx.size(), g + 19); ++k) pl->tracks.insert(lm_tracks[(size_t)idx[k]]);
+            }
+        }
+    }
     if (pb->prior_n > 0) {
         // the holder captures the linearization states from the frames at construction (marginalization_error_cost.h:36-47):
         // put them there for the moment of the call

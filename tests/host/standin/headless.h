@@ -78,6 +78,7 @@ class HeadlessVio {
     size_t window_frames() const { return window_map ? window_map->frame_num() : 0; }
     size_t keyframe_solves() const { return solves; }
     const Map *window() const { return window_map.get(); }
+    const Map *tracking_map() const { return feature_tracker ? feature_tracker->map.get() : nullptr; } // the feature tracker's own map (tests)
 
   private:
     struct Gyr {

@@ -1,0 +1,78 @@
+"""Sequence parity: the rendered sequence of test_host_headless.py goes through two
+chains that share nothing but the driver and the data-structure glue --
+
+  product chain   tests/host/libpvio_chain_hip.so: HipImage / FeatureTracker / visual_inertial_pnp / BundleAdjustor of pvio_amd/host above
+                  the HIP kernels (C ABI of libpvio_hip.so); `_emu`: the same above the kernel emulator, for the CPU suite
+  oracle chain    tests/host/libpvio_chain_oracle.so: every arithmetic piece replaced by the CPU oracle's (tests/host/oracle_chain.cpp lists
+                  the substitutions)
+
+each in its own process, each writing the record stream of tests/host/chain_log.h and a trajectory.tum.  tests/chain_compare.py holds the
+two comparisons and their tolerances: REPLAY (the oracle on the product chain's own inputs, call by call: the north_star's 1e-6 per
+iteration) and FREE RUNNING (the two chains side by side: identical track ids, corner lists, accept / reject traces; states and poses
+within what the LK rounding allows)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import chain_compare
+import test_host_headless as hh
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _run(lib, prefix, n_frames, window, gap, distance, size, timeout):
+    subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "host"), lib])
+    r = subprocess.run([sys.executable, os.path.join(HERE, "chain_run.py"), os.path.join(HERE, "host", lib), prefix, str(n_frames), str(window), str(gap), str(distance), size],
+                       capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    return r.stdout.strip().splitlines()[-1]
+
+
+def _follows_ground_truth(prefix, tol):
+    tum, gt = np.loadtxt(prefix + ".tum", ndmin=2), np.load(prefix + ".gt.npy")
+    idx = [int(np.argmin(np.abs(gt[:, 0] - t))) for t in tum[:, 0]]
+    return float(np.linalg.norm(tum[:, 1:4] - gt[idx, 1:4], axis=1).max()) < tol
+
+
+def test_chain_parity_emulated(tmp_path):
+    """12 frames at 352 x 264 through the kernel emulator: bootstrap of a 3-keyframe window, PnP on every later frame, a keyframe solve"""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "hipemu"), "libpvio_hipemu.so"])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(os.path.dirname(HERE), "oracle"), "liboracle.so"])
+    a, b = str(tmp_path / "product"), str(tmp_path / "oracle")
+    print(_run("libpvio_chain_hip_emu.so", a, 12, 3, 2, 18.0, "small", 900))
+    print(_run("libpvio_chain_oracle.so", b, 12, 3, 2, 18.0, "small", 300))
+    rep = chain_compare.compare_replay(a + ".log")
+    print("replay:", rep)
+    assert rep["solves"] >= 2 and rep["pnps"] >= 5
+    free = chain_compare.compare_free(a + ".log", b + ".log", hh.SMALL[2][0], a + ".tum", b + ".tum")
+    print("free running:", free)
+    assert free["frames"] == 12 and free["tracked"] > 800 and free["new"] > 100 and free["tum_poses"] >= 5
+    assert _follows_ground_truth(a, 0.02)
+
+
+@pytest.mark.gpu
+def test_chain_parity_gpu(tmp_path):
+    """60 frames at 512 x 384 on the GPU: window of 6 keyframes, marginalizations, a dozen keyframe solves"""
+    a, b = str(tmp_path / "product"), str(tmp_path / "oracle")
+    print(_run("libpvio_chain_hip.so", a, 60, 6, 3, 25.0, "full", 900))
+    print(_run("libpvio_chain_oracle.so", b, 60, 6, 3, 25.0, "full", 900))
+    keep = os.environ.get("PVIO_CHAIN_KEEP")  # keep the record streams of the run (to look at a failure off the GPU box)
+    if keep:
+        import shutil
+        os.makedirs(keep, exist_ok=True)
+        for f in (a + ".log", b + ".log", a + ".tum", b + ".tum"):
+            shutil.copy(f, keep)
+    rep = chain_compare.compare_replay(a + ".log")
+    print("replay:", rep)
+    assert rep["solves"] >= 4 and rep["pnps"] >= 30
+    free = chain_compare.compare_free(a + ".log", b + ".log", hh.K4[0], a + ".tum", b + ".tum")
+    print("free running:", free)
+    assert free["frames"] == 60 and free["solves"] == rep["solves"] and free["margs"] == rep["margs"]
+    assert _follows_ground_truth(a, 0.15)
+    out = os.environ.get("PVIO_CHAIN_REPORT")  # profiles/collect.sh: keep the numbers of the run
+    if out:
+        import json
+        json.dump(dict(replay=rep, free_running=free), open(out, "w"), indent=1)

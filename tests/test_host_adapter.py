@@ -8,6 +8,9 @@ CASES = {
     "vision": dict(n_frames=5, n_landmarks=40, visibility=4),
     "vio": dict(n_frames=5, n_landmarks=40, use_inertial=True, visibility=4),
     "vio_plane": dict(n_frames=5, n_landmarks=120, use_inertial=True, plane_fraction=0.5),
+    # tracks of planes with fewer than 20 members: their reprojection blocks are listed twice / three times (bundle_adjustor.cpp:165-179);
+    # the harness builds the small planes in the Map, the adapter has to find the multiplicities
+    "vio_small_planes": dict(n_frames=5, n_landmarks=60, use_inertial=True, visibility=4, duplicate_fraction=0.4),
 }
 
 

@@ -16,7 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # mode 2 = the matrix-core form of k_linearize (what sharded large windows run: bench.py's scaling_window leg)
 @pytest.mark.parametrize("case,world,mode", [("vio_plane", 2, 0), ("vision_partial", 3, 0), ("vio_partial", 2, 2),
-                                             ("vio_partial", 4, 0), ("vio_partial", 8, 0), ("vio_13_frames_global_matrix", 2, 0)])
+                                             ("vio_partial", 4, 0), ("vio_partial", 8, 0), ("vio_13_frames_global_matrix", 2, 0),
+                                             ("vio_duplicate_blocks", 2, 2)])
 def test_sharded_solve_matches_oracle(oracle, case, world, mode):
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "hipemu"), "libpvio_hipemu.so"])
     pb = ba_compare.make(oracle, **ba_compare.CASES[case])

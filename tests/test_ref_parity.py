@@ -18,7 +18,7 @@ from test_ref_pin import ref  # noqa: F401  (fixture)
 
 EMU_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hipemu")
 # RotationPriorFactor has no reference counterpart; everything else the reference can express
-SMALL = ["vision_partial", "vio_partial", "plane", "vio_plane", "vio_zero_bias_quirk", "config1_10x200", "vio_13_frames_global_matrix"]
+SMALL = ["vision_partial", "vio_partial", "plane", "vio_plane", "vio_zero_bias_quirk", "config1_10x200", "vio_13_frames_global_matrix", "vio_duplicate_blocks"]
 
 
 @pytest.fixture(scope="module")
@@ -30,7 +30,7 @@ def emu_ctx():
     ctx.close()
 
 
-@pytest.mark.parametrize("name", ["vision_partial", "vio_partial", "vio_plane", "vio_zero_bias_quirk"])
+@pytest.mark.parametrize("name", ["vision_partial", "vio_partial", "vio_plane", "vio_zero_bias_quirk", "vio_duplicate_blocks"])
 def test_emulated_kernels_match_reference_sources(emu_ctx, ref, oracle, name):
     pb = ba_compare.make(oracle, **ba_compare.CASES[name])
     print(name, ba_compare.check_against_reference(emu_ctx, ref, pb))

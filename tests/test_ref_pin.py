@@ -145,6 +145,43 @@ def test_preintegrator_equals_reference(ref, oracle):
     print("preintegrator worst relative differences (U: per unit of cond(cov)):", worst)
 
 
+def test_product_preintegrate_equals_reference_elementwise(ref, oracle):
+    """SURVEY section 8 row A4 -- the PRODUCT's pvio_preintegrate (C ABI of libpvio_hip.so: host FP64 code, loads and runs without a GPU)
+    against the reference's PreIntegrator::integrate (preintegrator.cpp:39-100) and against the oracle, element by element: delta
+    (t q p v), the 15 x 15 covariance, the five bias Jacobians and sqrt_inv_cov, over ordinary blocks and the edges -- t_end on the last sample, irregular sample times, zero biases; a t_end BEFORE the last sample is the reference's
+    runtime_assert(dt >= 0) (preintegrator.cpp:92): the product returns an error instead of integrating backwards."""
+    from pvio_amd.solver import preintegrate as product
+    rng = np.random.default_rng(131)
+    worst = dict(delta=0, cov=0, jac=0, U=0)
+    cases = []
+    for trial in range(200):
+        cases.append(_random_preint(rng, ref, n_s=int(rng.integers(2, 60))))
+    one = _random_preint(rng, ref, n_s=1)
+    t, w, a, te, bg, ba, nz = _random_preint(rng, ref, n_s=30)
+    cases.append((t, w, a, float(t[-1]), bg, ba, nz))                            # t_end on the last sample: a closing interval of zero length
+    cases.append((np.sort(rng.uniform(0, 0.15, 30)), w, a, 0.16, bg, ba, nz))    # irregular times
+    cases.append((t, w, a, te, np.zeros(3), np.zeros(3), nz))                    # zero biases
+    for args in cases:
+        dp, cp, Up, jp = product(*args)
+        for name, (dx, cx, Ux, jx) in (("reference", ref.preintegrate(*args)), ("oracle", oracle.preintegrate(*args))):
+            worst["delta"] = max(worst["delta"], close(dp, dx, what="delta vs " + name))
+            worst["cov"] = max(worst["cov"], close(cp, cx, what="cov vs " + name))
+            worst["jac"] = max(worst["jac"], close(jp, jx, what="bias jacobians vs " + name))
+            cond = np.linalg.cond(cx.reshape(15, 15))
+            worst["U"] = max(worst["U"], close(Up, Ux, rel=max(REL, 1e-15 * cond), what="sqrt_inv_cov vs %s (cond %.1e)" % (name, cond)) / cond)
+        U, c = Up.reshape(15, 15), cp.reshape(15, 15)
+        assert np.abs(U.T @ U @ c - np.eye(15)).max() < 1e-15 * np.linalg.cond(c) * 50
+    from pvio_amd.solver import HipError
+    with pytest.raises(HipError):
+        product(t, w, a, float(t[-1]) - 0.003, bg, ba, nz)
+    # ONE sample: the covariance of a single step has rank 12 (no position noise yet); the reference inverts it regardless and hands
+    # out NaN (preintegrator.cpp:97-99), the product (and the oracle) report the block as unusable instead
+    assert not np.isfinite(ref.preintegrate(*one)[2]).all() and np.linalg.matrix_rank(ref.preintegrate(*one)[1].reshape(15, 15)) == 12
+    with pytest.raises(HipError):
+        product(*one)
+    print("product pvio_preintegrate, worst relative differences (U: per unit of cond(cov)):", worst)
+
+
 def test_preintegration_factor_equals_reference(ref, oracle):
     rng = np.random.default_rng(14)
     L, R = oracle.lib(), ref.lib()
@@ -230,10 +267,14 @@ def _window(kind, oracle):
         return synth.make_window(n_frames=6, n_landmarks=100, use_inertial=True, visibility=5, seed=704, preintegrate=oracle.preintegrate, plane_fraction=0.3)
     if kind == "plane":
         return synth.make_window(n_frames=5, n_landmarks=80, visibility=4, seed=705, plane_fraction=0.4)
+    if kind == "vio_small_planes":
+        # tracks of planes with fewer than 20 members get their reprojection blocks a second (third) time: bundle_adjustor.cpp:165-179.
+        # On the reference side these ARE small planes in the Map (ref_py.tracks_of_problem); the flat problem carries lm_multiplicity.
+        return synth.make_window(n_frames=6, n_landmarks=90, use_inertial=True, visibility=4, seed=706, preintegrate=oracle.preintegrate, duplicate_fraction=0.35)
     raise KeyError(kind)
 
 
-@pytest.mark.parametrize("kind", ["vision", "vio", "vio_zero_bias", "vio_plane", "plane"])
+@pytest.mark.parametrize("kind", ["vision", "vio", "vio_zero_bias", "vio_plane", "plane", "vio_small_planes"])
 def test_solve_equals_reference(ref, oracle, kind):
     """The reference's BundleAdjustorSolver::solve (its own problem construction, cost functions, callbacks and post-solve pass,
     mini-Ceres underneath) against oracle_ba_solve: same accept / reject trace, states after every iteration, final states,
