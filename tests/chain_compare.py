@@ -14,7 +14,13 @@ per call -- and nothing downstream is re-synchronized.  Required
                      states after every iteration within FREE_STATE (inverse depths triangulated over a few pixels of parallax move by
                      1e-5 when a keypoint moves by 1e-3 px: that, not the solver, sets this number)
   per PnP / marginalization  identical shapes and iteration counts, results within the same tolerance
-  trajectory.tum     same poses at the same times within FREE_POSE."""
+  trajectory.tum     same poses at the same times within FREE_POSE.
+Identity of the decisions cannot hold forever: every threshold the pipeline compares a float against is a place where 1e-3 px decide.
+On the 60-frame GPU sequence the chains make identical decisions for 48 frames (6 023 tracked keypoints, 4 window solves, 2
+marginalizations, 31 PnP solves); in frame 48 two tracks of equal length come to lie 25.000 px apart -- the Poisson-disk radius of
+Frame::track_keypoints (frame.cpp:108-130, feature_tracker_min_keypoint_distance = 25) -- and one chain keeps both.  compare_free
+therefore takes `min_identical_frames`: strict record-by-record identity up to the first differing decision, which must not come
+earlier than that; the reported poses are held together over the WHOLE sequence regardless."""
 import numpy as np
 
 from chain_run import parse_log
@@ -110,27 +116,36 @@ def compare_replay(log):
     return info
 
 
-def compare_free(log_product, log_oracle, fx, tum_product=None, tum_oracle=None):
+def compare_free(log_product, log_oracle, fx, tum_product=None, tum_oracle=None, min_identical_frames=None):
+    """The two chains side by side.  They are compared record by record for as long as every discrete decision is the same; the first
+    record whose integers differ (a track that survived on one side only, another factor count, another accept / reject) ends the
+    strict part -- from there on the chains are different experiments -- and only the reported poses are held together (FREE_POSE) to
+    the end of the sequence.  min_identical_frames: how many camera frames must pass before that may happen (None: never)."""
     A = [r for r in parse_log(log_product) if abs(r[0]) not in (4, 5, 7)]
     B = parse_log(log_oracle)
-    assert [r[0] for r in A] == [r[0] for r in B], "the two chains did not make the same sequence of calls"
-    info = dict(frames=0, solves=0, margs=0, pnps=0, iterations=0, rejected_steps=0, tracked=0, new=0, max_kp_px=0.0, max_pose=0.0, max_marg=0.0, max_pnp=0.0)
-    for (tag, Ia, Da), (_, Ib, Db) in zip(A, B):
-        assert tag > 0, "a call failed in the chains (tag %d)" % tag
+    info = dict(frames=0, identical_frames=0, first_divergence=None, solves=0, margs=0, pnps=0, iterations=0, rejected_steps=0, tracked=0, new=0,
+                max_kp_px=0.0, max_pose=0.0, max_marg=0.0, max_pnp=0.0, max_window_inv_depth=0.0)
+    frame = -1
+    for (tag, Ia, Da), (tagb, Ib, Db) in zip(A, B):
+        assert tag > 0 and tagb > 0, "a call failed in the chains (tags %d %d)" % (tag, tagb)
+        same = tag == tagb and Ia.shape == Ib.shape and bool((Ia == Ib).all())
+        if tag == 6 and tagb == 6:
+            same = bool((Ia[:3] == Ib[:3]).all())  # factor counts; the iteration count of a converged PnP may move by one
+        if not same:
+            what = {1: "surviving tracks / new corners", 2: "window solve (shape, trace or depth gate)", 3: "marginalization", 6: "PnP factor count", 8: "window track flags"}
+            info["first_divergence"] = dict(after_frame=frame, record=what.get(tag, str(tag)))
+            break
         if tag == 1:
-            assert (Ia == Ib).all(), "frame %d: track ids / lengths differ" % Ia[0]
+            frame = int(Ia[0])
             n = int(Ia[4])
             ka, kb = Da[:2 * n].reshape(n, 2), Db[:2 * n].reshape(n, 2)
             fresh = Ia[5:].reshape(n, 2)[:, 1] == 0  # a corner detected in this frame: no track yet (Frame::detect_keypoints only appends keypoints)
-            assert (ka[fresh] == kb[fresh]).all(), "frame %d: new corners differ" % Ia[0]
+            assert (ka[fresh] == kb[fresh]).all(), "frame %d: new corners differ" % frame
             if (~fresh).any():
                 d = float(np.abs(ka[~fresh] - kb[~fresh]).max() * fx)
                 info["max_kp_px"] = max(info["max_kp_px"], d)
-                assert d <= FREE_KLT_PX, "frame %d: tracked keypoints differ by %.3g px" % (Ia[0], d)
-            d = float(np.abs(Da[2 * n:] - Db[2 * n:]).max())
-            info["max_pose"] = max(info["max_pose"], d)
-            assert d <= FREE_POSE, "frame %d: reported pose differs by %.3g" % (Ia[0], d)
-            info["frames"] += 1
+                assert d <= FREE_KLT_PX, "frame %d: tracked keypoints differ by %.3g px" % (frame, d)
+            info["identical_frames"] += 1
             info["tracked"] += int((~fresh).sum())
             info["new"] += int(fresh.sum())
         elif tag == 2:
@@ -144,6 +159,26 @@ def compare_free(log_product, log_oracle, fx, tum_product=None, tum_oracle=None)
         elif tag == 6:
             info["max_pnp"] = max(info["max_pnp"], _pnp("free", info["pnps"], Ia, Da, Ib, Db, FREE_STATE, False))
             info["pnps"] += 1
+        elif tag == 8:
+            n = int(Ia[2])
+            valid = Ia[3:].reshape(n, 3)[:, 1] == 1
+            if valid.any():
+                d = float(np.abs(Da.reshape(n, 2)[valid, 0] - Db.reshape(n, 2)[valid, 0]).max())
+                info["max_window_inv_depth"] = max(info["max_window_inv_depth"], d)
+                assert d <= FREE_STATE, "frame %d: inverse depths of the window's valid tracks differ by %.3g" % (frame, d)
+    # the reported pose of EVERY frame, divergence or not
+    pa = {int(I[0]): D[-8:] for t, I, D in A if t == 1}
+    pb = {int(I[0]): D[-8:] for t, I, D in B if t == 1}
+    assert sorted(pa) == sorted(pb)
+    info["frames"] = len(pa)
+    for f in sorted(pa):
+        d = float(np.abs(pa[f] - pb[f]).max())
+        info["max_pose"] = max(info["max_pose"], d)
+        assert d <= FREE_POSE, "frame %d: reported pose differs by %.3g" % (f, d)
+    if min_identical_frames is not None:
+        assert info["identical_frames"] >= min_identical_frames, "the chains part after %d identical frames: %s" % (info["identical_frames"], info["first_divergence"])
+    else:
+        assert info["first_divergence"] is None, info["first_divergence"]
     if tum_product and tum_oracle:
         ta, tb = np.loadtxt(tum_product, ndmin=2), np.loadtxt(tum_oracle, ndmin=2)
         assert ta.shape == tb.shape and ta.shape[0] > 0 and (ta[:, 0] == tb[:, 0]).all()
