@@ -49,6 +49,24 @@ __device__ long long g_stamp_t0[4], g_stamp_w0[4]; // shader clock / 100 MHz wal
         if (v.dbg && (v.dbg_sel < 0 || v.dbg_sel == (idx)) && blockIdx.x == 0 && threadIdx.x == 0) v.dbg[(kern)*32 + (idx)] = clock64() - g_stamp_t0[kern]; \
     } while (0)
 
+// k_dense: the start time is a local of the kernel (pv_t0), the stamp itself requests nothing
+#define PV_STAMP2(idx)                                                                                                          \
+    do {                                                                                                                        \
+        if (v.dbg && (v.dbg_sel < 0 || v.dbg_sel == (idx)) && threadIdx.x == 0) v.dbg[2 * 32 + (idx)] = clock64() - pv_t0;      \
+    } while (0)
+#define PV_STAMP2T(idx, thread) /* the same from another thread (wave 0 owns no tiles in the look-ahead form) */             \
+    do {                                                                                                                        \
+        if (v.dbg && (v.dbg_sel < 0 || v.dbg_sel == (idx)) && threadIdx.x == (thread)) v.dbg[2 * 32 + (idx)] = clock64() - pv_t0; \
+    } while (0)
+#ifdef PV_HIPEMU
+#define PV_STAMPV2(idx, var) PV_STAMP2(idx)
+#else
+#define PV_STAMPV2(idx, var)                      \
+    do {                                          \
+        asm volatile("" : "+v"(var));            \
+        PV_STAMP2(idx);                           \
+    } while (0)
+#endif
 #ifdef PV_HIPEMU
 #define PV_STAMPV(kern, idx, var) PV_STAMP(kern, idx)
 #else
@@ -996,6 +1014,10 @@ __device__ __forceinline__ void role_prior(const View &v, double *lds, const Pro
         double g = tid < 3 ? Jm[tid] * rt[0] + Jm[3 + tid] * rt[1] + Jm[6 + tid] * rt[2] : rt[tid];
         if (tid < 6 && v.frame_fixed[v.prior_frames[b]] && !marg) g = 0.0;
         v.prior_g[15 * b + tid] = g;
+        // the same number where k_dense finds it without knowing the slot of a frame (prior_gd: [N][30] = gradient, diagonal of H by
+        // FRAME, zero for frames the prior does not relate -- cleared at upload; written by the slot k_dense used to look up)
+        const int fb = v.prior_frames[b];
+        if (v.prior_slot[fb] == b) v.prior_gd[30 * fb + tid] = g;
     }
     // H rows of this frame: H = B^T Lambda B
     for (int idx = tid; idx < 15 * D; idx += kLinThreads) {
@@ -1015,6 +1037,10 @@ __device__ __forceinline__ void role_prior(const View &v, double *lds, const Pro
         }
         if (!marg && ((ka < 6 && v.frame_fixed[v.prior_frames[b]]) || (kc < 6 && v.frame_fixed[v.prior_frames[ic]]))) h = 0.0;
         v.prior_H[(size_t)a * D + c] = h;
+        if (c == a) {
+            const int fb = v.prior_frames[b];
+            if (v.prior_slot[fb] == b) v.prior_gd[30 * fb + 15 + ka] = h;
+        }
     }
     (void)nb;
 }
@@ -1261,8 +1287,10 @@ __device__ __forceinline__ void backsub_landmarks(const View &v, int lin, double
 // fixed order (tiles, odd IMU factors, even IMU factors, prior); passes that touch the same entries are separated by
 // barriers.  cm[a] = Jacobi scale of coordinate a, 0 if inactive.
 #ifdef PV_HIPEMU
-#define PV_KEEP(x) (void)(x)
+#define PV_KEEP(x) ((void)(x))
+#define PV_ORDER() ((void)0)
 #else
+#define PV_ORDER() asm volatile("" ::: "memory") // memory operations are not moved across this point by the compiler
 #define PV_KEEP(x) asm volatile("" : "+v"(x)) // the value is needed HERE: keeps its load unconditional and where it was written
 #endif
 // flags[j] = IMU factor j is present, pframe[q] = frame of prior slot q (both in LDS)
@@ -1593,28 +1621,6 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
     double *diagH = vec, *gtot = vec + LDV, *rhs = vec + 2 * LDV, *yv = vec + 3 * LDV, *vv = vec + 4 * LDV, *act = vec + 5 * LDV,
            *tmp = vec + 6 * LDV, *cpl = vec + 7 * LDV;
     double *ysol = rhs; // solution of the reduced system (rhs is dead once the augmented row has been written)
-    // Everything the control section reads comes in with one round of parallel loads (a dependent chain of single-thread
-    // global loads costs a trip through the fabric each: the producers ran on other XCDs).  The values are REQUESTED here and
-    // stored to LDS further down, behind the requests for the tiles: a store waits for its load, and loads retire in order, so
-    // storing first would put a whole trip between these loads and the tile loads (and requesting the tiles first would make
-    // the control inputs wait for 112 KB of tiles).
-    double in_val = 0.0;
-    {
-        constexpr int nw = (int)(sizeof(Ctrl) / sizeof(double));
-        const double *src = reinterpret_cast<const double *>(cg);
-        if (tid < nw) in_val = src[tid];
-        else if (tid < 64 + kNumLinScal && tid >= 64) {
-            const size_t base = nS + (size_t)kNumPoseVec * P6;
-            in_val = v.red[base + (tid - 64)];
-            if (tid - 64 == 4 && v.dm.world > 1) { // max |b_l|: one slot per rank behind the scalars (see k_reduce); all >= 0
-                in_val = 0.0;
-                for (int w = 0; w < v.dm.world; ++w) in_val = fmax(in_val, v.red[base + kNumLinScal + w]);
-            }
-        }
-        else if (tid >= 128 && tid < 128 + N) in_val = (tid - 128 >= 1 && v.dm.G_pre && v.pre_valid[tid - 128]) ? v.pre_cost[tid - 128] : 0.0;
-        else if (tid >= 192 && tid < 192 + v.dm.prior_n) in_val = v.prior_cost[tid - 192];
-        else if (tid == 255) in_val = v.dm.n_rot > 0 ? v.rot_cost[0] : 0.0;
-    }
     // Tile ownership of the register-resident factorization (LDSMAT).  Tile (g, h): g = tile column, h <= g = tile row, both
     // counted from the LAST one.  Rows are dealt to the waves in a zigzag (dense_row_of: rows w, 7 - w, 8 + w -> 15 / 14 / 13 / 13
     // tiles at P = 150 instead of 21 / 18 / 15 / 12 for h & 3: the rows nearest the end are the longest); a wave keeps the
@@ -1626,7 +1632,8 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
     constexpr int kSlots = LDSMAT ? dt_slots<LA>() : 1; // sum over g < 11 of ceil((g + 1) / 4): LDV <= 176 (look-ahead form: 26)
     constexpr int kNQ = dt_nq<LA>();                      // tile rows a wave can own
     const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6), lr = lane & 15, lk = lane >> 4;
-    const bool from_images = LDSMAT && v.dm.use_img; // the reduced system arrives as a tile image: loaded straight into registers
+    // the reduced system arrives as a tile image: loaded straight into registers (the look-ahead form is only launched on one)
+    const bool from_images = LA ? true : (LDSMAT && v.dm.use_img);
     int sbi[kSlots], sbk[kSlots];
     lds_d2 raw[kSlots][2];
     if constexpr (LDSMAT) {
@@ -1640,24 +1647,114 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
 #pragma unroll
         for (int i = 0; i < kSlots; ++i) raw[i][0][0] = 0.0, raw[i][0][1] = 0.0, raw[i][1][0] = 0.0, raw[i][1][1] = 0.0;
     }
-
-    const bool split = v.dm.split_fin != 0; // gradient max-norm, state / trace copies (and v^T S v: qvv_back) are finished by k_backsub
+    // gradient max-norm, state / trace copies (and v^T S v: qvv_back) are finished by k_backsub (always, in the look-ahead form)
+    const bool split = LA ? true : v.dm.split_fin != 0;
+    // `early`: everything small this launch reads is REQUESTED in one round, every request independent of every other, and waited for
+    // once; only then do the tile loads go out.  What the round-2 ISA did instead (one s_waitcnt vmcnt(0) per control input -- the
+    // branches of an if-chain loading into one register; the control inputs stored to LDS, and the termination flag tested, only
+    // after ALL tile loads had landed -- the per-slot branches around the tile loads leave the compiler no count of what is in
+    // flight, and vmcnt retires in order) put the control section 11 600 cycles into the launch and the first panel 30 500.
+    // (A property of the INSTANTIATION, not a run-time flag: a branch around the tile requests would again leave their number open.)
+    constexpr bool early = LA;
     PV_STAMP_BEGIN(2);
-    PV_STAMP(2, 0);
-    // Touch what the assembly reads, one load per 128-byte line: the sources were produced on other XCDs and a first touch
-    // costs a trip through the fabric -- paid once here, all lines in flight, overlapped with the control section.  When the
-    // reduced system arrives as a tile image this workgroup reads only the pose VECTORS and scalars of `red` and the
-    // DIAGONALS of the IMU / prior blocks (requested individually below): not the 250 KB of full blocks.
-    double pf = 0;
-    {
-        const size_t nR = nS + (size_t)kNumPoseVec * P6 + kNumLinScal;
-        if (from_images) {
-            // (a dozen lines, one per thread, requested behind the tile loads below)
-        } else {
-#pragma unroll 4
-            for (size_t e = (size_t)tid * 16; e < nR; e += (size_t)nthr * 16) pf += v.red[e];
+    const long long pv_t0 = v.dbg ? clock64() : 0; // (in a register: a stamp that fetched the start time would wait for every request in flight)
+    PV_STAMP2(0);
+    // ---- round 1: REQUESTS ONLY.  Every load below is unconditional (clamped index, selected address: all the arrays exist for every
+    // frame whatever the window holds), lands in a register of its own and is not looked at -- not even converted to a flag -- until
+    // the section is over: a value used inside a branch, or an `&&` on a loaded byte, makes the compiler wait for it on the spot.
+    constexpr int kCtrlWords = (int)(sizeof(Ctrl) / sizeof(double));
+    const bool g_pre = v.dm.G_pre != 0;
+    const size_t red_scal = nS + (size_t)kNumPoseVec * P6;
+    // (a) the control inputs, one per thread at a selected address (a thread with nothing to fetch re-reads the first word)
+    const double *in_ptr = reinterpret_cast<const double *>(cg);
+    if (tid < kCtrlWords) in_ptr = reinterpret_cast<const double *>(cg) + tid;
+    else if (tid >= 64 && tid < 64 + kNumLinScal) in_ptr = v.red + red_scal + (tid - 64);
+    else if (tid >= 129 && tid < 128 + N) in_ptr = v.pre_cost + (tid - 128);
+    else if (tid >= 192 && tid < 192 + v.dm.prior_n) in_ptr = v.prior_cost + (tid - 192);
+    else if (tid == 255) in_ptr = v.rot_cost;
+    const int jq = tid >= 129 && tid < 128 + N ? tid - 128 : 0;
+    const int fq = tid < N ? tid : N - 1;
+    const int a1 = tid < P ? tid : P - 1;                       // the coordinate of this thread (P <= nthr: one per thread)
+    const int f1 = d == 15 ? a1 / 15 : a1 / 6, k1 = a1 - d * f1; // its frame and its index in the frame's block
+    const int k6 = k1 < 6 ? k1 : 0, k3 = k1 < 3 ? k1 : 0, jB1 = f1 + 1 < N ? f1 + 1 : f1;
+    static_assert(15 * kMaxFrames <= 2 * kDenseThreads, "one coordinate per thread");
+    double L_in = *in_ptr;
+    unsigned L_pvq = v.pre_valid[jq];
+    // (b) static per-frame data of the vector assembly, the termination flag (every thread takes it from its own load: the control
+    // section may set the LDS copy's `done` while slower waves are still on their way to the test)
+    int L_slot = v.prior_slot[fq], L_frame = v.prior_frames[tid < v.dm.prior_n ? tid : 0]; // (both staged with at least one word)
+    unsigned L_valid = v.pre_valid[fq], L_pa = v.pose_active[fq], L_ma = v.motion_active[fq];
+    int was_done = cg->done;
+    // (c) the unscaled vectors of coordinate a1: diag(J^T J), gradient, Schur rhs -- the landmark part from k_reduce, the IMU factors
+    // on either side of the frame, the prior BY FRAME (prior_gd: zero where the prior does not reach), the rotation prior (zero
+    // block when the window has none), the Jacobi scale of the coordinate (written by the solve's first factoring launch)
+    double L_dg = redV[2 * P6 + 6 * f1 + k6], L_g = redV[6 * f1 + k6], L_rs = redV[P6 + 6 * f1 + k6];
+    unsigned L_vA = v.pre_valid[f1], L_vB = v.pre_valid[jB1];
+    double L_hA = v.pre_H[(size_t)f1 * 900 + (15 + k1) * 31], L_gA = v.pre_g[(size_t)f1 * 30 + 15 + k1];
+    double L_hB = v.pre_H[(size_t)jB1 * 900 + k1 * 31], L_gB = v.pre_g[(size_t)jB1 * 30 + k1];
+    double L_pg = v.prior_gd[30 * f1 + k1], L_ph = v.prior_gd[30 * f1 + 15 + k1];
+    double L_rg = v.rot_g[3 * f1 + k3], L_rh = v.rot_H[9 * f1 + 4 * k3];
+    unsigned L_actp = v.pose_active[f1], L_actm = v.motion_active[f1];
+    double in_cp = v.cp[a1];
+    if constexpr (LDSMAT) {
+        // ---- round 2, requested right behind round 1: this wave's tiles of the reduced system (112 KB for the workgroup; a rejected
+        // step fetches them for nothing).  One CU pulls them at ~8 bytes a cycle (14 000 cycles: bounded by the misses it can keep in
+        // flight times the latency of memory the producers -- other XCDs -- wrote to), which is the longest single item in front of the
+        // first panel: it has to start NOW and run under everything else.  vmcnt retires in order, so round 1 is back long before;
+        // for the compiler to know that -- to wait for "all but the last 52 requests" instead of for everything -- the NUMBER of tile
+        // requests must not depend on anything: a slot this wave does not own re-reads tile 0 (a hit in the CU's cache).
+        if constexpr (early) {
+            PV_ORDER(); // round 1 is requested FIRST: requests retire in the order they were made
+#pragma unroll
+            for (int i = 0; i < kSlots; ++i) {
+                const int ti = sbk[i] >= 0 ? ((sbi[i] * (sbi[i] + 1)) >> 1) + sbk[i] : 0;
+                const double *T = v.img + ((size_t)ti << 8) + 4 * lane;
+                raw[i][0] = *reinterpret_cast<const lds_d2 *>(T);
+                raw[i][1] = *reinterpret_cast<const lds_d2 *>(T + 2);
+            }
         }
-        if (d == 15 && !from_images) {
+    }
+    // every request above has been issued before any of them is looked at: the values are pinned HERE (the compiler would otherwise
+    // move a load into the branch that uses it -- behind the wait for the loads that the branch condition needs: a second trip)
+    PV_KEEP(L_in); PV_KEEP(L_pvq); PV_KEEP(L_slot); PV_KEEP(L_frame); PV_KEEP(L_valid); PV_KEEP(L_pa); PV_KEEP(L_ma); PV_KEEP(was_done);
+    PV_KEEP(L_dg); PV_KEEP(L_g); PV_KEEP(L_rs); PV_KEEP(L_vA); PV_KEEP(L_vB); PV_KEEP(L_hA); PV_KEEP(L_gA); PV_KEEP(L_hB); PV_KEEP(L_gB);
+    PV_KEEP(L_pg); PV_KEEP(L_ph); PV_KEEP(L_rg); PV_KEEP(L_rh); PV_KEEP(L_actp); PV_KEEP(L_actm); PV_KEEP(in_cp);
+    PV_STAMP2(28);
+    // ---- round 1: uses.  Selects, no branches on loaded values. ----
+    double in_val = L_in;
+    const unsigned in_pv = g_pre ? L_pvq : 0u; // IMU factor present (tid = 128 + j)
+    const int in_slot = v.dm.prior_n > 0 ? L_slot : -1, in_valid = (g_pre & (L_valid != 0)) ? 1 : 0, in_frame = L_frame;
+    const bool f_pose_active = (L_pa != 0) & (tid < N), f_motion_active = (L_ma != 0) & (tid < N);
+    double as_dg, as_g, as_r, as_act;
+    {
+        double dg = k1 < 6 ? L_dg : 0.0, g = k1 < 6 ? L_g : 0.0;
+        double r = g - (k1 < 6 ? L_rs : 0.0); // rhs_u = g_total - sum_l w_l W_l^T b_l
+        if (d == 15) {
+            // (an absent factor's block was never written: select, not multiply)
+            const bool vA = g_pre & (f1 >= 1) & (L_vA != 0), vB = g_pre & (f1 + 1 < N) & (L_vB != 0);
+            const double hA = vA ? L_hA : 0.0, gA = vA ? L_gA : 0.0, hB = vB ? L_hB : 0.0, gB = vB ? L_gB : 0.0;
+            if (g_pre) { // (a uniform condition on a kernel argument; x + 0 is exact, the branch only keeps -0 a -0)
+                if (f1 & 1) dg = (dg + hA) + hB, g = (g + gA) + gB, r = (r + gA) + gB;
+                else dg = (dg + hB) + hA, g = (g + gB) + gA, r = (r + gB) + gA;
+            }
+            if (v.dm.prior_n > 0) dg += L_ph, g += L_pg, r += L_pg;
+        }
+        if (v.dm.n_rot > 0 && k1 < 3) dg += L_rh, g += L_rg, r += L_rg;
+        as_act = ((k1 < 6 ? L_actp : L_actm) != 0) ? 1.0 : 0.0;
+        as_dg = dg, as_g = g, as_r = r;
+    }
+    if (v.dm.world > 1 && tid == 64 + 4) { // sharded windows: max |b_l|, one slot per rank behind the scalars (see k_reduce); all >= 0
+        in_val = 0.0;
+        for (int w = 0; w < v.dm.world; ++w) in_val = fmax(in_val, v.red[red_scal + kNumLinScal + w]);
+    }
+    // Touch what the entry-by-entry assembly reads (not the tile-image form), one load per 128-byte line: the sources were produced on
+    // other XCDs and a first touch costs a trip through the fabric -- paid once here, all lines in flight.
+    double pf = 0;
+    if (!from_images) {
+        const size_t nR = nS + (size_t)kNumPoseVec * P6 + kNumLinScal;
+#pragma unroll 4
+        for (size_t e = (size_t)tid * 16; e < nR; e += (size_t)nthr * 16) pf += v.red[e];
+        if (d == 15) {
             if (v.dm.G_pre) {
                 const size_t nH = (size_t)N * 900, nG = (size_t)N * 30;
 #pragma unroll 4
@@ -1672,25 +1769,9 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
             }
         }
     }
-    // static per-frame data of the vector assembly (prior slot, IMU factor present) and both state buffers (the gradient-max
-    // pass reads the accepted iterate; which buffer that is, is decided by the control section): staged with the control inputs.
-    // Lp is free until the factorization starts (48 N <= 8 LDV doubles).
-    int in_slot = -1, in_valid = 0, in_frame = 0;
-    if (tid < N) {
-        in_slot = v.dm.prior_n > 0 ? v.prior_slot[tid] : -1;
-        in_valid = (v.dm.G_pre && v.pre_valid[tid]) ? 1 : 0;
-        if (tid < v.dm.prior_n) in_frame = v.prior_frames[tid];
-    }
-    const bool f_pose_active = tid < N ? v.pose_active[tid] != 0 : false, f_motion_active = tid < N ? v.motion_active[tid] != 0 : false;
-    // every thread takes the termination flag from its own load: thread 0 may set the LDS copy's `done` in the control
-    // section below while slower waves are still on their way to this test
-    const int was_done = cg->done;
     if constexpr (LDSMAT) {
-        // split: with the finalize work off this kernel's critical path nothing is left to cover the latency of the tile loads -- a
-        // trip through the fabric, k_reduce ran on other XCDs -- so they are requested here, behind the control inputs and whatever
-        // the control section will decide (a rejected step wastes 112 KB of L2 traffic; round 2 issued them after the decision,
-        // hidden behind the vector assembly and the finalize pass that no longer run in this kernel)
-        if (split) {
+        // not `early` (split finalize off): the tile loads go out here, behind the control inputs, as in round 2
+        if (split && !early) {
 #pragma unroll
             for (int i = 0; i < kSlots; ++i)
                 if (from_images && sbk[i] >= 0) {
@@ -1700,18 +1781,19 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
                 }
         }
     }
-    if (from_images) { // first touch of the pose vectors of `red` (the value is only looked at when the kernel ends: nothing waits for it here)
-        const size_t nR = nS + (size_t)kNumPoseVec * P6 + kNumLinScal;
-        if (nS + (size_t)tid * 16 < nR) pf = v.red[nS + (size_t)tid * 16];
-    }
-    // the control inputs go to LDS (each store waits for its own load only: the tile loads behind it stay in flight)
+    // the control inputs go to LDS (the first use of round 1: everything requested above lands within the same trip)
     {
-        constexpr int nw = (int)(sizeof(Ctrl) / sizeof(double));
-        if (tid < nw) reinterpret_cast<double *>(c)[tid] = in_val;
+        if (tid < kCtrlWords) reinterpret_cast<double *>(c)[tid] = in_val;
         else if (tid < 64 + kNumLinScal && tid >= 64) redS[tid - 64] = in_val;
-        else if (tid >= 128 && tid < 128 + N) aux_costs[tid - 128] = in_val;
-        else if (tid >= 192 && tid < 192 + v.dm.prior_n) aux_costs[N + tid - 192] = in_val;
-        else if (tid == 255) aux_costs[N + v.dm.prior_n] = in_val;
+        else if (tid >= 128) {
+            // the costs of the IMU factors (wave 2) and of the prior slots + the rotation priors (wave 3), summed by their waves: the
+            // control thread adds two numbers instead of walking N + prior_n + 1 LDS words one latency at a time
+            double x = 0.0;
+            if (tid >= 129 && tid < 128 + N) x = in_pv ? in_val : 0.0; // (select: an absent factor's cost was never written)
+            else if ((tid >= 192 && tid < 192 + v.dm.prior_n) || tid == 255) x = in_val; // (rot_cost: zero block when the window has none)
+            x = wave_sum(x);
+            if ((tid & 63) == 0) aux_costs[tid >> 6] = x; // [2] IMU, [3] prior + rotation priors
+        }
         if (tid < N) {
             pslot[tid] = in_slot, pvalid[tid] = in_valid;
             if (tid < v.dm.prior_n) pframe[tid] = in_frame;
@@ -1721,51 +1803,19 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
         for (int e = tid; e < 32 * N; e += nthr) Lp[e] = v.fs[e];
         for (int e = tid; e < 16 * N; e += nthr) Lp[32 * N + e] = v.fs_user[e]; // the user state the finalize pass takes the old biases from
     }
-    __syncthreads(); // the staged control inputs are in LDS (global loads stay in flight across the barrier)
+    __syncthreads(); // the staged control inputs are in LDS (the tile requests stay in flight across the barrier)
+    PV_STAMP2(29);
     if (was_done) return; // nothing was modified
-    // ---------------- unscaled vectors, part 1: diag(J^T J), gradient, Schur rhs of coordinate a = tid ----------------
-    // requested and summed while thread 0 runs the control section below (P <= 15 * kMaxFrames <= nthr: one coordinate per
-    // thread); written to LDS afterwards if the control section says that `red` holds a new accepted linearization
-    static_assert(15 * kMaxFrames <= 2 * kDenseThreads, "one coordinate per thread");
-    double as_dg = 0, as_g = 0, as_r = 0, as_act = 0;
-    if (tid < P) {
-        const int a = tid;
-        const int f = d == 15 ? a / 15 : a / 6, k = a - d * f;
-        double dg = 0, g = 0, rs = 0;
-        if (k < 6) dg = redV[2 * P6 + 6 * f + k], g = redV[6 * f + k], rs = redV[P6 + 6 * f + k];
-        double r = g - rs; // rhs_u = g_total - sum_l w_l W_l^T b_l
-        if (d == 15) {
-            if (v.dm.G_pre) {
-                const int jA = f, jB = f + 1;
-                const bool vA = jA >= 1 && pvalid[jA], vB = jB < N && pvalid[jB];
-                const double hA = vA ? v.pre_H[(size_t)jA * 900 + (15 + k) * 31] : 0.0, gA = vA ? v.pre_g[(size_t)jA * 30 + 15 + k] : 0.0;
-                const double hB = vB ? v.pre_H[(size_t)jB * 900 + k * 31] : 0.0, gB = vB ? v.pre_g[(size_t)jB * 30 + k] : 0.0;
-                if (jA & 1) dg = (dg + hA) + hB, g = (g + gA) + gB, r = (r + gA) + gB;
-                else dg = (dg + hB) + hA, g = (g + gB) + gA, r = (r + gB) + gA;
-            }
-            const int ps = pslot[f];
-            if (ps >= 0) {
-                const int D = 15 * v.dm.prior_n, pa = 15 * ps + k;
-                const double pg = v.prior_g[pa];
-                dg += v.prior_H[(size_t)pa * D + pa], g += pg, r += pg;
-            }
-        }
-        if (v.dm.n_rot > 0 && k < 3) {
-            const double rg = v.rot_g[3 * f + k];
-            dg += v.rot_H[9 * f + 4 * k], g += rg, r += rg;
-        }
-        as_act = (k < 6 ? v.pose_active[f] : v.motion_active[f]) ? 1.0 : 0.0;
-        as_dg = dg, as_g = g, as_r = r;
-    }
     // ---------------- control (thread 0): Finalize the iteration in flight, decide what comes next ----------------
     if (tid == 0) {
-        const int lr = c->lin_result;
+        // on a register copy of the control block: every field read from LDS on its own is a latency of ~120 cycles in a chain of
+        // dependent branches (the section took 3 100 cycles that way)
+        Ctrl cc = *c;
+        const int lr = cc.lin_result;
         sh.do_solve = 0, sh.do_trace = 0, sh.accepted = 0, sh.first = 0, sh.replay_first = -1, sh.replay_count = 0;
         double aux_cost = 0;
         if (lr != LIN_INVALID_STEP) {
-            for (int j = 1; j < N; ++j) aux_cost += aux_costs[j]; // 0 where there is no factor (x + 0 is exact)
-            for (int i = 0; i < v.dm.prior_n; ++i) aux_cost += aux_costs[N + i];
-            aux_cost += aux_costs[N + v.dm.prior_n]; // rotation priors
+            aux_cost = aux_costs[2] + aux_costs[3]; // IMU factors; prior slots + rotation priors (summed by waves 2 and 3)
         }
         const double lm_cost = redS[0], lm_bad = redS[5];
         double total_cost = aux_cost + lm_cost;
@@ -1773,75 +1823,76 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
         bool finalize = false; // run FinalizeIterationAndCheckIfMinimizerCanContinue
         if (lr == LIN_INIT) {
             if (!finite_ok) {
-                c->termination = 2, c->done = 1; // FAILURE: initial evaluation failed
+                cc.termination = 2, cc.done = 1; // FAILURE: initial evaluation failed
             } else {
-                c->x_cost = total_cost, c->initial_cost = total_cost;
-                c->x_norm2_pose = c->cand_norm2_pose, c->x_norm2_lm = redS[3];
-                c->lm_g2 = redS[1];
-                c->it_cost = total_cost, c->it_cost_change = 0, c->it_step_norm = 0, c->it_rel = 0, c->it_valid = 1, c->it_success = 1;
+                cc.x_cost = total_cost, cc.initial_cost = total_cost;
+                cc.x_norm2_pose = cc.cand_norm2_pose, cc.x_norm2_lm = redS[3];
+                cc.lm_g2 = redS[1];
+                cc.it_cost = total_cost, cc.it_cost_change = 0, cc.it_step_norm = 0, cc.it_rel = 0, cc.it_valid = 1, cc.it_success = 1;
                 sh.first = 1, sh.accepted = 1;
                 finalize = true;
             }
         } else if (lr == LIN_CANDIDATE) {
             const double cand_cost = finite_ok ? total_cost : DBL_MAX;
-            const double step_norm = sqrt(c->cand_step2_pose + redS[2]);
-            const double x_norm = sqrt(c->x_norm2_pose + c->x_norm2_lm);
-            c->it_valid = 1, c->it_step_norm = step_norm;
-            c->invalid_steps = 0;
+            const double step_norm = sqrt(cc.cand_step2_pose + redS[2]);
+            const double x_norm = sqrt(cc.x_norm2_pose + cc.x_norm2_lm);
+            cc.it_valid = 1, cc.it_step_norm = step_norm;
+            cc.invalid_steps = 0;
             if (step_norm <= 1e-8 * (x_norm + 1e-8)) { // ParameterToleranceReached
-                c->termination = 0, c->done = 1;
+                cc.termination = 0, cc.done = 1;
             } else {
-                const double cost_change = c->x_cost - cand_cost;
-                c->it_cost_change = cost_change;
-                if (fabs(cost_change) <= 1e-6 * c->x_cost) { // FunctionToleranceReached (candidate NOT applied)
-                    c->termination = 0, c->done = 1;
+                const double cost_change = cc.x_cost - cand_cost;
+                cc.it_cost_change = cost_change;
+                if (fabs(cost_change) <= 1e-6 * cc.x_cost) { // FunctionToleranceReached (candidate NOT applied)
+                    cc.termination = 0, cc.done = 1;
                 } else {
-                    const double rel = cost_change / c->model_cost_change;
-                    c->it_rel = rel;
+                    const double rel = cost_change / cc.model_cost_change;
+                    cc.it_rel = rel;
                     if (rel > 1e-3) { // HandleSuccessfulStep
-                        c->cur = 1 - c->cur, c->lin = 1 - c->lin;
-                        c->x_cost = cand_cost;
-                        c->x_norm2_pose = c->cand_norm2_pose, c->x_norm2_lm = redS[3];
-                        c->lm_g2 = redS[1];
-                        if (rel < 0.25) c->radius *= 0.5; // DoglegStrategy::StepAccepted
-                        if (rel > 0.75) c->radius = fmax(c->radius, 3.0 * c->dogleg_step_norm);
-                        c->mu = fmax(1e-8, 2.0 * c->mu / 10.0);
-                        c->reuse = 0;
-                        c->it_success = 1, c->it_cost = cand_cost;
+                        cc.cur = 1 - cc.cur, cc.lin = 1 - cc.lin;
+                        cc.x_cost = cand_cost;
+                        cc.x_norm2_pose = cc.cand_norm2_pose, cc.x_norm2_lm = redS[3];
+                        cc.lm_g2 = redS[1];
+                        if (rel < 0.25) cc.radius *= 0.5; // DoglegStrategy::StepAccepted
+                        if (rel > 0.75) cc.radius = fmax(cc.radius, 3.0 * cc.dogleg_step_norm);
+                        cc.mu = fmax(1e-8, 2.0 * cc.mu / 10.0);
+                        cc.reuse = 0;
+                        cc.it_success = 1, cc.it_cost = cand_cost;
                         sh.accepted = 1;
                     } else { // HandleUnsuccessfulStep
-                        c->radius *= 0.5; // DoglegStrategy::StepRejected
-                        c->reuse = 1;
-                        c->it_success = 0, c->it_cost = cand_cost;
+                        cc.radius *= 0.5; // DoglegStrategy::StepRejected
+                        cc.reuse = 1;
+                        cc.it_success = 0, cc.it_cost = cand_cost;
                     }
                     finalize = true;
                 }
             }
         } else if (lr == LIN_INVALID_STEP) { // HandleInvalidStep
-            if (c->dbg_invalid_left > 0) c->dbg_invalid_left--;
-            c->it_valid = 0, c->it_success = 0, c->it_cost = c->x_cost, c->it_cost_change = 0, c->it_step_norm = 0, c->it_rel = 0;
-            if (++c->invalid_steps >= 5) {
-                c->termination = 2, c->done = 1;
+            if (cc.dbg_invalid_left > 0) cc.dbg_invalid_left--;
+            cc.it_valid = 0, cc.it_success = 0, cc.it_cost = cc.x_cost, cc.it_cost_change = 0, cc.it_step_norm = 0, cc.it_rel = 0;
+            if (++cc.invalid_steps >= 5) {
+                cc.termination = 2, cc.done = 1;
             } else {
-                c->mu *= 10.0; // DoglegStrategy::StepIsInvalid
-                c->reuse = 0;
+                cc.mu *= 10.0; // DoglegStrategy::StepIsInvalid
+                cc.reuse = 0;
                 finalize = true;
             }
         } else if (lr == LIN_RELIN) {
             // the accepted point re-linearized with a new mu: continue the iteration in flight
             sh.do_solve = finite_ok ? 1 : 0;
-            if (!finite_ok) c->termination = 2, c->done = 1;
+            if (!finite_ok) cc.termination = 2, cc.done = 1;
         }
-        sh.x_cost_new = c->x_cost;
+        sh.x_cost_new = cc.x_cost;
         sh.do_trace = 0;
         if (finalize) sh.do_trace = 1; // the record needs grad_max of an accepted linearization -> written after the build below
+        *c = cc;
     }
     __syncthreads();
     if (c->done && !sh.do_trace) {
         if (tid == 0) c->mode = MODE_DONE, *cg = *c;
         return;
     }
-    if (v.dbg && tid == 0) sh.stamp1 = clock64() - g_stamp_t0[2];
+    if (v.dbg && tid == 0) sh.stamp1 = clock64() - pv_t0;
     if (pf == 1.2345678901234567e301) v.vstep[0] = pf; // keeps the prefetch loads alive (never true for finite data)
     const bool need_build = sh.accepted || sh.do_solve; // a new accepted linearization (or RELIN) is in `red`
     if constexpr (LDSMAT) {
@@ -1889,31 +1940,75 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
         }
         __syncthreads();
     }
-    if (v.dbg && tid == 0) sh.stamp2 = clock64() - g_stamp_t0[2];
+    if (v.dbg && tid == 0) sh.stamp2 = clock64() - pv_t0;
+    // `early`: the scaling of the vectors (below, dense_scale_vectors) runs HERE, next to the Finalize section instead of behind it:
+    // it reads the control block's mu / scaling_ready, which Finalize does not touch, and this thread's own entries of the unscaled
+    // vectors; if Finalize ends the solve or finds nothing to factor its LDS results are simply not used.  Finalize runs on thread
+    // 192 then -- the first lane of the one wave that has no coordinate to scale (LDV <= 176) -- so that the two overlap.
+    const int fin_tid = early ? 192 : 0;
+    const bool first_scaling = !c->scaling_ready;
+    const double mu = c->mu;
+    double keep_Da = 0, keep_gh = 0, keep_cp = 0; // dogleg diagonal, scaled gradient, Jacobi scale of coordinate a = tid (LDV <= nthr)
+    auto dense_scale_vectors = [&]() {
+        for (int a = tid; a < LDV; a += nthr) {
+            if (a >= P) {
+                vv[a] = 0.0, cpl[a] = 0.0, tmp[a] = 0.0, yv[a] = 0.0; // padding (act[] is only read below P)
+                continue;
+            }
+            double cpa;
+            if (first_scaling) cpa = act[a] != 0.0 ? 1.0 / (1.0 + sqrt(diagH[a])) : 1.0; // jacobi_scaling = 1 / (1 + sqrt(col norm^2)), once
+            else cpa = early ? in_cp : v.cp[a];                                          // (early: requested in round 1; a == tid)
+            keep_cp = cpa;
+            cpl[a] = act[a] != 0.0 ? cpa : 0.0; // LDS copy: 0 marks an inactive coordinate
+            const double d2 = cpa * cpa * diagH[a];
+            const double Da = sqrt(fmin(fmax(d2, 1e-6), 1e32));
+            const double gh = act[a] != 0.0 ? cpa * gtot[a] / Da : 0.0;
+            keep_Da = Da, keep_gh = gh;
+            vv[a] = gh / Da;                                  // v = g^ / D
+            tmp[a] = Da;
+            yv[a] = act[a] != 0.0 ? cpa * rhs[a] : 0.0;       // scaled reduced rhs -> augmented row P
+        }
+        if (from_images) {
+            for (int a = tid; a < LDV; a += nthr) {
+                lds_d2 pr;
+                pr[0] = cpl[a], pr[1] = vv[a]; // {scale, v} pairs of the coordinates: one 16-byte read per row / column at load
+                *reinterpret_cast<lds_d2 *>(A + 2 * a) = pr;
+                diagH[a] = yv[a];               // keep the scaled rhs (yv is reused by the back substitution)
+                // diagonal patch of the assembled system: 1 on inactive coordinates and on the panel padding, mu D^2 elsewhere
+                yv[a] = a < P ? (cpl[a] == 0.0 ? 1.0 : mu * tmp[a] * tmp[a]) : (a < Pp ? 1.0 : 0.0);
+            }
+        }
+    };
+    if (early && need_build) dense_scale_vectors();
     // ---------------- Finalize: record, state-updating callback, termination tests ----------------
-    if (tid == 0 && sh.do_trace) {
-        const int lr = c->lin_result;
-        if (c->it_success) c->num_success++;
-        sh.trace_slot = record_trace(v, c, c->iter); // (split + accepted: gradient_max_norm is patched in by k_backsub's finalize workgroup)
+    if (tid == fin_tid && sh.do_trace) {
+        // IN PLACE (a reference): with a register copy here AS WELL AS in the control section the first factorization of every solve
+        // fails on the GPU -- the scaled system comes out wrong -- while either copy alone, and both in the emulator, are right
+        // (profiles/r3_kdense_ctrl_copy.txt; reproducer: tests/micro/build_variant.py fin_copy).  Not understood; Finalize runs next
+        // to the scaling in the look-ahead form, so its LDS latencies are off the critical path anyway.
+        Ctrl &cc = *c;
+        const int lr = cc.lin_result;
+        if (cc.it_success) cc.num_success++;
+        sh.trace_slot = record_trace(v, &cc, cc.iter); // (split + accepted: gradient_max_norm is patched in by k_backsub's finalize workgroup)
         if (split) {
-            c->fin_flags = kFinTrace | (sh.accepted ? kFinAccepted : 0) | (sh.first ? kFinFirst : 0);
-            c->fin_trace_slot = sh.trace_slot;
-            c->fin_lm_gmax = redS[4];
+            cc.fin_flags = kFinTrace | (sh.accepted ? kFinAccepted : 0) | (sh.first ? kFinFirst : 0);
+            cc.fin_trace_slot = sh.trace_slot;
+            cc.fin_lm_gmax = redS[4];
         }
         bool stop = false;
-        if (c->iter >= v.dm.max_iter) c->termination = 1, stop = true;                           // MaxSolverIterationsReached
+        if (cc.iter >= v.dm.max_iter) cc.termination = 1, stop = true;                           // MaxSolverIterationsReached
         // (split: the gradient of a linearization accepted in THIS launch is not known here -- the finalize workgroup applies the test
         // and takes the iteration back; a rejected step keeps the old gradient, whose test did not fire when it was accepted)
-        else if (!(split && sh.accepted) && c->it_success && c->grad_max <= 1e-10) c->termination = 0, stop = true; // GradientToleranceReached
-        else if (c->radius <= 1e-32) c->termination = 0, stop = true;                            // MinTrustRegionRadiusReached
+        else if (!(split && sh.accepted) && cc.it_success && cc.grad_max <= 1e-10) cc.termination = 0, stop = true; // GradientToleranceReached
+        else if (cc.radius <= 1e-32) cc.termination = 0, stop = true;                            // MinTrustRegionRadiusReached
         if (stop) {
-            c->done = 1;
+            cc.done = 1;
         } else {
-            c->iter++;
-            c->it_valid = 0, c->it_success = 0, c->it_cost_change = 0, c->it_step_norm = 0, c->it_rel = 0, c->it_cost = c->x_cost;
+            cc.iter++;
+            cc.it_valid = 0, cc.it_success = 0, cc.it_cost_change = 0, cc.it_step_norm = 0, cc.it_rel = 0, cc.it_cost = cc.x_cost;
             if (lr == LIN_INIT || (lr == LIN_CANDIDATE && sh.accepted)) sh.do_solve = 1;      // new Gauss-Newton step needed
-            else if (lr == LIN_CANDIDATE) c->mode = MODE_CANDIDATE, c->solve_ok = 0;          // rejected: reuse gn / gradient
-            else if (lr == LIN_INVALID_STEP) c->mode = MODE_RELIN, c->solve_ok = 0, c->retry_relin = 0;
+            else if (lr == LIN_CANDIDATE) cc.mode = MODE_CANDIDATE, cc.solve_ok = 0;          // rejected: reuse gn / gradient
+            else if (lr == LIN_INVALID_STEP) cc.mode = MODE_RELIN, cc.solve_ok = 0, cc.retry_relin = 0;
         }
     }
     __syncthreads();
@@ -1945,51 +2040,21 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
         return;
     }
 
-    PV_STAMP(2, 3);
+    PV_STAMP2(3);
     if (v.dbg && tid == 0 && (v.dbg_sel < 0 || v.dbg_sel == 1 || v.dbg_sel == 2)) v.dbg[2 * 32 + 1] = sh.stamp1, v.dbg[2 * 32 + 2] = sh.stamp2;
     // ---------------- Jacobi scaling (once), dogleg diagonal, scaled system ----------------
-    const bool first_scaling = !c->scaling_ready;
-    const double mu = c->mu;
-    double keep_Da = 0, keep_gh = 0; // dogleg diagonal and scaled gradient of coordinate a = tid (LDV <= nthr), for the output section
-    for (int a = tid; a < LDV; a += nthr) {
-        if (a >= P) {
-            vv[a] = 0.0, cpl[a] = 0.0, tmp[a] = 0.0, yv[a] = 0.0; // padding (act[] is only read below P)
-            continue;
-        }
-        double cpa;
-        if (first_scaling) {
-            cpa = act[a] != 0.0 ? 1.0 / (1.0 + sqrt(diagH[a])) : 1.0; // jacobi_scaling = 1 / (1 + sqrt(col norm^2)), once
-            v.cp[a] = cpa;
-        } else {
-            cpa = v.cp[a];
-        }
-        cpl[a] = act[a] != 0.0 ? cpa : 0.0; // LDS copy: 0 marks an inactive coordinate
-        const double d2 = cpa * cpa * diagH[a];
-        const double Da = sqrt(fmin(fmax(d2, 1e-6), 1e32));
-        const double gh = act[a] != 0.0 ? cpa * gtot[a] / Da : 0.0;
-        keep_Da = Da, keep_gh = gh;
-        vv[a] = gh / Da;                                  // v = g^ / D
-        tmp[a] = Da;
-        yv[a] = act[a] != 0.0 ? cpa * rhs[a] : 0.0;       // scaled reduced rhs -> augmented row P
-    }
+    if (!early) dense_scale_vectors();
+    if (first_scaling && tid < P) v.cp[tid] = keep_cp; // (one coordinate per thread: P <= nthr)
     if (from_images) {
-        for (int a = tid; a < LDV; a += nthr) {
-            lds_d2 pr;
-            pr[0] = cpl[a], pr[1] = vv[a]; // {scale, v} pairs of the coordinates: one 16-byte read per row / column at load
-            *reinterpret_cast<lds_d2 *>(A + 2 * a) = pr;
-            diagH[a] = yv[a];               // keep the scaled rhs (yv is reused by the back substitution)
-            // diagonal patch of the assembled system: 1 on inactive coordinates and on the panel padding, mu D^2 elsewhere
-            yv[a] = a < P ? (cpl[a] == 0.0 ? 1.0 : mu * tmp[a] * tmp[a]) : (a < Pp ? 1.0 : 0.0);
-        }
-        __syncthreads();
-        PV_STAMP(2, 21);
+        if (!early) __syncthreads(); // (early: the barriers behind Finalize already separate the scaling from its readers)
+        PV_STAMP2(21);
     } else {
         for (int e = tid; e < 8 * LDV; e += nthr) Lp[e] = 0.0;
         __syncthreads();
-        PV_STAMP(2, 21);
+        PV_STAMP2(21);
         if (!LDSMAT && v.dm.use_img) dense_build_image<nthr>(v, A, cpl, yv, P, Pp, nbk);
         else dense_build<nthr>(v, A, cpl, yv, pvalid, pframe, P, Pp, nbk);
-        PV_STAMP(2, 22);
+        PV_STAMP2(22);
         // pose quadratic form with the Schur-reduced scaled matrix (mu D^2 not yet added): v^T S v = sum S_ik v_i v_k
         // (thread = one (row, column) of every tile; the vector S v itself is not needed: v^T S y' follows from the solve)
         {
@@ -2011,7 +2076,7 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
             if (tid == 0) c->pose_qvv = s1[0];
         }
         for (int a = tid; a < P; a += nthr) diagH[a] = yv[a]; // keep the scaled rhs (yv is reused by the back substitution)
-        PV_STAMP(2, 23);
+        PV_STAMP2(23);
         for (int a = tid; a < P; a += nthr)
             if (act[a] != 0.0) A[mat_at(a, a)] -= mu * tmp[a] * tmp[a];
         __syncthreads();
@@ -2022,7 +2087,7 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
         }
         __syncthreads();
     }
-    PV_STAMP(2, 4);
+    PV_STAMP2(4);
     int fail = 0;
     if constexpr (LDSMAT) {
         // ---------------- register-resident panel Cholesky (width 8), two barriers per panel ----------------
@@ -2054,14 +2119,24 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
             const double *cv = A, *dgv = yv;
             const int brow = Pp >> 4; // tile row of the rhs row
             double q = 0;
+            if (v.dbg) { // profiling: when the last tile request is back (requests retire in order)
+                double last = raw[kSlots - 1][1][1];
+                PV_KEEP(last);
+                PV_STAMP2T(18, LA ? 64 : 0);
+            }
             // the {scale, v} pairs: a tile needs the pair of its column (one per lane) and of its four rows.  With the static
             // slot table they depend on the tile column g and on the wave's row index qq only: 11 + 3 * 4 reads for all 21
             // slots instead of five per slot (rows / columns outside the system read tile row / column 0: in range, never used)
+            // (the diagonal patch and the scaled rhs of a tile column are read here as well, once per column: inside the slot loop every
+            // one of them was an LDS latency of its own -- 52 reads, each waited for on the spot: half of the 12 500 cycles this section took)
             lds_d2 colop[kDenseCols], rowop[kNQ][4];
+            double dgcol[kDenseCols], rhcol[kDenseCols];
 #pragma unroll
             for (int g = 0; g < kDenseCols; ++g) {
                 const int bk = g < nbk ? nbk - 1 - g : 0;
                 colop[g] = *reinterpret_cast<const lds_d2 *>(cv + 2 * (16 * bk + lr));
+                dgcol[g] = dgv[16 * bk + lr];
+                rhcol[g] = diagH[16 * bk + lr];
             }
 #pragma unroll
             for (int qq = 0; qq < kNQ; ++qq) {
@@ -2090,26 +2165,28 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
                             q += val[r] * (ci[1] * vk2);
                         }
                     }
-                    if (bi == bk) { // diagonal tile: its diagonal counts once in v^T S v; unit / mu D^2 diagonal
-                        const double dgk = dgv[16 * bk + lr];
+                    { // diagonal tile: its diagonal counts once in v^T S v; unit / mu D^2 diagonal.  Selects: no branch, no read.
+                        const bool isdiag = bi == bk;
+                        const double dgk = dgcol[dt_slot_col<LA>(i)];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (lk + 4 * r == lr) {
-                                if (!v.dm.qvv_back) q -= val[r] * (rowop[dt_slot_q<LA>(i)][r][1] * ck[1]);
-                                val[r] += dgk;
-                            }
+                        for (int r = 0; r < 4; ++r) {
+                            const bool on = isdiag & (lk + 4 * r == lr);
+                            if (!v.dm.qvv_back) q -= on ? val[r] * (rowop[dt_slot_q<LA>(i)][r][1] * ck[1]) : 0.0;
+                            val[r] = on ? val[r] + dgk : val[r];
+                        }
                     }
-                    if (bi == brow) { // the scaled rhs in row Pp
-                        const double rk = diagH[16 * bk + lr];
+                    { // the scaled rhs in row Pp
+                        const bool isrhs = bi == brow;
+                        const double rk = rhcol[dt_slot_col<LA>(i)];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (16 * bi + lk + 4 * r == Pp) val[r] = rk;
+                        for (int r = 0; r < 4; ++r) val[r] = (isrhs & (16 * bi + lk + 4 * r == Pp)) ? rk : val[r];
                     }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[i][r] = -val[r];
                 }
             }
-            PV_STAMPV(2, 22, q);
+            PV_STAMPV2(22, q);
+            if (LA) PV_STAMP2T(19, 64);
             if (v.dm.qvv_back) {
                 if (tid == 0) c->pose_qvv = 0.0; // the whole v^T S v arrives through back_part[.][6]
             } else {
@@ -2117,7 +2194,7 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
                 block_sum<1>(s1, red_scratch);
                 if (tid == 0) c->pose_qvv = s1[0];
             }
-            PV_STAMP(2, 23);
+            PV_STAMP2(23);
         }
         // columns [o2, o2 + 8) of slot i's tile -> Xs (row-major, 8 per row; still negated)
 #define PV_PUBLISH_ROW(i, brow, o2)                                                                     \
@@ -2148,8 +2225,8 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
             if (wv == 0) {
                 int pidx = 0;
                 for (int j0 = 0; j0 < Pp; j0 += kPanel, ++pidx) {
-                    if (j0 == 0) PV_STAMP(2, 8);
-                    if (j0 == 80) PV_STAMP(2, 13);
+                    if (j0 == 0) PV_STAMP2(8);
+                    if (j0 == 80) PV_STAMP2(13);
                     dense_wait(flag_pub, 3 * (pidx + 1));
                     double Ld[kPanel][kPanel], inv[kPanel];
 #pragma unroll
@@ -2193,8 +2270,8 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
 #pragma unroll
                             for (int c2 = cc + 1; c2 < kPanel; ++c2) x[t][c2] -= x[t][cc] * Ls[c2][cc];
                     }
-                    if (j0 == 0) PV_STAMP(2, 9);
-                    if (j0 == 80) PV_STAMP(2, 14);
+                    if (j0 == 0) PV_STAMP2(9);
+                    if (j0 == 80) PV_STAMP2(14);
                     if (fail) { // uniform
                         if (lane == 0) sh_fail = 1;
                         dense_signal_set(flag_L, -1);
@@ -2221,11 +2298,11 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
                             }
                         }
                     }
-                    if (j0 == 0) PV_STAMP(2, 10);
-                    if (j0 == 80) PV_STAMP(2, 15);
+                    if (j0 == 0) PV_STAMP2(10);
+                    if (j0 == 80) PV_STAMP2(15);
                     dense_signal_set(flag_L, pidx + 1); // (release: the rows above are in LDS before the counter moves)
-                    if (j0 == 0) { PV_STAMP(2, 11); PV_STAMP(2, 12); }
-                    if (j0 == 80) { PV_STAMP(2, 16); PV_STAMP(2, 17); }
+                    if (j0 == 0) { PV_STAMP2(11); PV_STAMP2(12); }
+                    if (j0 == 80) { PV_STAMP2(16); PV_STAMP2(17); }
                     lfo += 8 * (LDV - j0);
                 }
             } else {
@@ -2280,8 +2357,8 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
         } else
         for (int j0 = 0; j0 < Pp; j0 += kPanel) {
             const int k0 = j0 + kPanel, b0 = k0 >> 4, o2 = k0 & 15;
-            if (j0 == 0) PV_STAMP(2, 8);
-            if (j0 == 80) PV_STAMP(2, 13);
+            if (j0 == 0) PV_STAMP2(8);
+            if (j0 == 80) PV_STAMP2(13);
             double Ld[kPanel][kPanel], inv[kPanel];
 #pragma unroll
             for (int r = 0; r < kPanel; ++r)
@@ -2324,10 +2401,10 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
 #pragma unroll
                 for (int c2 = cc + 1; c2 < kPanel; ++c2) x[c2] -= x[cc] * Ls[c2][cc];
             }
-            if (j0 == 0) PV_STAMP(2, 9);
-            if (j0 == 80) PV_STAMP(2, 14);
+            if (j0 == 0) PV_STAMP2(9);
+            if (j0 == 80) PV_STAMP2(14);
             if (fail) break; // uniform: every thread factored the same block
-            if (j0 == 80) PV_STAMPV(2, 18, Ls[7][6]);
+            if (j0 == 80) PV_STAMPV2(18, Ls[7][6]);
             if (tid < kPanel) {
                 double iv = inv[0];
 #pragma unroll
@@ -2337,10 +2414,10 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
             if (irow < LDV) {
                 // the owner's row went through the forward substitution inside the pivot loop; scaling and the mask of the
                 // panel's own rows (their strictly upper entries are not L) come last
-                if (j0 == 80) PV_STAMPV(2, 19, x[7]);
+                if (j0 == 80) PV_STAMPV2(19, x[7]);
 #pragma unroll
                 for (int cc = 0; cc < kPanel; ++cc) x[cc] = (j0 + cc <= irow) ? x[cc] * inv[cc] : 0.0;
-                if (j0 == 80) PV_STAMPV(2, 20, x[7]);
+                if (j0 == 80) PV_STAMPV2(20, x[7]);
                 lds_d2 *Lrow = reinterpret_cast<lds_d2 *>(Lf + lfo + 8 * tid);
 #pragma unroll
                 for (int h = 0; h < 4; ++h) {
@@ -2350,8 +2427,8 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
                 }
             }
             __syncthreads();
-            if (j0 == 0) PV_STAMP(2, 10);
-            if (j0 == 80) PV_STAMP(2, 15);
+            if (j0 == 0) PV_STAMP2(10);
+            if (j0 == 80) PV_STAMP2(15);
             // rank-8 update of the live tiles: (-C)(16x16) += L_i (16 x 8) L_k^T, two v_mfma_f64_16x16x4_f64 per tile.
             // Operand layout (cdna_hip_programming.md section 3, f64): lane l supplies A[l & 15][l >> 4] and
             // B[l >> 4][l & 15]; it receives D[(l >> 4) + 4 r][l & 15], r = 0..3.  The live tiles are the first `na` slots;
@@ -2404,16 +2481,16 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
                     }
 #undef PV_COLUMN
             }
-            if (j0 == 0) PV_STAMP(2, 11);
-            if (j0 == 80) PV_STAMP(2, 16);
+            if (j0 == 0) PV_STAMP2(11);
+            if (j0 == 80) PV_STAMP2(16);
             __syncthreads();
-            if (j0 == 0) PV_STAMP(2, 12);
-            if (j0 == 80) PV_STAMP(2, 17);
+            if (j0 == 0) PV_STAMP2(12);
+            if (j0 == 80) PV_STAMP2(17);
             lfo += 8 * (LDV - j0);
         }
 #undef PV_PUBLISH
 #undef PV_PUBLISH_ROW
-        PV_STAMP(2, 5);
+        PV_STAMP2(5);
         // ---------------- back substitution L^T y = z, 8 columns per step ----------------
         // L(i, k) = Lf[off(k >> 3) + (i - 8 (k >> 3)) * 8 + perm(k & 7)], off(p) = 8 p LDV - 32 p (p - 1), perm(c) = 2 (c & 3) + (c >> 2)
         if (tid == 0) sh_fail = fail;
@@ -2494,7 +2571,7 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
         double *Pn = Lp;
         for (int J0 = 0; J0 < Pp; J0 += W) {
             const int Wc = Pp - J0 < W ? Pp - J0 : W, jb = J0 >> 4, ntr = nbk - jb, ntc = (Wc + 15) >> 4;
-            if (J0 == 0) PV_STAMP(2, 8);
+            if (J0 == 0) PV_STAMP2(8);
             // ---- panel -> LDS, un-negated: a wave takes whole tiles (32 bytes per lane = the four entries rows lk + 4 r,
             // column lr it would own in an MFMA), four tiles in flight ----
             {
@@ -2523,7 +2600,7 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
                 }
             }
             __syncthreads();
-            if (J0 == 0) PV_STAMP(2, 9);
+            if (J0 == 0) PV_STAMP2(9);
             for (int s8 = 0; s8 < Wc; s8 += kPanel) {
                 const int j0 = J0 + s8;
                 double Ld[kPanel][kPanel], inv[kPanel];
@@ -2601,7 +2678,7 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
                 }
             }
             if (fail) break;
-            if (J0 == 0) PV_STAMP(2, 10);
+            if (J0 == 0) PV_STAMP2(10);
             // ---- finished L of the panel -> HBM (the back substitution reads it there); same tile ownership as the load ----
             {
                 const int nt = ntr * ntc;
@@ -2624,11 +2701,11 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
                 if (W == 32) dense_trailing_sweep<32, NW>(A, Pn, WS, (J0 + Wc) >> 4, nbk, wv, lane);
                 else dense_trailing_sweep<16, NW>(A, Pn, WS, (J0 + Wc) >> 4, nbk, wv, lane);
             }
-            if (J0 == 0) PV_STAMP(2, 11);
+            if (J0 == 0) PV_STAMP2(11);
             __syncthreads(); // the panel buffer is free again, the trailing tiles are in place (same-workgroup visibility)
-            if (J0 == 0) PV_STAMP(2, 12);
+            if (J0 == 0) PV_STAMP2(12);
         }
-        PV_STAMP(2, 5);
+        PV_STAMP2(5);
         // ---------------- back substitution L^T y = z, 8 columns per step ----------------
         if (tid == 0) sh_fail = fail;
         __syncthreads();
@@ -2718,7 +2795,7 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
             }
         }
     }
-    PV_STAMP(2, 6);
+    PV_STAMP2(6);
     // ---------------- outputs ----------------
     // y solves (S + mu D^2) y = rhs_s ; step direction y' = -y ; gn = D y'.  The scalars of the step are summed together
     // with the count of non-finite entries (one block reduction, one barrier less than testing the solution first); a
@@ -2827,7 +2904,7 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
     __syncthreads();
     // the control block goes back as one store per thread (a struct copy by thread 0 is 24 dependent LDS reads and stores)
     if (tid < (int)(sizeof(Ctrl) / sizeof(double))) reinterpret_cast<double *>(cg)[tid] = reinterpret_cast<const double *>(c)[tid];
-    PV_STAMP(2, 7);
+    PV_STAMP2(7);
     if (v.dbg && threadIdx.x == 0) v.dbg[2 * 32 + 30] = 0, v.dbg[2 * 32 + 31] = wall_clock64() - g_stamp_w0[2]; // 10 ns units
 }
 
@@ -3205,7 +3282,7 @@ hipError_t launch_dense(const View &v, hipStream_t st) {
     static const bool say = std::getenv("PVIO_HIP_DEBUG_LAUNCH") != nullptr;
     static bool said = false;
     if (say && !said) said = true, std::fprintf(stderr, "launch_dense: lds matrix %d, look-ahead %d, split finalize %d, qvv in backsub %d\n", lm, v.dm.dense_la, v.dm.split_fin, v.dm.qvv_back);
-    if (lm && v.dm.dense_la) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_dense<true, true>), dim3(1), dim3(kDenseThreads), lds, st, v);
+    if (lm && v.dm.dense_la && v.dm.split_fin && v.dm.use_img) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_dense<true, true>), dim3(1), dim3(kDenseThreads), lds, st, v);
     else if (lm) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_dense<true, false>), dim3(1), dim3(kDenseThreads), lds, st, v);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_dense<false, false>), dim3(1), dim3(2 * kDenseThreads), lds, st, v);
     return hipGetLastError();

@@ -346,13 +346,14 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st) {
     ok &= dev(pool_, "prior_H", Dp * Dp, &v.prior_H, &grew);
     ok &= dev(pool_, "prior_g", Dp, &v.prior_g, &grew);
     ok &= dev(pool_, "prior_cost", (size_t)std::max(dm.prior_n, 1), &v.prior_cost, &grew);
-    ok &= dev(pool_, "rot_H", Ns * 9, &v.rot_H, &grew);
-    ok &= dev(pool_, "rot_g", Ns * 3, &v.rot_g, &grew);
-    ok &= dev(pool_, "rot_cost", 1, &v.rot_cost, &grew);
-    if (ok && dm.n_rot == 0) { // read unconditionally by k_reduce / k_dense: zero when the window has none
-        if (check(hipMemsetAsync(v.rot_H, 0, Ns * 9 * sizeof(double), stream_), "memset rot") || check(hipMemsetAsync(v.rot_g, 0, Ns * 3 * sizeof(double), stream_), "memset rot") ||
-            check(hipMemsetAsync(v.rot_cost, 0, sizeof(double), stream_), "memset rot"))
-            return PVIO_ERR_HIP;
+    {
+        // arrays the kernels read for every frame whether the window has the factor or not: the prior's gradient / diagonal by frame
+        // (k_dense's vector assembly; frames without a prior slot stay zero) and the rotation-prior blocks (k_reduce / k_dense; zero
+        // when the window has none).  One block, one memset.
+        double *zb = nullptr;
+        ok &= dev(pool_, "zero_block", Ns * 42 + 1, &zb, &grew);
+        v.prior_gd = zb, v.rot_H = zb + Ns * 30, v.rot_g = v.rot_H + Ns * 9, v.rot_cost = v.rot_g + Ns * 3;
+        if (ok && check(hipMemsetAsync(zb, 0, (dm.n_rot == 0 ? Ns * 42 + 1 : Ns * 30) * sizeof(double), stream_), "memset zero block")) return PVIO_ERR_HIP;
     }
     const size_t P = dm.P;
     ok &= dev(pool_, "Smat", dense_tile_doubles(dm), &v.Smat, &grew);
@@ -455,9 +456,27 @@ int BASolver::enqueue_slot(hipEvent_t *ev) {
         if ((e = launch_reduce(v_, stream_, 2)) != hipSuccess) return check(e, "k_reduce (image)");
     }
     if (ev) (void)hipEventRecord(ev[3], stream_);
+    // diagnostics (PVIO_HIP_DEBUG_CTRL=1, plain launches only): the control block as each kernel of the slot leaves it
+    static const bool dump_ctrl = std::getenv("PVIO_HIP_DEBUG_CTRL") != nullptr;
+    auto dump = [&](const char *after) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(stream_, &cs);
+        if (!dump_ctrl || cs != hipStreamCaptureStatusNone) return;
+        Ctrl h;
+        (void)hipStreamSynchronize(stream_);
+        (void)hipMemcpy(&h, v_.ctrl, sizeof h, hipMemcpyDeviceToHost);
+        std::fprintf(stderr, "[ctrl after %-11s] mode %d lin_result %d cur %d lin %d iter %d succ %d invalid %d term %d done %d reuse %d solve_ok %d scaling %d trace %d retry %d | radius %.6e mu %.3e x_cost %.9e "
+                             "xn2 %.6e %.6e gmax %.3e | g2 %.6e gn2 %.6e gdot %.6e qvv %.6e qvy %.6e qyy %.6e gy %.6e lm_g2 %.6e | ca %.6e cb %.6e sn %.6e mcc %.6e | it %.6e %.3e %.3e %.3e v%d s%d | fin %d %d %.3e\n",
+                     after, h.mode, h.lin_result, h.cur, h.lin, h.iter, h.num_success, h.invalid_steps, h.termination, h.done, h.reuse, h.solve_ok, h.scaling_ready, h.trace_len, h.retry_relin, h.radius, h.mu, h.x_cost,
+                     h.x_norm2_pose, h.x_norm2_lm, h.grad_max, h.pose_g2, h.pose_gn2, h.pose_gdot, h.pose_qvv, h.pose_qvy, h.pose_qyy, h.pose_gy, h.lm_g2, h.ca, h.cb, h.dogleg_step_norm, h.model_cost_change,
+                     h.it_cost, h.it_cost_change, h.it_step_norm, h.it_rel, h.it_valid, h.it_success, h.fin_flags, h.fin_trace_slot, h.fin_lm_gmax);
+    };
+    dump("k_reduce");
     if ((e = launch_dense(v_, stream_)) != hipSuccess) return check(e, "k_dense");
+    dump("k_dense");
     if (ev) (void)hipEventRecord(ev[4], stream_);
     if (!v_.dm.fuse_backsub && (e = launch_backsub(v_, stream_)) != hipSuccess) return check(e, "k_backsub");
+    dump("k_backsub");
     if (ev) (void)hipEventRecord(ev[5], stream_);
     if (sharded_) {
         double *back_local = static_cast<double *>(pool_.get("back_local", kNumBackScal * sizeof(double)));

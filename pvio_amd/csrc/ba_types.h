@@ -142,6 +142,7 @@ struct View { // passed by value to every kernel
     double *back_red;  // [8]
     double *pre_H, *pre_g, *pre_cost;       // [N][900], [N][30], [N]
     double *prior_H, *prior_g, *prior_cost; // [(15n)^2], [15n], [1]
+    double *prior_gd;                       // [N][30] by FRAME: prior gradient [15], diagonal of the prior's H [15]; 0 where no prior
     // dense system
     double *Smat;      // tile image of the reduced system (systems too large for LDS)
     double *img;       // the unscaled reduced system as a tile image (lower block triangle, MFMA accumulator order), written by

@@ -287,6 +287,11 @@ inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) {
     *ms = (float)(b->t - a->t);
     return hipSuccess;
 }
+enum hipStreamCaptureStatus { hipStreamCaptureStatusNone, hipStreamCaptureStatusActive, hipStreamCaptureStatusInvalidated };
+inline hipError_t hipStreamIsCapturing(hipStream_t s, hipStreamCaptureStatus *st) {
+    *st = s->capturing ? hipStreamCaptureStatusActive : hipStreamCaptureStatusNone;
+    return hipSuccess;
+}
 inline hipError_t hipStreamBeginCapture(hipStream_t s, hipStreamCaptureMode) {
     s->capturing = true;
     s->graph = new std::vector<std::function<void()>>();

@@ -39,7 +39,13 @@ OPB_R2_DESC = """                for (int g = kDenseCols - 1; g >= 0; --g)
 OPB_DESC_UNCOND = """                for (int g = kDenseCols - 1; g >= 0; --g)
                     opB[g] = *reinterpret_cast<const lds_d2 *>(Lpan + 128 * (g < R ? nbk - 1 - g : b0));"""
 
+FIN_REF = "        Ctrl &cc = *c;\n        const int lr = cc.lin_result;\n        if (cc.it_success) cc.num_success++;"
+FIN_COPY = "        Ctrl cc = *c;\n        const int lr = cc.lin_result;\n        if (cc.it_success) cc.num_success++;"
+
 RECIPES = {
+    # round 3, second finding: a register copy of the control block in k_dense's Finalize section on top of the one in its control
+    # section -> the first factorization of every solve fails on the GPU (tests/micro/dbg_case.py shows the control block)
+    "fin_copy": dict(subs=[(FIN_REF, FIN_COPY)]),
     "shipped": dict(),
     "r2_asc": dict(subs=[(OPB_SHIPPED, OPB_R2_ASC)]),                      # round 2's product: passes
     "desc": dict(subs=[(OPB_SHIPPED, OPB_R2_DESC)]),                       # THE REPRODUCER: wrong results on the GPU
