@@ -99,7 +99,7 @@ def load(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("PVIO_HIP_LIB") or LIB_PATH  # (PVIO_HIP_LIB: another BUILD of the same library, for same-box experiments)
     if not os.path.exists(p):
         raise RuntimeError(
             "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -1143,6 +1143,9 @@ __device__ __forceinline__ double reduced_entry_terms(const View &v, double val,
 __global__ void __launch_bounds__(kRedElems *kRedGroups) k_reduce(View v, int nb_red, int phase) {
     // the control word is only needed before anything is written: its load travels together with the partials
     const int ctl_done = v.ctrl->done, ctl_result = v.ctrl->lin_result;
+    // Dims::img_scaled: once the Jacobi scaling of the solve exists the image is written as -(C S C) -- entry by entry the product
+    // k_dense formed when it loaded the tile, (S_ik (c_i c_k)) negated: what its accumulators hold, so that it loads without touching
+    const bool scale_img = v.dm.img_scaled && v.ctrl->scaling_ready;
     const size_t nS = (size_t)v.dm.n_tasks * 9, nV = (size_t)kNumPoseVec * v.dm.P6;
     const size_t total = nS + nV + kNumLinScal;
     if ((int)blockIdx.x >= nb_red) {
@@ -1159,7 +1162,9 @@ __global__ void __launch_bounds__(kRedElems *kRedGroups) k_reduce(View v, int nb
         if (k > i || i >= P) return;
         const int fa = i / d, ka = i - d * fa, fb = k / d, kb = k - d * fb;
         if (ka < 6 && kb < 6) return; // has a landmark / plane part: written by the thread that reduces it
-        v.img[pos] = reduced_entry_terms(v, 0.0, fa, ka, fb, kb);
+        double val = reduced_entry_terms(v, 0.0, fa, ka, fb, kb);
+        if (scale_img) val = -(val * (v.cpl[i] * v.cpl[k]));
+        v.img[pos] = val;
         return;
     }
     __shared__ double part[kRedGroups][kRedElems];
@@ -1214,8 +1219,12 @@ __global__ void __launch_bounds__(kRedElems *kRedGroups) k_reduce(View v, int nb
             int fi, fj, si, sj;
             unpack_task(v.task_desc[t], fi, fj, si, sj);
             const int ra = 3 * si + q / 3, ca = 3 * sj + q % 3; // coordinates inside frames fi (row of the task) and fj, fi <= fj
-            if (fi != fj) v.img[mat_at(d * fj + ca, d * fi + ra)] = reduced_entry_terms(v, r, fj, ca, fi, ra);
-            else if (ra >= ca) v.img[mat_at(d * fi + ra, d * fi + ca)] = reduced_entry_terms(v, r, fi, ra, fi, ca); // diagonal blocks come in full
+            if (fi != fj || ra >= ca) { // (diagonal blocks come in full: their upper half is not stored)
+                const int row = fi != fj ? d * fj + ca : d * fi + ra, col = fi != fj ? d * fi + ra : d * fi + ca;
+                double val = fi != fj ? reduced_entry_terms(v, r, fj, ca, fi, ra) : reduced_entry_terms(v, r, fi, ra, fi, ca);
+                if (scale_img) val = -(val * (v.cpl[row] * v.cpl[col]));
+                v.img[mat_at(row, col)] = val;
+            }
         }
     }
 }
@@ -1635,7 +1644,14 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
     // the reduced system arrives as a tile image: loaded straight into registers (the look-ahead form is only launched on one)
     const bool from_images = LA ? true : (LDSMAT && v.dm.use_img);
     int sbi[kSlots], sbk[kSlots];
-    lds_d2 raw[kSlots][2];
+    // the accumulators of the register-resident factorization: the tile requests land in them directly (the tile image holds the
+    // accumulator layout), so that a tile that needs no work -- Dims::img_scaled -- costs no instruction at all
+    mfma_d4 acc[kSlots];
+#define PV_LOAD_TILE(i, T)                                                       \
+    do {                                                                         \
+        const lds_d2 t01 = *reinterpret_cast<const lds_d2 *>(T), t23 = *reinterpret_cast<const lds_d2 *>((T) + 2); \
+        acc[i][0] = t01[0], acc[i][1] = t01[1], acc[i][2] = t23[0], acc[i][3] = t23[1]; \
+    } while (0)
     if constexpr (LDSMAT) {
 #pragma unroll
         for (int i = 0; i < kSlots; ++i) {
@@ -1645,7 +1661,7 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
             sbi[i] = valid ? nbk - 1 - h : 0;
         }
 #pragma unroll
-        for (int i = 0; i < kSlots; ++i) raw[i][0][0] = 0.0, raw[i][0][1] = 0.0, raw[i][1][0] = 0.0, raw[i][1][1] = 0.0;
+        for (int i = 0; i < kSlots; ++i) acc[i][0] = 0.0, acc[i][1] = 0.0, acc[i][2] = 0.0, acc[i][3] = 0.0;
     }
     // gradient max-norm, state / trace copies (and v^T S v: qvv_back) are finished by k_backsub (always, in the look-ahead form)
     const bool split = LA ? true : v.dm.split_fin != 0;
@@ -1702,15 +1718,14 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
         // flight times the latency of memory the producers -- other XCDs -- wrote to), which is the longest single item in front of the
         // first panel: it has to start NOW and run under everything else.  vmcnt retires in order, so round 1 is back long before;
         // for the compiler to know that -- to wait for "all but the last 52 requests" instead of for everything -- the NUMBER of tile
-        // requests must not depend on anything: a slot this wave does not own re-reads tile 0 (a hit in the CU's cache).
+        // requests must not depend on anything: a slot this wave does not own reads the all-zero tile kept behind the image.
         if constexpr (early) {
             PV_ORDER(); // round 1 is requested FIRST: requests retire in the order they were made
 #pragma unroll
             for (int i = 0; i < kSlots; ++i) {
-                const int ti = sbk[i] >= 0 ? ((sbi[i] * (sbi[i] + 1)) >> 1) + sbk[i] : 0;
+                const int ti = sbk[i] >= 0 ? ((sbi[i] * (sbi[i] + 1)) >> 1) + sbk[i] : (v.dm.img_sz >> 8); // (the tile behind the image: zeros)
                 const double *T = v.img + ((size_t)ti << 8) + 4 * lane;
-                raw[i][0] = *reinterpret_cast<const lds_d2 *>(T);
-                raw[i][1] = *reinterpret_cast<const lds_d2 *>(T + 2);
+                PV_LOAD_TILE(i, T);
             }
         }
     }
@@ -1776,8 +1791,7 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
             for (int i = 0; i < kSlots; ++i)
                 if (from_images && sbk[i] >= 0) {
                     const double *T = v.img + ((size_t)(((sbi[i] * (sbi[i] + 1)) >> 1) + sbk[i]) << 8) + 4 * lane;
-                    raw[i][0] = *reinterpret_cast<const lds_d2 *>(T);
-                    raw[i][1] = *reinterpret_cast<const lds_d2 *>(T + 2);
+                    PV_LOAD_TILE(i, T);
                 }
         }
     }
@@ -1905,8 +1919,7 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
             for (int i = 0; i < kSlots; ++i)
                 if (from_images && sbk[i] >= 0) {
                     const double *T = v.img + ((size_t)(((sbi[i] * (sbi[i] + 1)) >> 1) + sbk[i]) << 8) + 4 * lane;
-                    raw[i][0] = *reinterpret_cast<const lds_d2 *>(T);
-                    raw[i][1] = *reinterpret_cast<const lds_d2 *>(T + 2);
+                    PV_LOAD_TILE(i, T);
                 }
         }
     }
@@ -2044,7 +2057,10 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
     if (v.dbg && tid == 0 && (v.dbg_sel < 0 || v.dbg_sel == 1 || v.dbg_sel == 2)) v.dbg[2 * 32 + 1] = sh.stamp1, v.dbg[2 * 32 + 2] = sh.stamp2;
     // ---------------- Jacobi scaling (once), dogleg diagonal, scaled system ----------------
     if (!early) dense_scale_vectors();
-    if (first_scaling && tid < P) v.cp[tid] = keep_cp; // (one coordinate per thread: P <= nthr)
+    if (first_scaling && tid < P) v.cp[tid] = keep_cp, v.cpl[tid] = cpl[tid]; // (one coordinate per thread: P <= nthr; cpl: own entry)
+    if (tid < P) v.vraw[tid] = vv[tid];                                       // v = g^ / D (k_backsub: v^T S v from the scaled image)
+    const bool img_scaled = LA && v.dm.img_scaled && !first_scaling;         // what k_reduce wrote in this slot (it read the same flag)
+    if (tid == 0) c->img_scaled_now = img_scaled ? 1 : 0;
     if (from_images) {
         if (!early) __syncthreads(); // (early: the barriers behind Finalize already separate the scaling from its readers)
         PV_STAMP2(21);
@@ -2101,7 +2117,6 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
         // entries into L (row Pp = right-hand side -> forward substitution for free).  The system is padded with identity
         // rows to whole panels, so nothing in the loop depends on a partial panel.
         double *Xs = Lp, *Lf = A;
-        mfma_d4 acc[kSlots];
         if (!from_images) {
 #pragma unroll
             for (int i = 0; i < kSlots; ++i) {
@@ -2120,7 +2135,7 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
             const int brow = Pp >> 4; // tile row of the rhs row
             double q = 0;
             if (v.dbg) { // profiling: when the last tile request is back (requests retire in order)
-                double last = raw[kSlots - 1][1][1];
+                double last = acc[kSlots - 1][3];
                 PV_KEEP(last);
                 PV_STAMP2T(18, LA ? 64 : 0);
             }
@@ -2144,15 +2159,21 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
 #pragma unroll
                 for (int r = 0; r < 4; ++r) rowop[qq][r] = *reinterpret_cast<const lds_d2 *>(cv + 2 * (16 * bi + lk + 4 * r));
             }
+            if (img_scaled) {
+                // The image IS -(C S C) (k_reduce scaled and negated it, Dims::img_scaled) and the requests delivered it into the
+                // accumulators: nothing to do here.  What the image cannot hold -- the mu D^2 / unit diagonal and the scaled rhs in row
+                // Pp, both of which this launch has only just formed -- is added by the factor wave when it takes a panel's columns out
+                // of Xs (`late_patch` below): 8 diagonal entries and one row per panel, from the LDS vectors, instead of a walk over all
+                // 26 accumulator slots (11 500 cycles of execute-once code: instruction fetch, not arithmetic).
+            } else
 #pragma unroll
             for (int i = 0; i < kSlots; ++i) {
-                acc[i][0] = 0, acc[i][1] = 0, acc[i][2] = 0, acc[i][3] = 0;
                 if (sbk[i] >= 0) {
                     const int bi = sbi[i], bk = sbk[i];
                     const lds_d2 ck = colop[dt_slot_col<LA>(i)];
                     // C is 0 on inactive and padding coordinates, the image is 0 above the diagonal and outside
                     // the real rows: one formula for every entry, the structural entries are patched below
-                    double val[4] = {raw[i][0][0], raw[i][0][1], raw[i][1][0], raw[i][1][1]};
+                    double val[4] = {acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
                     const double vk2 = 2.0 * ck[1];
                     if (v.dm.qvv_back) { // v^T S v comes from k_backsub (same image, C v from HBM): scaling only
 #pragma unroll
@@ -2222,11 +2243,20 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
             //                      publish its 8 columns into Xs -> flag_pub += 1 -> rank-8 update of the other columns
             // Xs is single-buffered: the update waves overwrite it only after flag_L = p + 1, i.e. after wave 0 has read every
             // row of panel p; Lf(p) and Lf(p + 1) are different regions.
+            const bool late_patch = img_scaled; // (uniform)
             if (wv == 0) {
                 int pidx = 0;
                 for (int j0 = 0; j0 < Pp; j0 += kPanel, ++pidx) {
                     if (j0 == 0) PV_STAMP2(8);
                     if (j0 == 80) PV_STAMP2(13);
+                    // late_patch: this panel's diagonal patch and its piece of the rhs row are requested from LDS BEFORE the wait for the
+                    // update waves (they do not depend on them): the latency disappears in the wait
+                    lds_d2 dg2[4], rh2[4];
+                    if (late_patch) {
+#pragma unroll
+                        for (int h = 0; h < 4; ++h) dg2[h] = *reinterpret_cast<const lds_d2 *>(yv + j0 + 2 * h), rh2[h] = *reinterpret_cast<const lds_d2 *>(diagH + j0 + 2 * h);
+                        PV_ORDER(); // (the requests stay in front of the wait)
+                    }
                     dense_wait(flag_pub, 3 * (pidx + 1));
                     double Ld[kPanel][kPanel], inv[kPanel];
 #pragma unroll
@@ -2245,12 +2275,24 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
                     double x[kPass][kPanel];
 #pragma unroll
                     for (int t = 0; t < kPass; ++t) {
-                        const int irow = j0 + lane + 64 * t, ir = irow < LDV ? irow : LDV - 1;
+                        // rows counted from the END (row LDV - 1 - lane - 64 t): the rhs row Pp (LDV - 16 or LDV - 8) sits in the same lane of
+                        // pass 0 in EVERY panel
+                        const int irow = LDV - 1 - lane - 64 * t, ir = irow >= j0 ? irow : j0;
 #pragma unroll
                         for (int h = 0; h < 4; ++h) {
                             const lds_d2 g2 = *reinterpret_cast<const lds_d2 *>(Xs + ir * 8 + 2 * h);
                             x[t][2 * h] = -g2[0], x[t][2 * h + 1] = -g2[1];
                         }
+                    }
+                    if (late_patch) {
+                        // the accumulators started from -(C S C) alone: the diagonal patch (mu D^2, or 1 on an inactive / padding
+                        // coordinate) and the scaled rhs of row Pp join here, where the panel's columns leave Xs (a sum is a sum:
+                        // the rank-8 updates that came first do not care)
+#pragma unroll
+                        for (int h = 0; h < 4; ++h) Ld[2 * h][2 * h] += dg2[h][0], Ld[2 * h + 1][2 * h + 1] += dg2[h][1];
+                        const double is_rhs = lane == LDV - 1 - Pp ? 1.0 : 0.0; // row Pp: one lane of pass 0 (the rows are dealt from the end)
+#pragma unroll
+                        for (int h = 0; h < 4; ++h) x[0][2 * h] += is_rhs * rh2[h][0], x[0][2 * h + 1] += is_rhs * rh2[h][1];
                     }
                     double Ls[kPanel][kPanel];
 #pragma unroll
@@ -2285,11 +2327,11 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
                     }
 #pragma unroll
                     for (int t = 0; t < kPass; ++t) {
-                        const int irow = j0 + lane + 64 * t;
-                        if (irow < LDV) {
+                        const int irow = LDV - 1 - lane - 64 * t;
+                        if (irow >= j0) {
 #pragma unroll
                             for (int cc = 0; cc < kPanel; ++cc) x[t][cc] = (j0 + cc <= irow) ? x[t][cc] * inv[cc] : 0.0;
-                            lds_d2 *Lrow = reinterpret_cast<lds_d2 *>(Lf + lfo + 8 * (lane + 64 * t));
+                            lds_d2 *Lrow = reinterpret_cast<lds_d2 *>(Lf + lfo + 8 * (irow - j0));
 #pragma unroll
                             for (int h = 0; h < 4; ++h) {
                                 lds_d2 pr;
@@ -3013,6 +3055,10 @@ __global__ void __launch_bounds__(256) k_backsub(View v) {
     const int lc_first = l_first < M ? l_first : M - 1;
     int o0n = v.lm_ptr[lc_first], o1n = v.lm_ptr[lc_first + 1], an = v.lm_anchor[lc_first];
     for (int e = threadIdx.x; e < P; e += blockDim.x) stepv[e] = v.vstep[e], stepy[e] = v.ystep[e];
+    __shared__ double rawv[kMaxFrames * 15];
+    const bool scaled_img = v.dm.img_scaled && c->img_scaled_now;
+    if (v.dm.img_scaled)
+        for (int e = threadIdx.x; e < P; e += blockDim.x) rawv[e] = v.vraw[e];
     // qvv_back: this workgroup's tiles of the reduced system's image (written by k_reduce, loaded by k_dense) for the pose part of
     // v^T H v = (C v)^T H (C v): thread = one entry of a tile (MFMA accumulator order: entry e of lane e >> 2, r = e & 3)
     const int n_lm_wg = v.dm.split_fin ? v.dm.G_back : (int)gridDim.x; // landmark workgroups (the finalize workgroup is not one)
@@ -3031,7 +3077,8 @@ __global__ void __launch_bounds__(256) k_backsub(View v) {
         while (((bi * (bi + 1)) >> 1) > t) --bi;
         const int bk = t - ((bi * (bi + 1)) >> 1), ln = threadIdx.x >> 2, r = threadIdx.x & 3;
         hi = 16 * bi + (ln >> 4) + 4 * r, hk = 16 * bk + (ln & 15);
-        if (hi < P && hk <= hi) s[6] += (hi == hk ? himg : 2.0 * himg) * stepv[hi] * stepv[hk]; // the image is the lower triangle
+        // (the image is the lower triangle; scaled_img: it holds -(C S C), and v^T (C S C) v takes v = g^ / D itself)
+        if (hi < P && hk <= hi) s[6] += scaled_img ? (hi == hk ? -himg : -2.0 * himg) * rawv[hi] * rawv[hk] : (hi == hk ? himg : 2.0 * himg) * stepv[hi] * stepv[hk];
     }
     for (int l0 = blockIdx.x * per_block; l0 < M; l0 += n_lm_wg * per_block) { // uniform trip count per block
         const int l = l0 + (threadIdx.x >> 4);

@@ -377,10 +377,17 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st) {
         static const int la_env = std::getenv("PVIO_HIP_DENSE_LA") ? std::atoi(std::getenv("PVIO_HIP_DENSE_LA")) : -1;
         dm.dense_la = (lds_matrix && dm.use_img && (la_env < 0 ? kDenseLookAheadDefault : la_env != 0)) ? 1 : 0;
         v.dm.dense_la = dm.dense_la;
-        ok &= dev(pool_, "img", img_sz, &v.img, &grew);
-        if (ok && v.dm.use_img && check(hipMemsetAsync(v.img, 0, img_sz * sizeof(double), stream_), "memset img")) return PVIO_ERR_HIP;
+        // the image in the form the accumulators hold once the scaling exists (PVIO_HIP_IMG_SCALED=0: k_dense scales every time)
+        static const bool img_scaled_off = std::getenv("PVIO_HIP_IMG_SCALED") != nullptr && std::atoi(std::getenv("PVIO_HIP_IMG_SCALED")) == 0;
+        dm.img_scaled = (dm.dense_la && dm.split_fin && dm.qvv_back && !img_scaled_off) ? 1 : 0;
+        v.dm.img_scaled = dm.img_scaled;
+        // (+ one tile of zeros behind the image: what k_dense's waves load into the accumulator slots they do not own)
+        ok &= dev(pool_, "img", img_sz + 256, &v.img, &grew);
+        if (ok && v.dm.use_img && check(hipMemsetAsync(v.img, 0, (img_sz + 256) * sizeof(double), stream_), "memset img")) return PVIO_ERR_HIP;
     }
     ok &= dev(pool_, "cp", P, &v.cp, &grew);
+    ok &= dev(pool_, "cpl", P, &v.cpl, &grew);
+    ok &= dev(pool_, "vraw", P, &v.vraw, &grew);
     ok &= dev(pool_, "Dp", P, &v.Dp, &grew);
     ok &= dev(pool_, "gtot", P, &v.gtot, &grew);
     ok &= dev(pool_, "ghp", P, &v.ghp, &grew);

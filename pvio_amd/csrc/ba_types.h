@@ -72,6 +72,9 @@ struct Ctrl {
     int32_t fin_flags;       // kFinTrace | kFinAccepted | kFinFirst; 0 = nothing pending
     int32_t fin_trace_slot;  // trace record of the iteration (or -1)
     double fin_lm_gmax;      // max |b_l| of the accepted linearization (landmark part of the gradient max-norm)
+    // Dims::img_scaled: the tile image k_dense factored in this slot was the SCALED, negated system -(C S C) (k_reduce applies the
+    // Jacobi scaling once it exists); k_backsub forms v^T S v from the same image and has to know which one it is
+    int32_t img_scaled_now, reserved0;
 };
 enum : int32_t { kFinTrace = 1, kFinAccepted = 2, kFinFirst = 4 };
 
@@ -99,6 +102,8 @@ struct Dims {
                           // (qvv_back) the pose part of v^T H v to k_backsub, where they run beside the landmark back-substitution
     int32_t qvv_back;     // v^T S v from the tile image in k_backsub (partials in back_part[.][6]) instead of k_dense
     int32_t dense_la;     // register-resident factorization in its look-ahead form (wave 0 factors panel p + 1 while waves 1..3 apply panel p)
+    int32_t img_scaled;   // look-ahead form: once the Jacobi scaling exists (after the first factoring launch of a solve) k_reduce writes the
+                          // image as -(C S C), the form the accumulators hold, and k_dense loads it without touching it (Ctrl::img_scaled_now)
     int32_t lm_mm;        // landmark workgroups accumulate the Schur complement as 16x16 f64 MFMA tiles and walk a contiguous chunk range
 };
 
@@ -148,6 +153,7 @@ struct View { // passed by value to every kernel
     double *img;       // the unscaled reduced system as a tile image (lower block triangle, MFMA accumulator order), written by
                        // k_reduce; zero wherever nothing is ever written
     double *cp, *Dp, *gtot, *ghp, *vstep, *ystep; // [P] each
+    double *cpl, *vraw; // [P] each: Jacobi scale with 0 on inactive coordinates (img_scaled: read by k_reduce); v = g^ / D before C is applied
     // trace
     TraceRec *trace;
     double *trace_states;

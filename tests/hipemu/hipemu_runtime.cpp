@@ -86,6 +86,18 @@ void wave_exchange(const void *in, void *out_all, size_t elem) {
 
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+std::vector<Guarded> &guarded() {
+    static std::vector<Guarded> g;
+    return g;
+}
+void check_guards(const char *where) {
+    for (const Guarded &a : guarded())
+        for (int k = -256; k < 256; ++k)
+            if ((unsigned char)(k < 0 ? a.p[k] : a.p[a.n + k]) != 0x5C) {
+                std::fprintf(stderr, "hipemu: %s (kernel %s): write %d bytes past the end of a device allocation of %zu bytes\n", where, g_kernel_name ? g_kernel_name : "?", k, a.n);
+                std::abort();
+            }
+}
 void launch(dim3 grid, dim3 block, size_t shmem, Stream *s, std::function<void()> body) {
     auto run = [grid, block, shmem, body]() mutable {
         ++launch_counter;
@@ -159,6 +171,7 @@ void launch(dim3 grid, dim3 block, size_t shmem, Stream *s, std::function<void()
                     }
                 }
         g_cur = nullptr;
+        check_guards("after the launch");
     };
     if (s && s->capturing)
         s->graph->push_back(run);

@@ -217,25 +217,43 @@ inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) {
     p->totalGlobalMem = 1ull << 34;
     return hipSuccess;
 }
+// every device allocation carries 256 guard bytes behind it; hipemu_check_guards() (after every kernel, at every free) aborts with the
+// size of the allocation a kernel wrote past
+namespace hipemu {
+struct Guarded { char *p; size_t n; };
+std::vector<Guarded> &guarded();
+void check_guards(const char *where);
+} // namespace hipemu
 template <typename T>
 inline hipError_t hipMalloc(T **p, size_t n) {
-    *p = (T *)std::malloc(n ? n : 1);
-    if (*p) std::memset((void *)*p, 0xA5, n); // poison: catches reads of never-written device memory
+    char *q = (char *)std::malloc((n ? n : 1) + 512);
+    if (q) {
+        std::memset((void *)q, 0x5C, 256);
+        q += 256;
+        std::memset((void *)q, 0xA5, n); // poison: catches reads of never-written device memory
+        std::memset((void *)(q + n), 0x5C, 256);
+        hipemu::guarded().push_back({q, n});
+    }
+    *p = (T *)q;
     return *p ? hipSuccess : hipErrorOutOfMemory;
 }
 template <typename T>
 inline hipError_t hipHostMalloc(T **p, size_t n, unsigned = 0) {
-    *p = (T *)std::malloc(n ? n : 1);
-    return *p ? hipSuccess : hipErrorOutOfMemory;
+    return hipMalloc(p, n);
 }
 inline hipError_t hipFree(void *p) {
+    hipemu::check_guards("hipFree");
+    auto &g = hipemu::guarded();
+    for (size_t i = 0; i < g.size(); ++i)
+        if (g[i].p == p) {
+            g.erase(g.begin() + (std::ptrdiff_t)i);
+            std::free((char *)p - 256);
+            return hipSuccess;
+        }
     std::free(p);
     return hipSuccess;
 }
-inline hipError_t hipHostFree(void *p) {
-    std::free(p);
-    return hipSuccess;
-}
+inline hipError_t hipHostFree(void *p) { return hipFree(p); }
 inline void hipemu_enqueue(hipStream_t s, std::function<void()> f) {
     if (s && s->capturing)
         s->graph->push_back(std::move(f));
