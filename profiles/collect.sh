@@ -1,14 +1,14 @@
 #!/bin/bash
 # Collects the round's evidence on the GPU box: run from the repo root through gpurun, e.g.
-#   gpurun --timeout 1500 -- 'bash profiles/collect.sh r2'
+#   gpurun --timeout 1500 -- 'bash profiles/collect.sh r3'
 # Everything lands in gpurun_out/<tag>_*; copy what should be judged into profiles/.
 set -u
-TAG=${1:-r2}
+TAG=${1:-r3}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-(cd $R && python -m pytest tests -m gpu -q 2>&1 | grep -v "^RCCL version\|^HIP version\|^ROCm version\|^Hostname\|^Librccl path" | tail -5) > $OUT/${TAG}_pytest_gpu.txt
+(cd $R && PVIO_CHAIN_REPORT=$OUT/${TAG}_chain_parity.json python -m pytest tests -m gpu -q --durations=8 2>&1 | grep -v "^RCCL version\|^HIP version\|^ROCm version\|^Hostname\|^Librccl path" | tail -16) > $OUT/${TAG}_pytest_gpu.txt
 # large windows (k_linearize in its matrix-core form): bench lines + kernel stats + HBM counters of the 30 KF x 50k VIO window
 for W in 30x50000_vio 30x50000_vision 10x50000_vio; do
   python $R/bench.py --workload $W --steps 10 --warmup 2 --no-klt --no-cpu-baseline > $OUT/${TAG}_bench_$W.json 2> $OUT/${TAG}_bench_$W.err
@@ -26,9 +26,8 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_pro
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_prof_write -- python $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline --no-scaling-window > $OUT/${TAG}_prof_write.log 2>&1
 python $R/profiles/summarize_pmc.py $OUT/${TAG}_prof_fetch $OUT/${TAG}_prof_write $OUT/${TAG}_pmc_hbm.json > /dev/null
 find $OUT/${TAG}_prof_stats -name '*kernel_stats.csv' -exec cp {} $OUT/${TAG}_kernel_stats_bench_vio.csv \;
-# the headline lines come AFTER the counter passes: bench.py prints roofline.traffic from the PMC summary only when it was collected on
-# exactly these kernel sources (fingerprint), i.e. from the file written just above
-cp $OUT/${TAG}_pmc_hbm.json $R/profiles/${TAG}_pmc_hbm.json 2>/dev/null
+# the headline lines (round 3: bench.py collects roofline.traffic itself, with two counter passes of its own run; the summary above is the
+# independent collection it can be compared with)
 python $R/bench.py > $OUT/${TAG}_bench_vio.json 2> $OUT/${TAG}_bench_vio.err
 python $R/bench.py --workload vision > $OUT/${TAG}_bench_vision.json 2> $OUT/${TAG}_bench_vision.err
 # the multi-GPU code path with the one rank there is: process group, RCCL communicator, sharded iteration (captured in the hipGraph)
@@ -39,6 +38,7 @@ python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.
 (cd $R && python tests/prof_upload.py) > $OUT/${TAG}_prof_upload.txt 2>&1
 (cd $R && python tests/prof_klt.py) > $OUT/${TAG}_prof_klt.txt 2>&1
 (cd $R && python tests/prof_dense_large.py) > $OUT/${TAG}_prof_dense_large.txt 2>&1
+(cd $R && python tests/prof_phases.py) > $OUT/${TAG}_prof_phases.txt 2>&1
 # the raw traces are large: keep the summaries only
 rm -rf $OUT/${TAG}_prof_fetch/*/*kernel_trace.csv $OUT/${TAG}_prof_write/*/*kernel_trace.csv 2>/dev/null
 ls -la $OUT | head -40
