@@ -1,5 +1,5 @@
 """Ad-hoc parity sweep on the GPU: 60 windows of random shape (2-32 frames, 10-1500 landmarks, visibility, plane share, inertial
-or not, a fixed frame) against the oracle with the test tolerances.  Last run: 57 pass at 1e-8 .. 1e-14; the three that do not are
+or not, a fixed frame) against the oracle with the test tolerances.  Last run (round 3, profiles/r3_sweep_random_windows.txt): 58 pass at 1e-8 .. 1e-15; the two that do not (round 2: three) are
 vision-only windows whose landmarks are all seen by exactly two frames (no gauge, barely observable depths): <= 1.5e-5 in the
 inverse depths -- and the kernel emulator (CPU double arithmetic, the kernels' summation order) is off by the same amount on
 them, i.e. conditioning, not device arithmetic."""
