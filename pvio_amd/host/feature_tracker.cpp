@@ -8,7 +8,25 @@ namespace pvio {
 HostFeatureTracker::HostFeatureTracker(std::shared_ptr<Config> config) : map(std::make_unique<Map>()), config(std::move(config)) {}
 HostFeatureTracker::~HostFeatureTracker() = default;
 
+// The reference's forensics timer of FeatureTracker::work (core/feature_tracker.cpp:38-46: the running average behind pvio-pc's "FT Time"
+// graph, main.cpp:165-167): the reference's own `make_timer` / `critical_forensics` inside the PVIO tree, nothing in the standalone build.
+#ifdef PVIO_HOST_USE_REFERENCE_TYPES
+#define PVIO_HOST_FT_TIMER()                                                 \
+    auto ft_timer = make_timer([](double t) {                                \
+        critical_forensics(feature_tracker_time, time) {                     \
+            static double avg_time = 0;                                      \
+            static double avg_count = 0;                                     \
+            avg_time = (avg_time * avg_count + t) / (avg_count + 1);         \
+            avg_count += 1.0;                                                \
+            time = avg_time;                                                 \
+        }                                                                    \
+    })
+#else
+#define PVIO_HOST_FT_TIMER() ((void)0)
+#endif
+
 void HostFeatureTracker::track_frame(std::unique_ptr<Frame> frame) {
+    PVIO_HOST_FT_TIMER();
     frame->image->preprocess(); // HipImage: upload (+ undistortion), CLAHE, pyramid, Scharr on the device
 
     size_t optimized_id = nil();
