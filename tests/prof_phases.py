@@ -8,7 +8,7 @@ from pvio_amd import synth, BASummary
 from pvio_amd.solver import HipContext, preintegrate
 
 DENSE_SITES = [(28, "round 1 of requests back"), (29, "control inputs in LDS"), (1, "control done"), (2, "vectors assembled"), (3, "finalize done"), (4, "scaled vectors"), (18, "wave 1: last tile request back"), (19, "wave 1: tiles scaled"), (8, "tiles scaled, first panel starts"),
-               (10, "panel 0: L rows stored"), (11, "panel 0: update done"), (12, "panel 0: end"), (13, "panel 10 starts"), (17, "panel 10: end"),
+               (10, "panel 0: L rows stored"), (11, "panel 0: update done"), (12, "panel 0: end"), (13, "panel 10 starts"), (14, "panel 10: pivot loop done"), (15, "panel 10: L rows stored"), (17, "panel 10: end"),
                (5, "factorization done"), (6, "back substitution done"), (7, "end")]
 LIN_SITES = [(1, "prologue done"), (2, "first chunk: cleared"), (3, "factors evaluated"), (4, "landmark sums"), (5, "landmark scalars"), (6, "tile accumulation starts"),
              (7, "tiles accumulated"), (8, "partial row flushed"), (9, "end")]
