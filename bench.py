@@ -171,10 +171,32 @@ def bench_klt(ctx, args, width=512, height=512, n_points=1500, reps=50):
     for _ in range(20):
         corners, _ = detect_corners(ctx, A)  # Harris response + NMS on the device, ordering + min-distance selection on the host
     detect_ms = 1e3 * (time.perf_counter() - t0) / 20
+    # the outlier rejection of a frame: cv::findFundamentalMat(FM_RANSAC, 1 px, 0.99) over the tracked matches, hypotheses in batches on the device
+    from pvio_amd.solver import fundamental_ransac
+    # (matches of a 3-D scene seen by two cameras 0.3 m apart, 0.3 px of noise, every tenth match a gross outlier: the image pair above is a
+    # plane under a homography, for which the fundamental matrix is not unique)
+    rr = np.random.default_rng(8)
+    Kc = np.array([[458.654, 0, 367.215], [0, 457.296, 248.375], [0, 0, 1]])
+    X3 = np.stack([rr.uniform(-3, 3, n_points), rr.uniform(-2, 2, n_points), rr.uniform(3, 9, n_points)], 1)
+    ang = 0.06
+    R2 = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]])
+    proj = lambda Xc: (Kc @ (Xc / Xc[:, 2:3]).T).T[:, :2]
+    rp = (proj(X3) + rr.normal(0, 0.3, (n_points, 2))).astype(np.float32)
+    rq = proj((R2 @ X3.T).T + np.array([0.3, 0.02, 0.05])) + rr.normal(0, 0.3, (n_points, 2))
+    rq[::10] += rr.uniform(8, 60, (len(rq[::10]), 2)) * rr.choice([-1, 1], (len(rq[::10]), 2))
+    rq = rq.astype(np.float32)
+    for _ in range(3):
+        fundamental_ransac(ctx, rp, rq)
+    t0 = time.perf_counter()
+    for _ in range(20):
+        r_good, _, _, r_hyp = fundamental_ransac(ctx, rp, rq)
+    ransac_ms = 1e3 * (time.perf_counter() - t0) / 20
     alg_bytes = 11616 * n_points  # 4 levels x (22^2 u8 template + 22^2 x 2 int16 derivatives + 22^2 u8 target)
     out = {"metric": "KLT tracks/ms", "value": n_points / dev_ms, "unit": "tracks/ms", "value_incl_h2d_d2h": n_points / wall_ms,
            "workload": "%dx%d u8 pair, %d tracks, win 21x21, 4 levels, <=30 iterations, initial flow given" % (width, height, n_points),
            "tracked": int(st.sum()), "preprocess_ms_per_image": prep_ms, "preprocess_undistorted_ms_per_image": prep_ud_ms, "detect_ms_per_image": detect_ms, "detected_corners": int(len(corners)),
+           "ransac_ms_per_frame": ransac_ms, "ransac": {"matches": int(len(rp)), "inliers": int(r_good), "hypotheses_evaluated": int(r_hyp),
+                                                         "what": "pvio_hip_fundamental_ransac incl. the copies, 10 % gross outliers"},
            "roofline": {"bound": "hbm", "kernel": "k_lk_track", "achieved": alg_bytes / (dev_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": alg_bytes / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc_traffic("k_lk_track", args), "algorithmic_bytes_per_launch": alg_bytes,
                         "avg_launch_us": dev_ms * 1e3}}

@@ -292,6 +292,15 @@ int32_t pvio_hip_image_download_response(pvio_hip_ctx *ctx, const pvio_hip_image
 /* hipEvent duration [ms] of the LK kernel of the last pvio_hip_klt_track call (bench.py: tracks/ms, pyramids resident) */
 double pvio_hip_klt_last_device_ms(const pvio_hip_ctx *ctx);
 
+/* Fundamental-matrix RANSAC of OpenCvImage::track_keypoints (opencv_image.cpp:113-129: cv::findFundamentalMat(p, q, FM_RANSAC, 1.0, 0.99,
+ * mask), of which the reference uses the inlier mask only).  The samples are drawn on the host in cv::RNG's order, the hypotheses of a
+ * batch are solved (7-point) and scored against all n matches on the device, the host replays the adaptive iteration count: the result is
+ * the sequential algorithm's.  p_xy / q_xy: n points (x, y) each, single precision like cv::Point2f; mask[n] = 1 for the inliers of the best
+ * model; F row-major (may be NULL); *n_inliers = 0 and an all-zero mask when no model was found or n < 7. */
+int32_t pvio_hip_fundamental_ransac(pvio_hip_ctx *ctx, int32_t n, const float *p_xy, const float *q_xy, double threshold, double confidence,
+                                    int32_t max_iterations, uint8_t *mask, double F[9], int32_t *n_inliers);
+int32_t pvio_hip_ransac_last_hypotheses(const pvio_hip_ctx *ctx);
+
 #ifdef __cplusplus
 }
 #endif

@@ -87,7 +87,7 @@ EXPORTS = [
     "pvio_hip_ba_upload", "pvio_hip_ba_solve_resident", "pvio_hip_ba_download", "pvio_hip_ba_profile_resident",
     "pvio_hip_comm_unique_id", "pvio_hip_comm_init", "pvio_preintegrate",
     "pvio_hip_image_create", "pvio_hip_image_release", "pvio_hip_image_download_level", "pvio_hip_klt_track", "pvio_hip_image_detect", "pvio_hip_image_download_response",
-    "pvio_hip_klt_last_device_ms",
+    "pvio_hip_klt_last_device_ms", "pvio_hip_fundamental_ransac", "pvio_hip_ransac_last_hypotheses",
     "pvio_hip_undistort_create", "pvio_hip_undistort_release", "pvio_hip_image_create_undistorted",
 ]
 
@@ -156,6 +156,11 @@ def load(path=None):
     lib.pvio_hip_image_download_response.restype = C.c_int32
     lib.pvio_hip_klt_last_device_ms.argtypes = [vp]
     lib.pvio_hip_klt_last_device_ms.restype = C.c_double
+    lib.pvio_hip_fundamental_ransac.argtypes = [vp, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_double, C.c_double, C.c_int32, c_uint8_p, c_double_p,
+                                                C.POINTER(C.c_int32)]
+    lib.pvio_hip_fundamental_ransac.restype = C.c_int32
+    lib.pvio_hip_ransac_last_hypotheses.argtypes = [vp]
+    lib.pvio_hip_ransac_last_hypotheses.restype = C.c_int32
     if path is None:
         _lib = lib
     return lib

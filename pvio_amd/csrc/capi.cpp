@@ -156,4 +156,14 @@ int32_t pvio_hip_klt_track(pvio_hip_ctx *ctx, const pvio_hip_image *prev, const 
 
 double pvio_hip_klt_last_device_ms(const pvio_hip_ctx *ctx) { return ctx ? ctx->klt->last_track_ms() : 0.0; }
 
+int32_t pvio_hip_fundamental_ransac(pvio_hip_ctx *ctx, int32_t n, const float *p_xy, const float *q_xy, double threshold, double confidence,
+                                    int32_t max_iterations, uint8_t *mask, double F[9], int32_t *n_inliers) {
+    if (!ctx || n < 0 || (n > 0 && (!p_xy || !q_xy || !mask)) || !n_inliers || max_iterations < 1) return PVIO_ERR_INVALID_ARGUMENT;
+    int good = 0;
+    const int rc = ctx->klt->fundamental_ransac(n, p_xy, q_xy, threshold, confidence, max_iterations, mask, F, &good);
+    *n_inliers = good;
+    return rc;
+}
+int32_t pvio_hip_ransac_last_hypotheses(const pvio_hip_ctx *ctx) { return ctx ? ctx->klt->last_ransac_hypotheses() : 0; }
+
 } // extern "C"

@@ -26,6 +26,9 @@ class Klt {
     // Harris corners of level 0 (cv::goodFeaturesToTrack semantics); xy / response need room for max_corners entries
     int detect(const Image *img, int max_corners, double quality, double min_distance, float *xy, float *response, int *n_out);
     int download_response(const Image *img, float *resp);
+    // cv::findFundamentalMat(p, q, FM_RANSAC, threshold, confidence) with the hypotheses evaluated in batches on the device; mask[n]
+    int fundamental_ransac(int n, const float *p, const float *q, double threshold, double confidence, int max_iterations, uint8_t *mask, double *F_out, int *n_inliers);
+    int last_ransac_hypotheses() const { return last_fm_hypotheses_; } // hypotheses the last run evaluated (diagnostics)
     const std::string &error() const { return err_; }
     double last_track_ms() const { return last_ms_; } // hipEvent time of the last k_lk_track launch
 
@@ -38,6 +41,9 @@ class Klt {
     void *d_pts_ = nullptr;
     size_t pts_cap_ = 0;
     void *h_pts_ = nullptr; // pinned mirror of d_pts_
+    void *d_fm_ = nullptr, *h_fm_ = nullptr; // fundamental_ransac: points, samples, counts, models, mask words (+ pinned mirror)
+    size_t fm_cap_ = 0;
+    int last_fm_hypotheses_ = 0;
     void *d_src_ = nullptr; // distorted source pixels of the image being built
     size_t src_cap_ = 0;
     void *d_det_ = nullptr; // detection scratch: cov planes, response map, candidates

@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "../../include/pvio_hip.h"
+#include "pv_fundamental.h"
 
 namespace pvklt {
 
@@ -459,6 +460,8 @@ Klt::~Klt() {
     if (d_det_) (void)hipFree(d_det_);
     if (d_src_) (void)hipFree(d_src_);
     if (h_pts_) (void)hipHostFree(h_pts_);
+    if (d_fm_) (void)hipFree(d_fm_);
+    if (h_fm_) (void)hipHostFree(h_fm_);
     if (det_host_) (void)hipHostFree(det_host_);
     for (auto &s : slab_pool_) (void)hipFree(s.second);
     if (staging_) (void)hipHostFree(staging_);
@@ -996,6 +999,152 @@ int Klt::download_response(const Image *img, float *resp) { // tests: the last d
     }
     const float *r = static_cast<const float *>(d_det_) + 3 * px;
     if (hipMemcpy(resp, r, px * 4, hipMemcpyDeviceToHost) != hipSuccess) return PVIO_ERR_HIP;
+    return PVIO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Fundamental-matrix RANSAC, hypotheses in batches (opencv_image.cpp:113-129).
+//
+// cv::findFundamentalMat(FM_RANSAC) is a sequential hypothesise-and-verify loop, but the only thing a hypothesis needs from its
+// predecessors is WHETHER it still has to be looked at (the adaptive iteration count): the samples come from a generator and the points
+// alone (pv_fundamental.h: fm_draw_sample).  So the host draws the samples of a batch, the device turns every sample into its (up to
+// three) models and scores each against all the matches -- one wave per sample: the 7-point solver runs redundantly in every lane, the
+// lanes then stride over the points, one ballot per 64 points gives the inlier mask words and the count -- and the host replays the
+// loop's bookkeeping over the counts in the original order (a model replaces the best when it has MORE inliers, the iteration count
+// shrinks as in RANSACUpdateNumIters).  Hypotheses drawn beyond the point where the sequential loop stops are simply not looked at:
+// the result is the sequential algorithm's.  Batches of 48, 192, then the rest: at the inlier ratios of a tracker (>= 80 %) the first
+// batch ends the run.
+// ------------------------------------------------------------------------------------------------------------------------------
+struct FundArgs {
+    int n, nw;                  // matches; 64-bit mask words per model
+    const float *p, *q;         // [n][2]
+    const float *samples;       // [H][28]: the seven sample points of either image
+    double thr2;
+    int *counts;                // [H][4]: number of models, inliers of each
+    double *models;             // [H][27]
+    unsigned long long *masks;  // [H][3][nw]
+};
+
+__global__ void __launch_bounds__(64) k_fund_hypotheses(FundArgs a) {
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+    const int h = blockIdx.x, lane = threadIdx.x;
+    float sp[14], sq[14];
+#pragma unroll
+    for (int k = 0; k < 14; ++k) sp[k] = a.samples[(size_t)h * 28 + k], sq[k] = a.samples[(size_t)h * 28 + 14 + k];
+    double F[27];
+    for (int k = 0; k < 27; ++k) F[k] = 0.0;
+    const int nm = pvfm::fm_seven_point(sp, sq, F); // every lane the same arithmetic on the same numbers
+    for (int m = 0; m < 3; ++m) {
+        int count = 0;
+        for (int i0 = 0; i0 < a.n; i0 += 64) {
+            const int i = i0 + lane;
+            int in = 0;
+            if (i < a.n && m < nm) in = pvfm::fm_error(F + 9 * m, a.p[2 * i], a.p[2 * i + 1], a.q[2 * i], a.q[2 * i + 1]) <= a.thr2 ? 1 : 0;
+            const unsigned long long word = __ballot(in);
+            if (lane == 0) a.masks[((size_t)h * 3 + m) * a.nw + (i0 >> 6)] = word;
+            count += __popcll(word);
+        }
+        if (lane == 0) a.counts[4 * h + 1 + m] = count;
+    }
+    if (lane == 0) a.counts[4 * h] = nm;
+    if (lane < 27) a.models[(size_t)h * 27 + lane] = F[lane];
+}
+
+int Klt::fundamental_ransac(int n, const float *p, const float *q, double threshold, double confidence, int max_iterations, uint8_t *mask, double *F_out, int *n_inliers) {
+    constexpr int kModel = 7;
+    *n_inliers = 0;
+    for (int i = 0; i < n; ++i) mask[i] = 0;
+    last_fm_hypotheses_ = 0;
+    if (n < kModel) return PVIO_OK;
+    (void)hipSetDevice(device_);
+    const int nw = (n + 63) / 64;
+    const int cap_h = std::max(1, std::min(max_iterations, 1000));
+    // one device block + its pinned mirror: [p | q | samples | counts | models | masks]
+    const size_t off_q = (size_t)n * 8, off_s = off_q + (size_t)n * 8, off_c = (off_s + (size_t)cap_h * 28 * 4 + 15) & ~(size_t)15,
+                 off_m = off_c + (size_t)cap_h * 16, off_k = off_m + (size_t)cap_h * 27 * 8, total = off_k + (size_t)cap_h * 3 * nw * 8;
+    if (total > fm_cap_) {
+        if (d_fm_) (void)hipFree(d_fm_);
+        if (h_fm_) (void)hipHostFree(h_fm_);
+        d_fm_ = h_fm_ = nullptr, fm_cap_ = 0;
+        if (hipMalloc(&d_fm_, total) != hipSuccess || hipHostMalloc(&h_fm_, total) != hipSuccess) {
+            err_ = "fundamental_ransac: allocation failed";
+            return PVIO_ERR_OUT_OF_MEMORY;
+        }
+        fm_cap_ = total;
+    }
+    char *hb = static_cast<char *>(h_fm_), *db = static_cast<char *>(d_fm_);
+    std::memcpy(hb, p, (size_t)n * 8), std::memcpy(hb + off_q, q, (size_t)n * 8);
+    if (hipMemcpyAsync(db, hb, off_s, hipMemcpyHostToDevice, stream_) != hipSuccess) {
+        err_ = "fundamental_ransac: upload failed";
+        return PVIO_ERR_HIP;
+    }
+    pvfm::FmRng rng((uint64_t)-1);
+    int niters = n == kModel ? 1 : max_iterations, iter = 0, max_good = 0;
+    double bestF[9] = {0};
+    std::vector<unsigned long long> best_words((size_t)nw, 0);
+    float *hs = reinterpret_cast<float *>(hb + off_s);
+    int batch = 48;
+    bool exhausted = false;
+    while (iter < niters && !exhausted) {
+        int H = std::min(std::min(batch, niters - iter), cap_h);
+        batch = batch == 48 ? 192 : cap_h;
+        int drawn = 0;
+        for (; drawn < H; ++drawn) {
+            float *sp = hs + (size_t)drawn * 28, *sq = sp + 14;
+            if (n > kModel) {
+                if (!pvfm::fm_draw_sample(rng, n, p, q, sp, sq)) {
+                    exhausted = true; // no admissible sample any more: the sequential loop stops where it gets here
+                    break;
+                }
+            } else {
+                std::memcpy(sp, p, 56), std::memcpy(sq, q, 56);
+            }
+        }
+        H = drawn;
+        if (H == 0) break;
+        FundArgs a;
+        a.n = n, a.nw = nw, a.p = reinterpret_cast<const float *>(db), a.q = reinterpret_cast<const float *>(db + off_q);
+        a.samples = reinterpret_cast<const float *>(db + off_s), a.thr2 = threshold * threshold;
+        a.counts = reinterpret_cast<int *>(db + off_c), a.models = reinterpret_cast<double *>(db + off_m), a.masks = reinterpret_cast<unsigned long long *>(db + off_k);
+        bool ok = hipMemcpyAsync(db + off_s, hb + off_s, (size_t)H * 28 * 4, hipMemcpyHostToDevice, stream_) == hipSuccess;
+        hipLaunchKernelGGL(k_fund_hypotheses, dim3(H), dim3(64), 0, stream_, a);
+        // counts and models come back now; the mask words of ONE model are fetched once the replay knows which (they are 3 nw words per
+        // hypothesis: copying them all would be most of the traffic)
+        ok = ok && hipMemcpyAsync(hb + off_c, db + off_c, (off_m - off_c) + (size_t)H * 27 * 8, hipMemcpyDeviceToHost, stream_) == hipSuccess;
+        ok = ok && hipStreamSynchronize(stream_) == hipSuccess && hipGetLastError() == hipSuccess;
+        if (!ok) {
+            err_ = "fundamental_ransac: batch failed";
+            return PVIO_ERR_HIP;
+        }
+        last_fm_hypotheses_ += H;
+        const int *cnt = reinterpret_cast<const int *>(hb + off_c);
+        const double *models = reinterpret_cast<const double *>(hb + off_m);
+        int win_h = -1, win_m = -1;
+        for (int hh = 0; hh < H && iter < niters; ++hh, ++iter) {
+            const int nm = cnt[4 * hh];
+            for (int m = 0; m < nm; ++m) {
+                const int good = cnt[4 * hh + 1 + m];
+                if (good > std::max(max_good, kModel - 1)) {
+                    win_h = hh, win_m = m, max_good = good;
+                    std::memcpy(bestF, models + (size_t)hh * 27 + 9 * m, sizeof bestF);
+                    niters = pvfm::fm_update_iterations(confidence, (double)(n - good) / n, kModel, niters);
+                }
+            }
+        }
+        if (win_h >= 0) { // the best model of the run so far lives in this batch: its mask words
+            if (hipMemcpy(best_words.data(), a.masks + ((size_t)win_h * 3 + win_m) * nw, (size_t)nw * 8, hipMemcpyDeviceToHost) != hipSuccess) {
+                err_ = "fundamental_ransac: mask download failed";
+                return PVIO_ERR_HIP;
+            }
+        }
+    }
+    if (max_good > 0) {
+        for (int i = 0; i < n; ++i) mask[i] = (uint8_t)((best_words[(size_t)i >> 6] >> (i & 63)) & 1ull);
+        if (F_out) std::memcpy(F_out, bestF, sizeof bestF);
+    }
+    *n_inliers = max_good;
     return PVIO_OK;
 }
 

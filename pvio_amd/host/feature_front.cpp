@@ -260,8 +260,12 @@ void HipImage::track_keypoints(const Image *next_image, const std::vector<vector
                 p.push_back(prev_xy[2 * i]), p.push_back(prev_xy[2 * i + 1]), q.push_back(next_xy[2 * i]), q.push_back(next_xy[2 * i + 1]);
             }
         if (l.size() >= 8) {
-            std::vector<uint8_t> mask;
-            find_fundamental_ransac((int)l.size(), p.data(), q.data(), 1.0, 0.99, mask);
+            // hypotheses in batches on the device, the adaptive stopping rule replayed on the host (pvio_hip_fundamental_ransac; the
+            // sequential host form, fundamental_ransac.h, is what the tests hold it against)
+            std::vector<uint8_t> mask(l.size(), 0);
+            int32_t good = 0;
+            const int32_t rc = pvio_hip_fundamental_ransac(ctx_, (int32_t)l.size(), p.data(), q.data(), 1.0, 0.99, 1000, mask.data(), nullptr, &good);
+            if (rc != 0) throw std::runtime_error(std::string("pvio_hip_fundamental_ransac: ") + pvio_hip_last_error(ctx_)); // no CPU path
             for (size_t i = 0; i < l.size(); ++i)
                 if (mask[i] == 0) result_status[l[i]] = 0;
         }

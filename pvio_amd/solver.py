@@ -160,6 +160,19 @@ def klt_track(ctx, prev, nxt, prev_xy, next_xy_init):
     return q, st, ctx.lib.pvio_hip_klt_last_device_ms(ctx.ctx)
 
 
+def fundamental_ransac(ctx, p_xy, q_xy, threshold=1.0, confidence=0.99, max_iterations=1000):
+    """pvio_hip_fundamental_ransac: cv::findFundamentalMat(FM_RANSAC) with the hypotheses evaluated in batches on the device.
+    -> (inlier count, mask uint8 [n], F 3x3, hypotheses evaluated)"""
+    p = np.ascontiguousarray(p_xy, dtype=np.float32)
+    q = np.ascontiguousarray(q_xy, dtype=np.float32)
+    n = p.shape[0]
+    mask, F, good = np.zeros(max(n, 1), np.uint8), np.zeros(9), C.c_int32(0)
+    fp = C.POINTER(C.c_float)
+    ctx._check(ctx.lib.pvio_hip_fundamental_ransac(ctx.ctx, n, p.ctypes.data_as(fp), q.ctypes.data_as(fp), float(threshold), float(confidence), int(max_iterations),
+                                                   mask.ctypes.data_as(capi.c_uint8_p), F.ctypes.data_as(capi.c_double_p), C.byref(good)), "fundamental_ransac")
+    return good.value, mask[:n], F.reshape(3, 3), int(ctx.lib.pvio_hip_ransac_last_hypotheses(ctx.ctx))
+
+
 def preintegrate(t, w, a, t_end, bg, ba, noise, lib=None):
     """Product host-side pre-integration (pvio_preintegrate); same signature as oracle_py.preintegrate."""
     lib = lib or capi.load()

@@ -146,6 +146,7 @@ inline int __builtin_amdgcn_readfirstlane(int v) {
     hipemu::wave_exchange(&v, all, sizeof(int));
     return all[0];
 }
+inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline unsigned long long __ballot(int pred) {
     int all[64];
     hipemu::wave_exchange(&pred, all, sizeof(int));

@@ -120,3 +120,74 @@ def test_ransac_degenerate_inputs(host):
     assert good == 0 and not mask.any()
     o_good, o_mask, _ = run_oracle(p, p.copy())
     assert o_good == 0 and not o_mask.any()
+
+
+# ---- the batched device form (pvio_hip_fundamental_ransac: what HipImage::track_keypoints calls) ---------------------------------------
+DEVICE_CASES = [(300, 0.2, 0.3, 2), (120, 0.4, 0.2, 3), (60, 0.0, 0.5, 4), (800, 0.1, 0.1, 5), (9, 0.0, 0.05, 6), (1500, 0.1, 0.3, 8), (200, 0.6, 0.2, 9)]
+
+
+def _check_device(ctx, host, n, frac, noise, seed):
+    """The device form against the sequential host form (same arithmetic, pv_fundamental.h: same winner, same mask up to threshold ties of
+    the device's libm) and against the C++ oracle (another null-space algorithm)."""
+    from pvio_amd.solver import fundamental_ransac
+    p, q, out = two_views(n, frac, noise, seed)
+    good, mask, F, hyp = fundamental_ransac(ctx, p, q)
+    mask = mask.astype(bool)
+    assert good == mask.sum()
+    h_good, h_mask, h_F = run_host(host, p, q)
+    o_good, o_mask, o_F = run_oracle(p, q)
+    tol = max(1, n // 200)
+    assert (mask != h_mask).sum() <= tol and abs(good - h_good) <= tol, ("vs host form", good, h_good)
+    assert (mask != o_mask).sum() <= tol and abs(good - o_good) <= tol, ("vs oracle", good, o_good)
+    if good and (mask == h_mask).all():
+        assert np.abs(F / np.linalg.norm(F) - h_F / np.linalg.norm(h_F)).max() < 1e-9
+    assert mask[out].sum() <= max(1, int(0.02 * n))
+    return good, hyp
+
+
+@pytest.mark.parametrize("n,frac,noise,seed", DEVICE_CASES[:5])
+def test_device_ransac_emulated(host, n, frac, noise, seed):
+    from pvio_amd import capi
+    from pvio_amd.solver import HipContext
+    ctx = HipContext(lib=capi.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "hipemu", "libpvio_hipemu.so")))
+    try:
+        print(_check_device(ctx, host, n, frac, noise, seed))
+    finally:
+        ctx.close()
+
+
+def test_device_ransac_degenerate_inputs_emulated(host):
+    from pvio_amd import capi
+    from pvio_amd.solver import HipContext, fundamental_ransac
+    ctx = HipContext(lib=capi.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "hipemu", "libpvio_hipemu.so")))
+    try:
+        p, q, _ = two_views(6, 0.0, 0.0, 7)
+        good, mask, _, _ = fundamental_ransac(ctx, p, q)
+        assert good == 0 and not mask.any()
+        p = np.tile(np.array([[100.0, 120.0]], np.float32), (20, 1))
+        good, mask, _, _ = fundamental_ransac(ctx, p, p.copy())
+        assert good == 0 and not mask.any()
+        p, q, _ = two_views(7, 0.0, 0.05, 11)  # exactly seven points: one hypothesis, the points themselves
+        good, mask, _, hyp = fundamental_ransac(ctx, p, q)
+        assert hyp == 1 and good == run_host(host, p, q)[0]
+    finally:
+        ctx.close()
+
+
+@pytest.fixture(scope="module")
+def host_gpu():
+    """the same harness linked against the product library (the emulated build must not share a process with it: both define the kernels' symbols)"""
+    lib = host_compare.load("libpvio_host.so")
+    lib.host_ransac.restype = C.c_int
+    return lib
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,frac,noise,seed", DEVICE_CASES)
+def test_device_ransac_gpu(host_gpu, n, frac, noise, seed):
+    from pvio_amd.solver import HipContext
+    ctx = HipContext(device=0)
+    try:
+        print(_check_device(ctx, host_gpu, n, frac, noise, seed))
+    finally:
+        ctx.close()
