@@ -1,5 +1,9 @@
+"""Oracle and GPU traces of the named windows (tests/ba_compare.CASES) side by side.  PVIO_LIB=path picks a build of the library,
+PVIO_HIP_DEBUG_CTRL=1 makes the solver print the control block after every kernel of the first (plain-launch) solve.
+usage: python tests/micro/dbg_case.py CASE [CASE ...]"""
 import sys, os
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np
 import ba_compare
 from oracle import oracle_py as O

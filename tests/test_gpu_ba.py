@@ -233,7 +233,7 @@ def test_gpu_full_size_window_properties(oracle):
     np.testing.assert_allclose(st1.lm_inv_depth, st.lm_inv_depth, rtol=0, atol=1e-7)
 
 
-@pytest.mark.parametrize("name", ["vio_partial", "vio_plane", "metric_10x1000_vio", "vio_13_frames_global_matrix"])
+@pytest.mark.parametrize("name", ["vio_partial", "vio_plane", "metric_10x1000_vio", "vio_13_frames_global_matrix", "vio_duplicate_blocks"])
 def test_gpu_one_rank_communicator_runs_the_sharded_path(oracle, name):
     """The landmark-sharded code path on the one GPU there is: a ONE-rank RCCL communicator (ncclCommInitRank with nranks = 1)
     carries the real all-reduces on the solver's stream, launches are eager, the reduced system is assembled from the
