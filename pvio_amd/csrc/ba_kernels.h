@@ -15,5 +15,6 @@ hipError_t launch_dense(const View &v, hipStream_t st);
 hipError_t launch_backsub(const View &v, hipStream_t st);
 hipError_t launch_back_reduce(const View &v, double *back_local, hipStream_t st);
 hipError_t launch_quality(const View &v, hipStream_t st, int buf_from_ctrl, double *err_sum);
+hipError_t launch_reset(const View &v, const double *fs_init, const double *rho_init, const Ctrl *tmpl, hipStream_t st);
 hipError_t launch_prior_prep(const double *S, const double *s, int D, double *Lambda, double *eta, double *ST, hipStream_t st);
 } // namespace pvba

@@ -3350,6 +3350,25 @@ hipError_t launch_quality(const View &v, hipStream_t st, int buf_from_ctrl, doub
     hipLaunchKernelGGL(k_quality, dim3(grid), dim3(256), 0, st, v, buf_from_ctrl, err_sum);
     return hipGetLastError();
 }
+// The reset in front of a solve -- accepted iterate <- initial state, user state <- initial state, control block <- its template -- as ONE
+// launch (three device-to-device copies and a host-to-device copy of the control block cost four stream operations per solve before)
+__global__ void __launch_bounds__(256) k_reset(View v, const double *fs_init, const double *rho_init, const Ctrl *tmpl) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    const size_t nf = (size_t)v.dm.N * 16, M = (size_t)v.dm.M;
+    for (size_t e = i; e < nf; e += stride) {
+        const double x = fs_init[e];
+        v.fs[e] = x, v.fs_user[e] = x;
+    }
+    for (size_t e = i; e < M; e += stride) v.rho[e] = rho_init[e];
+    if (blockIdx.x == 0 && threadIdx.x < sizeof(Ctrl) / sizeof(double))
+        reinterpret_cast<double *>(v.ctrl)[threadIdx.x] = reinterpret_cast<const double *>(tmpl)[threadIdx.x];
+}
+hipError_t launch_reset(const View &v, const double *fs_init, const double *rho_init, const Ctrl *tmpl, hipStream_t st) {
+    int grid = (int)(((size_t)v.dm.M + 255) / 256);
+    grid = grid < 1 ? 1 : (grid > 512 ? 512 : grid);
+    hipLaunchKernelGGL(k_reset, dim3(grid), dim3(256), 0, st, v, fs_init, rho_init, tmpl);
+    return hipGetLastError();
+}
 hipError_t launch_prior_prep(const double *S, const double *s, int D, double *Lambda, double *eta, double *ST, hipStream_t st) {
     int grid = (D * (D + 1) + 255) / 256;
     hipLaunchKernelGGL(k_prior_prep, dim3(grid), dim3(256), 0, st, S, s, D, Lambda, eta, ST);

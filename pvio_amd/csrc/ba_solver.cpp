@@ -558,18 +558,26 @@ int BASolver::solve(pvio_ba_summary *sum, pvio_ba_kernel_times *prof) {
         }
     }
     // reset: state buffer 0 <- initial state, user state, control block
-    const double *fs_init = fs_init_, *rho_init = rho_init_;
-    if (check(hipMemcpyAsync(v_.fs, fs_init, Ns * 16 * sizeof(double), hipMemcpyDeviceToDevice, stream_), "reset fs")) return PVIO_ERR_HIP;
-    if (check(hipMemcpyAsync(v_.fs_user, fs_init, Ns * 16 * sizeof(double), hipMemcpyDeviceToDevice, stream_), "reset user")) return PVIO_ERR_HIP;
-    if (dm.M && check(hipMemcpyAsync(v_.rho, rho_init, (size_t)dm.M * sizeof(double), hipMemcpyDeviceToDevice, stream_), "reset rho")) return PVIO_ERR_HIP;
-    std::memset(h_ctrl_, 0, sizeof(Ctrl));
-    h_ctrl_->mode = MODE_INIT;
-    h_ctrl_->radius = 1e4;        // initial_trust_region_radius
-    h_ctrl_->mu = 1e-8;           // DoglegStrategy kMinMu
-    h_ctrl_->termination = PVIO_TERM_NO_CONVERGENCE;
-    h_ctrl_->trace_cap = trace_cap_;
-    h_ctrl_->dbg_fail_left = dbg_fail_, h_ctrl_->dbg_invalid_left = dbg_invalid_;
-    if (check(hipMemcpyAsync(v_.ctrl, h_ctrl_, sizeof(Ctrl), hipMemcpyHostToDevice, stream_), "reset ctrl")) return PVIO_ERR_HIP;
+    // (one launch: k_reset; the control block's template lives on the device and is sent again only when it changes)
+    {
+        Ctrl t;
+        std::memset(&t, 0, sizeof t);
+        t.mode = MODE_INIT;
+        t.radius = 1e4;        // initial_trust_region_radius
+        t.mu = 1e-8;           // DoglegStrategy kMinMu
+        t.termination = PVIO_TERM_NO_CONVERGENCE;
+        t.trace_cap = trace_cap_;
+        t.dbg_fail_left = dbg_fail_, t.dbg_invalid_left = dbg_invalid_;
+        bool grew = false;
+        Ctrl *d_tmpl = nullptr;
+        if (!dev(pool_, "ctrl_template", 1, &d_tmpl, &grew)) return fail(PVIO_ERR_OUT_OF_MEMORY, "ctrl template");
+        if (grew || d_tmpl != d_ctrl_tmpl_ || std::memcmp(&t, &h_ctrl_tmpl_, sizeof t) != 0) {
+            h_ctrl_tmpl_ = t, d_ctrl_tmpl_ = d_tmpl;
+            // (pageable source: the copy is staged by the runtime before the call returns)
+            if (check(hipMemcpyAsync(d_tmpl, &h_ctrl_tmpl_, sizeof t, hipMemcpyHostToDevice, stream_), "ctrl template")) return PVIO_ERR_HIP;
+        }
+        if (check(launch_reset(v_, fs_init_, rho_init_, d_tmpl, stream_), "k_reset")) return PVIO_ERR_HIP;
+    }
     if (check(hipEventRecord(ev0_, stream_), "event")) return PVIO_ERR_HIP;
     // every slot = one pass of [linearize, reduce, dense, backsub]; iteration 0 + max_iter iterations; relaunch while the device
     // has not reported done

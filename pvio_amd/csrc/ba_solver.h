@@ -72,6 +72,8 @@ class BASolver {
     void *h_stage_ = nullptr; // pinned staging of one upload's inputs
     size_t h_stage_cap_ = 0;
     const double *fs_init_ = nullptr, *rho_init_ = nullptr; // initial state inside the inputs slab
+    Ctrl h_ctrl_tmpl_{};                                    // what a solve's control block starts from (k_reset copies the device copy)
+    Ctrl *d_ctrl_tmpl_ = nullptr;
     int trace_cap_ = 0;
     bool want_trace_states_ = false;
     hipGraph_t graph_ = nullptr;
