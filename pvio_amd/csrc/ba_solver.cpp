@@ -106,7 +106,7 @@ static bool dev(DevicePool &pool, const char *name, size_t n, T **dst, bool *gre
     return p != nullptr;
 }
 
-int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st) {
+int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st, bool may_return_early) {
     if (!pb || !st || !st->frame_state) return fail(PVIO_ERR_INVALID_ARGUMENT, "null problem/state");
     const int N = pb->n_frames, M = pb->n_landmarks, F = pb->n_obs;
     if (N < 1 || N > kMaxFrames) return fail(PVIO_ERR_UNSUPPORTED, "n_frames must be in [1, 32]");
@@ -259,7 +259,7 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st) {
             for (int s = 0; s < 4; ++s) task_desc.push_back(fi | (fj << 8) | ((s >> 1) << 16) | ((s & 1) << 17));
 
     // ---- device buffers ----
-    bool grew = false;
+    bool grew = false, sent_directly = false;
     View v{};
     v.dm = dm;
     const size_t Ns = N, Ms = std::max(M, 1), Fs = std::max(F, 1);
@@ -431,8 +431,10 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st) {
         }
         if (check(hipMemcpyAsync(slab, h_stage_, staged, hipMemcpyHostToDevice, stream_), "H2D inputs")) return PVIO_ERR_HIP;
         for (const auto &it : stage.items)
-            if (it.src && it.bytes >= kDirect && check(hipMemcpyAsync(slab + it.off, it.src, it.bytes, hipMemcpyHostToDevice, stream_), "H2D inputs"))
-                return PVIO_ERR_HIP;
+            if (it.src && it.bytes >= kDirect) {
+                if (check(hipMemcpyAsync(slab + it.off, it.src, it.bytes, hipMemcpyHostToDevice, stream_), "H2D inputs")) return PVIO_ERR_HIP;
+                sent_directly = true;
+            }
     }
     if (lm_mult.empty()) v.lm_mult = nullptr; // no duplicates: the kernels take the unscaled path
     if (dm.prior_n > 0 && check(launch_prior_prep(v.prior_S, v.prior_s, (int)Dp, Lambda, eta, ST, stream_), "k_prior_prep")) return PVIO_ERR_HIP;
@@ -442,6 +444,11 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st) {
     v_ = v;
     uploaded_ = true;
     solves_since_upload_ = 0;
+    // The caller of the public entry point may release its arrays as soon as this returns, and arrays that went straight from where they
+    // lay (>= 1 MB; some of them temporaries of this function) must have left: wait.  A solve that follows immediately on the same stream
+    // (pvio_hip_ba_solve: may_return_early) synchronizes anyway before ITS caller gets the arrays back; the staged part was copied into the
+    // pinned buffer above, which is not written again before the next upload.
+    if (may_return_early && !sent_directly) return PVIO_OK;
     return check(hipStreamSynchronize(stream_), "upload sync");
 }
 

@@ -40,7 +40,7 @@ class BASolver {
     void set_fault_injection(int fail_factorizations, int invalid_steps) { dbg_fail_ = fail_factorizations, dbg_invalid_ = invalid_steps; }
     void set_linearize_mode(int m) { lin_mode_ = m; }
     ~BASolver();
-    int upload(const pvio_ba_problem *pb, const pvio_ba_state *st);   // H2D of the flat problem + initial state
+    int upload(const pvio_ba_problem *pb, const pvio_ba_state *st, bool may_return_early = false);   // H2D of the flat problem + initial state
     int solve(pvio_ba_summary *sum, pvio_ba_kernel_times *prof = nullptr); // runs from the uploaded initial state
     int download(pvio_ba_state *st);                                   // D2H of the accepted iterate (+ quality pass)
     int reprojection_error(double *out);

@@ -78,7 +78,7 @@ int32_t pvio_hip_ba_download(pvio_hip_ctx *ctx, pvio_ba_state *state) {
 }
 int32_t pvio_hip_ba_solve(pvio_hip_ctx *ctx, const pvio_ba_problem *problem, pvio_ba_state *state, pvio_ba_summary *summary) {
     if (!ctx || !problem || !state) return PVIO_ERR_INVALID_ARGUMENT;
-    int rc = ctx->ba->upload(problem, state);
+    int rc = ctx->ba->upload(problem, state, /*may_return_early=*/true); // (the solve below synchronizes before the arrays go back to the caller)
     if (rc != PVIO_OK) return rc;
     rc = ctx->ba->solve(summary);
     if (rc != PVIO_OK) return rc;
