@@ -62,6 +62,7 @@ BASolver::~BASolver() {
     invalidate_graph();
     if (h_ctrl_) (void)hipHostFree(h_ctrl_);
     if (h_stage_) (void)hipHostFree(h_stage_);
+    if (h_back_) (void)hipHostFree(h_back_);
     if (ev0_) (void)hipEventDestroy(ev0_);
     if (ev1_) (void)hipEventDestroy(ev1_);
     if (stream_) (void)hipStreamDestroy(stream_);
@@ -798,10 +799,13 @@ int BASolver::marginalize(const pvio_ba_problem *pb, const pvio_ba_state *st, in
     if (victim < 0 || victim >= N || N < 2) return fail(PVIO_ERR_INVALID_ARGUMENT, "victim frame out of range");
     // marginalization always works on the full 15-dim error state and ignores FF_FIX_POSE; IMU factors are used
     // whenever they exist (:416-450), regardless of how the last solve was configured
+    static const bool timing = std::getenv("PVIO_HIP_TIMING") != nullptr; // diagnostics: where a marginalization's time goes
+    const auto tm0 = std::chrono::steady_clock::now();
     pvio_ba_problem p2 = *pb;
     p2.use_inertial = 1;
     int rc = upload(&p2, st);
     if (rc != PVIO_OK) return rc;
+    const auto tm1 = std::chrono::steady_clock::now();
     const Dims &dm = v_.dm;
     const size_t Ns = N;
     const double *fs_init = fs_init_, *rho_init = rho_init_;
@@ -820,22 +824,29 @@ int BASolver::marginalize(const pvio_ba_problem *pb, const pvio_ba_state *st, in
     // landmark shards: every rank holds the victim's landmarks of its own range only -> sum the reduced buffers (the IMU
     // factors, the old prior and the rotation prior are replicated and are added once, below, on every rank alike)
     if (sharded_ && comm_allreduce(comm_, v_.red, nS + nV + kNumLinScal + (size_t)world_, 0, stream_)) return fail(PVIO_ERR_COMM, "all-reduce failed");
-    std::vector<double> red(nS + nV + kNumLinScal), preH(Ns * 900), preg(Ns * 30);
+    // read-back into ONE pinned buffer: a D2H copy into pageable memory is staged synchronously by the runtime (about 20 us
+    // each, eight of them); into pinned memory the eight copies queue behind the kernels and cost one wait
     const size_t Dp = 15 * (size_t)dm.prior_n;
-    std::vector<double> priH(Dp * Dp), prig(Dp);
-    std::vector<int32_t> tasks(dm.n_tasks);
-    std::vector<double> rotH(Ns * 9), rotg(Ns * 3);
-    if (check(hipMemcpyAsync(rotH.data(), v_.rot_H, rotH.size() * sizeof(double), hipMemcpyDeviceToHost, stream_), "D2H")) return PVIO_ERR_HIP;
-    if (check(hipMemcpyAsync(rotg.data(), v_.rot_g, rotg.size() * sizeof(double), hipMemcpyDeviceToHost, stream_), "D2H")) return PVIO_ERR_HIP;
-    if (check(hipMemcpyAsync(red.data(), v_.red, red.size() * sizeof(double), hipMemcpyDeviceToHost, stream_), "D2H")) return PVIO_ERR_HIP;
-    if (check(hipMemcpyAsync(preH.data(), v_.pre_H, preH.size() * sizeof(double), hipMemcpyDeviceToHost, stream_), "D2H")) return PVIO_ERR_HIP;
-    if (check(hipMemcpyAsync(preg.data(), v_.pre_g, preg.size() * sizeof(double), hipMemcpyDeviceToHost, stream_), "D2H")) return PVIO_ERR_HIP;
-    if (Dp) {
-        if (check(hipMemcpyAsync(priH.data(), v_.prior_H, priH.size() * sizeof(double), hipMemcpyDeviceToHost, stream_), "D2H")) return PVIO_ERR_HIP;
-        if (check(hipMemcpyAsync(prig.data(), v_.prior_g, prig.size() * sizeof(double), hipMemcpyDeviceToHost, stream_), "D2H")) return PVIO_ERR_HIP;
+    const size_t n_back[8] = {nS + nV + kNumLinScal, Ns * 900, Ns * 30, Dp * Dp, Dp, Ns * 9, Ns * 3, ((size_t)dm.n_tasks + 1) / 2};
+    size_t off_back[9] = {0};
+    for (int k = 0; k < 8; ++k) off_back[k + 1] = off_back[k] + ((n_back[k] + 7) & ~(size_t)7);
+    if (off_back[8] > h_back_cap_) {
+        if (h_back_) (void)hipHostFree(h_back_);
+        h_back_ = nullptr, h_back_cap_ = 0;
+        const size_t cap = off_back[8] + off_back[8] / 4;
+        if (hipHostMalloc(reinterpret_cast<void **>(&h_back_), cap * sizeof(double)) != hipSuccess) return fail(PVIO_ERR_OUT_OF_MEMORY, "hipHostMalloc failed");
+        h_back_cap_ = cap;
     }
-    if (check(hipMemcpyAsync(tasks.data(), v_.task_desc, tasks.size() * sizeof(int32_t), hipMemcpyDeviceToHost, stream_), "D2H")) return PVIO_ERR_HIP;
+    const double *red = h_back_ + off_back[0], *preH = h_back_ + off_back[1], *preg = h_back_ + off_back[2], *priH = h_back_ + off_back[3];
+    const double *prig = h_back_ + off_back[4], *rotH = h_back_ + off_back[5], *rotg = h_back_ + off_back[6];
+    const int32_t *tasks = reinterpret_cast<const int32_t *>(h_back_ + off_back[7]);
+    const void *src_back[8] = {v_.red, v_.pre_H, v_.pre_g, v_.prior_H, v_.prior_g, v_.rot_H, v_.rot_g, v_.task_desc};
+    for (int k = 0; k < 8; ++k) {
+        const size_t bytes = k == 7 ? (size_t)dm.n_tasks * sizeof(int32_t) : n_back[k] * sizeof(double);
+        if (bytes && check(hipMemcpyAsync(h_back_ + off_back[k], src_back[k], bytes, hipMemcpyDeviceToHost, stream_), "D2H")) return PVIO_ERR_HIP;
+    }
     if (check(hipStreamSynchronize(stream_), "marginalize sync")) return PVIO_ERR_HIP;
+    const auto tm2 = std::chrono::steady_clock::now();
 
     // ---- assemble the 15N information matrix / vector ----
     const int D = 15 * N;
@@ -899,19 +910,26 @@ int BASolver::marginalize(const pvio_ba_problem *pb, const pvio_ba_state *st, in
     if (out->info_vector) std::memcpy(out->info_vector, cv.data(), sizeof(double) * R);
     // ---- sqrt information: sqrt(L) V^T and L^-1/2 V^T b, eigenvalues <= 1e-8 zeroed (:583-590) ----
     std::vector<double> w(R), V((size_t)R * R);
+    const auto tm3 = std::chrono::steady_clock::now();
     sym_eig(C.data(), R, w.data(), V.data());
+    const auto tm4 = std::chrono::steady_clock::now();
     out->n = N - 1;
     for (int k = 0; k < R; ++k) {
         const double lam = w[k] > 1.0e-8 ? w[k] : 0.0, lam_inv = w[k] > 1.0e-8 ? 1.0 / w[k] : 0.0;
         const double sl = std::sqrt(lam), sli = std::sqrt(lam_inv);
         double acc = 0;
         for (int i = 0; i < R; ++i) {
-            out->S[(size_t)k * R + i] = sl * V[(size_t)i * R + k];
-            acc += V[(size_t)i * R + k] * cv[i];
+            out->S[(size_t)k * R + i] = sl * V[(size_t)k * R + i];
+            acc += V[(size_t)k * R + i] * cv[i];
         }
         out->s[k] = sli * acc;
     }
     uploaded_ = false; // the device buffers now hold a marginalization pass, not a solvable window
+    if (timing) {
+        auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+        std::fprintf(stderr, "[pvio-hip] marginalize: upload %.0f us, kernels + read-back %.0f us, assembly + elimination %.0f us, eigen-decomposition (%d x %d) %.0f us, sqrt-information %.0f us\n",
+                     us(tm0, tm1), us(tm1, tm2), us(tm2, tm3), R, R, us(tm3, tm4), us(tm4, std::chrono::steady_clock::now()));
+    }
     return PVIO_OK;
 }
 

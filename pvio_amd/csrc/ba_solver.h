@@ -71,11 +71,12 @@ class BASolver {
     int cus_ = 0;
     void *h_stage_ = nullptr; // pinned staging of one upload's inputs
     size_t h_stage_cap_ = 0;
+    double *h_back_ = nullptr; // pinned read-back of one marginalization pass
+    size_t h_back_cap_ = 0;    // in doubles
     const double *fs_init_ = nullptr, *rho_init_ = nullptr; // initial state inside the inputs slab
     Ctrl h_ctrl_tmpl_{};                                    // what a solve's control block starts from (k_reset copies the device copy)
     Ctrl *d_ctrl_tmpl_ = nullptr;
     int trace_cap_ = 0;
-    bool want_trace_states_ = false;
     hipGraph_t graph_ = nullptr;
     hipGraphExec_t graph_exec_ = nullptr;
     int graph_slots_ = 0;
