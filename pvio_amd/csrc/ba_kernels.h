@@ -14,7 +14,12 @@ hipError_t launch_reduce(const View &v, hipStream_t st, int phase = 0); // phase
 hipError_t launch_dense(const View &v, hipStream_t st);
 hipError_t launch_backsub(const View &v, hipStream_t st);
 hipError_t launch_back_reduce(const View &v, double *back_local, hipStream_t st);
-hipError_t launch_quality(const View &v, hipStream_t st, int buf_from_ctrl, double *err_sum);
+hipError_t launch_quality(const View &v, hipStream_t st, int buf_from_ctrl, double *err_sum, double *pack = nullptr);
 hipError_t launch_reset(const View &v, const double *fs_init, const double *rho_init, const Ctrl *tmpl, hipStream_t st);
+struct GatherArgs {
+    const void *src[8];
+    uint32_t words[8], off[8]; // 32-bit words: length of segment k, its offset in the destination
+};
+hipError_t launch_gather(const GatherArgs &a, void *dst, hipStream_t st);
 hipError_t launch_prior_prep(const double *S, const double *s, int D, double *Lambda, double *eta, double *ST, hipStream_t st);
 } // namespace pvba

@@ -3159,12 +3159,17 @@ __global__ void k_back_reduce(View v, int rows, double *back_local) {
 // ------------------------------------------------------------------------------------------------------
 // post-solve quality pass (bundle_adjustor.cpp:277-296) and compute_reprojection_error (:321-336)
 // ------------------------------------------------------------------------------------------------------
-__global__ void k_quality(View v, int buf_from_ctrl, double *err_sum /* [2] optional: sum, count */) {
+// `pack` (optional, solve path): the accepted iterate and the pass's outputs in ONE contiguous buffer -- frame states [16N], inverse depths [M],
+// quality [M] (0 where the landmark was invalidated), valid bytes [M] -- so that a solve through the API reads its results back with one copy
+// queued behind the iterations instead of a second round of launches, pageable copies and synchronizations (BASolver::solve, fused read-back)
+__global__ void k_quality(View v, int buf_from_ctrl, double *err_sum /* [2] optional: sum, count */, double *pack) {
     __shared__ double scratch[2 * 16];
     const int N = v.dm.N, M = v.dm.M;
     const int cur = buf_from_ctrl ? v.ctrl->cur : 0;
     const double *fs = v.fs + (size_t)cur * N * 16, *rho = v.rho + (size_t)cur * M;
     double es = 0, en = 0;
+    if (pack && blockIdx.x == 0)
+        for (int e = threadIdx.x; e < 16 * N; e += blockDim.x) pack[e] = fs[e];
     for (int l = blockIdx.x * blockDim.x + threadIdx.x; l < M; l += gridDim.x * blockDim.x) {
         const int a = v.lm_anchor[l];
         double rec_a[kFrameRec], Rwc[9], pwc[3], y0[3], x[3], t[3];
@@ -3203,6 +3208,11 @@ __global__ void k_quality(View v, int buf_from_ctrl, double *err_sum /* [2] opti
         } else {
             if (v.lm_valid) v.lm_valid[l] = ok ? 1 : 0;
             if (ok && v.lm_quality) v.lm_quality[l] = q / fmax(qn, 1.0);
+            if (pack) {
+                pack[16 * (size_t)N + l] = rho[l];
+                pack[16 * (size_t)N + M + l] = ok ? q / fmax(qn, 1.0) : 0.0;
+                reinterpret_cast<unsigned char *>(pack + 16 * (size_t)N + 2 * (size_t)M)[l] = ok ? 1 : 0;
+            }
         }
     }
     if (err_sum) {
@@ -3343,11 +3353,11 @@ hipError_t launch_back_reduce(const View &v, double *back_local, hipStream_t st)
     hipLaunchKernelGGL(k_back_reduce, dim3(1), dim3(64), 0, st, v, v.dm.G_back, back_local);
     return hipGetLastError();
 }
-hipError_t launch_quality(const View &v, hipStream_t st, int buf_from_ctrl, double *err_sum) {
+hipError_t launch_quality(const View &v, hipStream_t st, int buf_from_ctrl, double *err_sum, double *pack) {
     int grid = (v.dm.M + 255) / 256;
     if (grid < 1) grid = 1;
     if (grid > 1024) grid = 1024;
-    hipLaunchKernelGGL(k_quality, dim3(grid), dim3(256), 0, st, v, buf_from_ctrl, err_sum);
+    hipLaunchKernelGGL(k_quality, dim3(grid), dim3(256), 0, st, v, buf_from_ctrl, err_sum, pack);
     return hipGetLastError();
 }
 // The reset in front of a solve -- accepted iterate <- initial state, user state <- initial state, control block <- its template -- as ONE
@@ -3367,6 +3377,17 @@ hipError_t launch_reset(const View &v, const double *fs_init, const double *rho_
     int grid = (int)(((size_t)v.dm.M + 255) / 256);
     grid = grid < 1 ? 1 : (grid > 512 ? 512 : grid);
     hipLaunchKernelGGL(k_reset, dim3(grid), dim3(256), 0, st, v, fs_init, rho_init, tmpl);
+    return hipGetLastError();
+}
+// Eight result arrays of a marginalization pass -> one contiguous buffer (one D2H copy instead of eight; 32-bit words, so that the int32
+// task table travels the same way as the FP64 arrays)
+__global__ void __launch_bounds__(256) k_gather(GatherArgs a, uint32_t *dst) {
+    const int seg = blockIdx.y;
+    const uint32_t *src = static_cast<const uint32_t *>(a.src[seg]);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < a.words[seg]; i += gridDim.x * blockDim.x) dst[a.off[seg] + i] = src[i];
+}
+hipError_t launch_gather(const GatherArgs &a, void *dst, hipStream_t st) {
+    hipLaunchKernelGGL(k_gather, dim3(32, 8), dim3(256), 0, st, a, static_cast<uint32_t *>(dst));
     return hipGetLastError();
 }
 hipError_t launch_prior_prep(const double *S, const double *s, int D, double *Lambda, double *eta, double *ST, hipStream_t st) {

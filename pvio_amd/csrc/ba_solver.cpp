@@ -63,6 +63,7 @@ BASolver::~BASolver() {
     if (h_ctrl_) (void)hipHostFree(h_ctrl_);
     if (h_stage_) (void)hipHostFree(h_stage_);
     if (h_back_) (void)hipHostFree(h_back_);
+    if (h_pack_) (void)hipHostFree(h_pack_);
     if (ev0_) (void)hipEventDestroy(ev0_);
     if (ev1_) (void)hipEventDestroy(ev1_);
     if (stream_) (void)hipStreamDestroy(stream_);
@@ -546,12 +547,26 @@ int BASolver::run_slots(int n_slots) {
     return PVIO_OK;
 }
 
-int BASolver::solve(pvio_ba_summary *sum, pvio_ba_kernel_times *prof) {
+int BASolver::solve(pvio_ba_summary *sum, pvio_ba_kernel_times *prof, pvio_ba_state *read_back) {
     if (!uploaded_) return fail(PVIO_ERR_INVALID_ARGUMENT, "no problem uploaded");
     auto t0 = std::chrono::steady_clock::now();
     if (check(hipSetDevice(device_), "hipSetDevice")) return PVIO_ERR_HIP;
     const Dims &dm = v_.dm;
     const size_t Ns = dm.N, Ms = std::max(dm.M, 1);
+    // fused read-back: frame states, inverse depths, quality, valid bytes in one pinned buffer
+    const size_t n_pack = Ns * 16 + 2 * (size_t)dm.M + ((size_t)dm.M + 7) / 8;
+    double *d_pack = nullptr;
+    if (read_back) {
+        bool grew = false;
+        if (!dev(pool_, "result_pack", n_pack, &d_pack, &grew)) return fail(PVIO_ERR_OUT_OF_MEMORY, "result_pack");
+        if (n_pack > h_pack_cap_) {
+            if (h_pack_) (void)hipHostFree(h_pack_);
+            h_pack_ = nullptr, h_pack_cap_ = 0;
+            const size_t cap = n_pack + n_pack / 4;
+            if (hipHostMalloc(reinterpret_cast<void **>(&h_pack_), cap * sizeof(double)) != hipSuccess) return fail(PVIO_ERR_OUT_OF_MEMORY, "hipHostMalloc failed");
+            h_pack_cap_ = cap;
+        }
+    }
     // trace states are optional and live in a separate buffer so that bench runs do not pay for them
     const bool want_states = sum && sum->trace_states && sum->trace_capacity > 0;
     {
@@ -645,6 +660,10 @@ int BASolver::solve(pvio_ba_summary *sum, pvio_ba_kernel_times *prof) {
         if (rc != PVIO_OK) return rc;
         if (check(hipMemcpyAsync(h_ctrl_, v_.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, stream_), "ctrl D2H")) return PVIO_ERR_HIP;
         if (check(hipEventRecord(ev1_, stream_), "event")) return PVIO_ERR_HIP;
+        if (read_back) { // speculative: all but never is the state machine still running after one replay (then this is repeated)
+            if (check(launch_quality(v_, stream_, 1, nullptr, d_pack), "k_quality")) return PVIO_ERR_HIP;
+            if (check(hipMemcpyAsync(h_pack_, d_pack, n_pack * sizeof(double), hipMemcpyDeviceToHost, stream_), "results D2H")) return PVIO_ERR_HIP;
+        }
         if (check(hipStreamSynchronize(stream_), "solve sync")) return PVIO_ERR_HIP;
         if (h_ctrl_->done || ++rounds > (time_limited ? 16 * (dm.max_iter + 1) : 16)) break;
         // max_solver_time_in_seconds (solver_options.h:30): the state machine runs on the device, so the wall clock is looked at
@@ -703,6 +722,17 @@ int BASolver::solve(pvio_ba_summary *sum, pvio_ba_kernel_times *prof) {
                 if (check(hipMemcpy(sum->trace_states, v_.trace_states, (size_t)n * (Ns * 16 + dm.M) * sizeof(double), hipMemcpyDeviceToHost), "trace states D2H")) return PVIO_ERR_HIP;
         }
         sum->solve_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    if (read_back) { // same semantics as download(): invalidated landmarks keep their old quality (bundle_adjustor.cpp:294)
+        const size_t M = dm.M;
+        if (read_back->frame_state) std::memcpy(read_back->frame_state, h_pack_, Ns * 16 * sizeof(double));
+        if (M && read_back->lm_inv_depth) std::memcpy(read_back->lm_inv_depth, h_pack_ + Ns * 16, M * sizeof(double));
+        const double *q = h_pack_ + Ns * 16 + M;
+        const unsigned char *val = reinterpret_cast<const unsigned char *>(h_pack_ + Ns * 16 + 2 * M);
+        for (size_t l = 0; l < M; ++l) {
+            if (read_back->lm_valid) read_back->lm_valid[l] = val[l];
+            if (read_back->lm_quality && val[l]) read_back->lm_quality[l] = q[l];
+        }
     }
     return PVIO_OK;
 }
@@ -803,15 +833,14 @@ int BASolver::marginalize(const pvio_ba_problem *pb, const pvio_ba_state *st, in
     const auto tm0 = std::chrono::steady_clock::now();
     pvio_ba_problem p2 = *pb;
     p2.use_inertial = 1;
-    int rc = upload(&p2, st);
+    int rc = upload(&p2, st, /*may_return_early=*/true); // (this call synchronizes below, before the caller's arrays can change)
     if (rc != PVIO_OK) return rc;
     const auto tm1 = std::chrono::steady_clock::now();
     const Dims &dm = v_.dm;
     const size_t Ns = N;
     const double *fs_init = fs_init_, *rho_init = rho_init_;
-    if (check(hipMemcpyAsync(v_.fs, fs_init, Ns * 16 * sizeof(double), hipMemcpyDeviceToDevice, stream_), "reset fs")) return PVIO_ERR_HIP;
-    if (check(hipMemcpyAsync(v_.fs_user, fs_init, Ns * 16 * sizeof(double), hipMemcpyDeviceToDevice, stream_), "reset user")) return PVIO_ERR_HIP;
-    if (dm.M && check(hipMemcpyAsync(v_.rho, rho_init, (size_t)dm.M * sizeof(double), hipMemcpyDeviceToDevice, stream_), "reset rho")) return PVIO_ERR_HIP;
+    // working states <- the uploaded ones, in one launch (the control block it also copies is its own content: overwritten right below)
+    if (check(launch_reset(v_, fs_init, rho_init, v_.ctrl, stream_), "k_reset")) return PVIO_ERR_HIP;
     std::memset(h_ctrl_, 0, sizeof(Ctrl));
     h_ctrl_->mode = MODE_MARG;
     h_ctrl_->marg_victim = victim;
@@ -824,8 +853,8 @@ int BASolver::marginalize(const pvio_ba_problem *pb, const pvio_ba_state *st, in
     // landmark shards: every rank holds the victim's landmarks of its own range only -> sum the reduced buffers (the IMU
     // factors, the old prior and the rotation prior are replicated and are added once, below, on every rank alike)
     if (sharded_ && comm_allreduce(comm_, v_.red, nS + nV + kNumLinScal + (size_t)world_, 0, stream_)) return fail(PVIO_ERR_COMM, "all-reduce failed");
-    // read-back into ONE pinned buffer: a D2H copy into pageable memory is staged synchronously by the runtime (about 20 us
-    // each, eight of them); into pinned memory the eight copies queue behind the kernels and cost one wait
+    // read-back as ONE copy into a pinned buffer: a D2H copy into pageable memory is staged synchronously by the runtime (about 20 us
+    // each, eight of them); the eight arrays are gathered on the device first (k_gather)
     const size_t Dp = 15 * (size_t)dm.prior_n;
     const size_t n_back[8] = {nS + nV + kNumLinScal, Ns * 900, Ns * 30, Dp * Dp, Dp, Ns * 9, Ns * 3, ((size_t)dm.n_tasks + 1) / 2};
     size_t off_back[9] = {0};
@@ -841,16 +870,28 @@ int BASolver::marginalize(const pvio_ba_problem *pb, const pvio_ba_state *st, in
     const double *prig = h_back_ + off_back[4], *rotH = h_back_ + off_back[5], *rotg = h_back_ + off_back[6];
     const int32_t *tasks = reinterpret_cast<const int32_t *>(h_back_ + off_back[7]);
     const void *src_back[8] = {v_.red, v_.pre_H, v_.pre_g, v_.prior_H, v_.prior_g, v_.rot_H, v_.rot_g, v_.task_desc};
+    GatherArgs ga;
     for (int k = 0; k < 8; ++k) {
-        const size_t bytes = k == 7 ? (size_t)dm.n_tasks * sizeof(int32_t) : n_back[k] * sizeof(double);
-        if (bytes && check(hipMemcpyAsync(h_back_ + off_back[k], src_back[k], bytes, hipMemcpyDeviceToHost, stream_), "D2H")) return PVIO_ERR_HIP;
+        ga.src[k] = src_back[k];
+        ga.words[k] = (uint32_t)(k == 7 ? (size_t)dm.n_tasks : 2 * n_back[k]);
+        ga.off[k] = (uint32_t)(2 * off_back[k]);
     }
+    double *d_back = nullptr;
+    {
+        bool grew = false;
+        if (!dev(pool_, "marg_back", off_back[8], &d_back, &grew)) return fail(PVIO_ERR_OUT_OF_MEMORY, "marg_back");
+    }
+    if (check(launch_gather(ga, d_back, stream_), "k_gather")) return PVIO_ERR_HIP;
+    if (check(hipMemcpyAsync(h_back_, d_back, off_back[8] * sizeof(double), hipMemcpyDeviceToHost, stream_), "D2H")) return PVIO_ERR_HIP;
     if (check(hipStreamSynchronize(stream_), "marginalize sync")) return PVIO_ERR_HIP;
     const auto tm2 = std::chrono::steady_clock::now();
 
     // ---- assemble the 15N information matrix / vector ----
     const int D = 15 * N;
-    std::vector<double> H((size_t)D * D, 0.0), b(D, 0.0);
+    // (the large work arrays are members: a fresh 180 KB vector per call is an mmap, its page faults and an munmap)
+    std::vector<double> &H = marg_H_, &C = marg_C_, &V = marg_V_;
+    std::vector<double> b(D, 0.0);
+    H.assign((size_t)D * D, 0.0);
     for (int t = 0; t < dm.n_tasks; ++t) {
         const int fi = tasks[t] & 255, fj = (tasks[t] >> 8) & 255, si = (tasks[t] >> 16) & 1, sj = (tasks[t] >> 17) & 1;
         for (int el = 0; el < 9; ++el) {
@@ -873,10 +914,14 @@ int BASolver::marginalize(const pvio_ba_problem *pb, const pvio_ba_state *st, in
         b[15 * victim + a] += rotg[(size_t)victim * 3 + a];
         for (int c = 0; c < 3; ++c) H[(size_t)(15 * victim + a) * D + 15 * victim + c] += rotH[(size_t)victim * 9 + 3 * a + c];
     }
+    std::vector<int> gprior(Dp); // prior coordinate -> window coordinate (a division per ELEMENT of the 135 x 135 block cost 40 us here)
+    for (size_t a = 0; a < Dp; ++a) gprior[a] = 15 * pb->prior_frames[a / 15] + (int)(a % 15);
     for (size_t a = 0; a < Dp; ++a) {
-        const int ga = 15 * pb->prior_frames[a / 15] + (int)(a % 15);
+        const int ga = gprior[a];
         b[ga] += prig[a];
-        for (size_t c = 0; c < Dp; ++c) H[(size_t)ga * D + 15 * pb->prior_frames[c / 15] + (int)(c % 15)] += priH[a * Dp + c];
+        double *hrow = &H[(size_t)ga * D];
+        const double *prow = &priH[a * Dp];
+        for (size_t c = 0; c < Dp; ++c) hrow[gprior[c]] += prow[c];
     }
     // ---- eliminate the victim's 15 x 15 block (:547-581) ----
     const int R = D - 15;
@@ -885,31 +930,46 @@ int BASolver::marginalize(const pvio_ba_problem *pb, const pvio_ba_state *st, in
         for (int y = 0; y < 15; ++y) Hvv[x * 15 + y] = H[(size_t)(15 * victim + x) * D + 15 * victim + y];
     if (!lu_inverse15(Hvv, Hinv)) return fail(PVIO_ERR_INVALID_ARGUMENT, "singular victim block");
     auto gidx = [&](int k) { return k < 15 * victim ? k : k + 15; };
-    std::vector<double> C((size_t)R * R, 0.0), cv(R, 0.0), T((size_t)R * 15);
-    for (int i = 0; i < R; ++i)
-        for (int y = 0; y < 15; ++y) {
-            double s = 0;
-            for (int x = 0; x < 15; ++x) s += H[(size_t)gidx(i) * D + 15 * victim + x] * Hinv[x * 15 + y];
-            T[(size_t)i * 15 + y] = s;
+    std::vector<double> cv(R, 0.0), T((size_t)R * 15);
+    C.assign((size_t)R * R, 0.0);
+    for (int i = 0; i < R; ++i) { // T = H_rv Hvv^-1: fifteen independent sums per row, each still taken over x in ascending order
+        const double *hiv = &H[(size_t)gidx(i) * D + 15 * victim];
+        double trow[15] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int x = 0; x < 15; ++x) {
+            const double hx = hiv[x];
+            for (int y = 0; y < 15; ++y) trow[y] += hx * Hinv[x * 15 + y];
         }
+        for (int y = 0; y < 15; ++y) T[(size_t)i * 15 + y] = trow[y];
+    }
     const int split = 15 * victim;
+    // the victim's rows with the victim's own columns removed, so that the inner loops below run over contiguous memory (the sums are
+    // taken in the same order as a loop over y per element would take them; that form cost 100 us per marginalization)
+    std::vector<double> Hv((size_t)15 * R), acc(R);
+    for (int y = 0; y < 15; ++y)
+        for (int j = 0; j < R; ++j) Hv[(size_t)y * R + j] = H[(size_t)(15 * victim + y) * D + gidx(j)];
     for (int i = 0; i < R; ++i) {
         double s = 0;
         for (int y = 0; y < 15; ++y) s += T[(size_t)i * 15 + y] * b[15 * victim + y];
         cv[i] = b[gidx(i)] - s;
-        for (int j = 0; j < R; ++j) {
-            if (i >= split && j < split) continue; // lower-left = transpose of upper-right (:572-576)
-            double s2 = 0;
-            for (int y = 0; y < 15; ++y) s2 += T[(size_t)i * 15 + y] * H[(size_t)(15 * victim + y) * D + gidx(j)];
-            C[(size_t)i * R + j] = H[(size_t)gidx(i) * D + gidx(j)] - s2;
+        const int j0 = i >= split ? split : 0; // lower-left = transpose of upper-right (:572-576), filled in below
+        for (int j = j0; j < R; ++j) acc[j] = 0;
+        for (int y = 0; y < 15; ++y) {
+            const double ty = T[(size_t)i * 15 + y];
+            const double *hv = &Hv[(size_t)y * R];
+            for (int j = j0; j < R; ++j) acc[j] += ty * hv[j];
         }
+        const double *hi = &H[(size_t)gidx(i) * D];
+        double *ci = &C[(size_t)i * R];
+        for (int j = j0; j < split; ++j) ci[j] = hi[j] - acc[j];
+        for (int j = j0 > split ? j0 : split; j < R; ++j) ci[j] = hi[j + 15] - acc[j];
     }
     for (int i = split; i < R; ++i)
         for (int j = 0; j < split; ++j) C[(size_t)i * R + j] = C[(size_t)j * R + i];
     if (out->info_matrix) std::memcpy(out->info_matrix, C.data(), sizeof(double) * R * R);
     if (out->info_vector) std::memcpy(out->info_vector, cv.data(), sizeof(double) * R);
     // ---- sqrt information: sqrt(L) V^T and L^-1/2 V^T b, eigenvalues <= 1e-8 zeroed (:583-590) ----
-    std::vector<double> w(R), V((size_t)R * R);
+    std::vector<double> w(R);
+    V.resize((size_t)R * R);
     const auto tm3 = std::chrono::steady_clock::now();
     sym_eig(C.data(), R, w.data(), V.data());
     const auto tm4 = std::chrono::steady_clock::now();

@@ -41,7 +41,9 @@ class BASolver {
     void set_linearize_mode(int m) { lin_mode_ = m; }
     ~BASolver();
     int upload(const pvio_ba_problem *pb, const pvio_ba_state *st, bool may_return_early = false);   // H2D of the flat problem + initial state
-    int solve(pvio_ba_summary *sum, pvio_ba_kernel_times *prof = nullptr); // runs from the uploaded initial state
+    // runs from the uploaded initial state; `read_back`: the accepted iterate + quality pass land in the caller's arrays as part of the same
+    // stream round (what upload + solve + download cost as three round trips before)
+    int solve(pvio_ba_summary *sum, pvio_ba_kernel_times *prof = nullptr, pvio_ba_state *read_back = nullptr);
     int download(pvio_ba_state *st);                                   // D2H of the accepted iterate (+ quality pass)
     int reprojection_error(double *out);
     int marginalize(const pvio_ba_problem *pb, const pvio_ba_state *st, int victim, pvio_ba_prior *out);
@@ -73,6 +75,9 @@ class BASolver {
     size_t h_stage_cap_ = 0;
     double *h_back_ = nullptr; // pinned read-back of one marginalization pass
     size_t h_back_cap_ = 0;    // in doubles
+    std::vector<double> marg_H_, marg_C_, marg_V_; // host work arrays of a marginalization (15N x 15N, twice 15(N-1) x 15(N-1))
+    double *h_pack_ = nullptr; // pinned: a solve's packed results (k_quality `pack`)
+    size_t h_pack_cap_ = 0;    // in doubles
     const double *fs_init_ = nullptr, *rho_init_ = nullptr; // initial state inside the inputs slab
     Ctrl h_ctrl_tmpl_{};                                    // what a solve's control block starts from (k_reset copies the device copy)
     Ctrl *d_ctrl_tmpl_ = nullptr;

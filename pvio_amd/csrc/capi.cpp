@@ -1,4 +1,7 @@
 // capi.cpp -- extern "C" entry points declared in include/pvio_hip.h.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -78,11 +81,17 @@ int32_t pvio_hip_ba_download(pvio_hip_ctx *ctx, pvio_ba_state *state) {
 }
 int32_t pvio_hip_ba_solve(pvio_hip_ctx *ctx, const pvio_ba_problem *problem, pvio_ba_state *state, pvio_ba_summary *summary) {
     if (!ctx || !problem || !state) return PVIO_ERR_INVALID_ARGUMENT;
+    static const bool timing = std::getenv("PVIO_HIP_TIMING") != nullptr; // diagnostics: host time of the two halves of a call
+    const auto t0 = std::chrono::steady_clock::now();
     int rc = ctx->ba->upload(problem, state, /*may_return_early=*/true); // (the solve below synchronizes before the arrays go back to the caller)
     if (rc != PVIO_OK) return rc;
-    rc = ctx->ba->solve(summary);
-    if (rc != PVIO_OK) return rc;
-    return ctx->ba->download(state);
+    const auto t1 = std::chrono::steady_clock::now();
+    rc = ctx->ba->solve(summary, nullptr, state); // the accepted iterate and the quality pass come back in the solve's own stream round
+    if (timing)
+        std::fprintf(stderr, "[pvio-hip] ba_solve: staging + upload enqueue %.0f us, iterations + read-back %.0f us (device: %.0f us)\n",
+                     std::chrono::duration<double, std::micro>(t1 - t0).count(), std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count(),
+                     summary ? 1e6 * summary->device_seconds : 0.0);
+    return rc;
 }
 int32_t pvio_hip_ba_marginalize(pvio_hip_ctx *ctx, const pvio_ba_problem *problem, const pvio_ba_state *state, int32_t victim, pvio_ba_prior *out) {
     if (!ctx || !problem || !state || !out) return PVIO_ERR_INVALID_ARGUMENT;

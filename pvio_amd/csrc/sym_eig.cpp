@@ -11,20 +11,47 @@
 #define PVBA_EIG_FN sym_eig_generic
 #define PVBA_EIG_DISPATCHER 1
 #endif
+// tests/micro/eig_bench.cpp builds extra copies with -DPVBA_EIG_TIMES=<array> (microseconds of reduction / accumulation / QL of the
+// last call) and -DPVBA_EIG_HYPOT=1 (hypot() for every rotation, the form measured against); the library's builds carry neither
+#ifdef PVBA_EIG_TIMES
+#include <chrono>
+namespace pvba {
+double PVBA_EIG_TIMES[3];
+}
+#define PVBA_EIG_T(k)                                                                                        \
+    {                                                                                                        \
+        const auto now = std::chrono::steady_clock::now();                                                   \
+        PVBA_EIG_TIMES[k] = std::chrono::duration<double, std::micro>(now - eig_t0).count(), eig_t0 = now;  \
+    }
+#else
+#define PVBA_EIG_T(k)
+#endif
+#ifndef PVBA_EIG_HYPOT
+#define PVBA_EIG_HYPOT 0
+#endif
 
 namespace pvba {
 namespace eig_detail {
+// sixteen partial sums = four independent vector accumulators under AVX2: one accumulator is a chain of dependent FMAs (4 cycles each),
+// i.e. one double per cycle where the core can do eight
 static inline double dot(const double *__restrict a, const double *__restrict b, int n) {
-    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    double s[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t4[4] = {0, 0, 0, 0}, r = 0;
     int k = 0;
-    for (; k + 4 <= n; k += 4) s0 += a[k] * b[k], s1 += a[k + 1] * b[k + 1], s2 += a[k + 2] * b[k + 2], s3 += a[k + 3] * b[k + 3];
-    for (; k < n; ++k) s0 += a[k] * b[k];
-    return (s0 + s1) + (s2 + s3);
+    for (; k + 16 <= n; k += 16)
+        for (int t = 0; t < 16; ++t) s[t] += a[k + t] * b[k + t];
+    for (; k + 4 <= n; k += 4)
+        for (int t = 0; t < 4; ++t) t4[t] += a[k + t] * b[k + t];
+    for (; k < n; ++k) r += a[k] * b[k];
+    for (int t = 0; t < 4; ++t) t4[t] += (s[t] + s[t + 4]) + (s[t + 8] + s[t + 12]);
+    return r + ((t4[0] + t4[1]) + (t4[2] + t4[3]));
 }
 } // namespace eig_detail
 
 void PVBA_EIG_FN(const double *A, int n, double *__restrict w, double *__restrict Vt) {
     using eig_detail::dot;
+#ifdef PVBA_EIG_TIMES
+    auto eig_t0 = std::chrono::steady_clock::now();
+#endif
     double *__restrict e = new double[n > 0 ? n : 1]();
     auto Z = [Vt, n](int a, int b) -> double & { return Vt[(size_t)b * n + a]; }; // Z(a, .) contiguous in a
     for (int i = 0; i < n; ++i)
@@ -53,14 +80,9 @@ void PVBA_EIG_FN(const double *A, int n, double *__restrict w, double *__restric
                 f = w[j];
                 Z(j, i) = f;
                 const double *__restrict zj = &Z(0, j);
-                double g0 = e[j] + zj[j] * f, g1 = 0;
-                int k = j + 1;
-                for (; k + 2 <= i; k += 2) {
-                    g0 += zj[k] * w[k], g1 += zj[k + 1] * w[k + 1];
-                    e[k] += zj[k] * f, e[k + 1] += zj[k + 1] * f;
-                }
-                for (; k < i; ++k) g0 += zj[k] * w[k], e[k] += zj[k] * f;
-                e[j] = g0 + g1;
+                // two clean passes over the (L1-resident) column instead of one fused loop: the fused form did not vectorize
+                e[j] = e[j] + zj[j] * f + dot(zj + j + 1, w + j + 1, i - j - 1);
+                for (int k = j + 1; k < i; ++k) e[k] += zj[k] * f;
             }
             f = 0;
             for (int j = 0; j < i; ++j) e[j] /= h, f += e[j] * w[j];
@@ -76,6 +98,7 @@ void PVBA_EIG_FN(const double *A, int n, double *__restrict w, double *__restric
         }
         w[i] = h;
     }
+    PVBA_EIG_T(0)
     for (int i = 0; i < n - 1; ++i) { // accumulate the reflectors into Z
         Z(n - 1, i) = Z(i, i);
         Z(i, i) = 1.0;
@@ -96,6 +119,7 @@ void PVBA_EIG_FN(const double *A, int n, double *__restrict w, double *__restric
     // Z now holds Q with A = Q T Q^T; column j of Q = Z(., j) = row j of Vt, so the QL rotations, which mix pairs of columns
     // of the eigenvector matrix, mix pairs of contiguous rows.
     // --- implicit QL on the tridiagonal matrix ---
+    PVBA_EIG_T(1)
     for (int i = 1; i < n; ++i) e[i - 1] = e[i];
     e[n - 1] = 0;
     double f = 0, tst1 = 0;
@@ -126,7 +150,14 @@ void PVBA_EIG_FN(const double *A, int n, double *__restrict w, double *__restric
                     c3 = c2, c2 = c, s2 = s;
                     g = c * e[i];
                     h = c * p;
+#if PVBA_EIG_HYPOT
                     r = std::hypot(p, e[i]);
+#else
+                    // the rotation's radius sits on the serial chain of the sweep (c and p of the next rotation depend on it): a plain
+                    // square root where the squares can neither overflow nor vanish, hypot() (three times the latency) otherwise
+                    const double r2 = p * p + e[i] * e[i];
+                    r = (r2 > 1.0e-280 && r2 < 1.0e280) ? std::sqrt(r2) : std::hypot(p, e[i]);
+#endif
                     e[i + 1] = s * r;
                     s = e[i] / r;
                     c = p / r;
@@ -147,6 +178,7 @@ void PVBA_EIG_FN(const double *A, int n, double *__restrict w, double *__restric
         w[l] += f;
         e[l] = 0;
     }
+    PVBA_EIG_T(2)
     for (int i = 0; i < n - 1; ++i) { // ascending order
         int k = i;
         double p = w[i];

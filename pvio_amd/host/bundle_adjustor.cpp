@@ -208,7 +208,9 @@ void put_m3(std::vector<double> &v, size_t off, const matrix<3> &m) { // -> row-
 // keypoint index (:91-103); reprojection blocks per track in ascending frame id with the anchor first (track.h:69).
 // (Ceres sums residual blocks frame-major; the flat CSR is landmark-major -- a different summation order, i.e. a
 // difference at rounding level only.)
-void flatten(Map *map, Config *config, bool use_inertial, bool for_marginalization, Flat &F, ObsCache *cache = nullptr) {
+// `victim` (marginalization only): the landmarks are the tracks the victim frame observes (:453-457), in its keypoint order -- the other
+// frames' keypoints are not walked at all.
+void flatten(Map *map, Config *config, bool use_inertial, bool for_marginalization, Flat &F, ObsCache *cache = nullptr, int victim = -1) {
     const int N = (int)map->frame_num();
     // the device path takes windows of at most PVIO_MAX_FRAMES frames (the reference's sliding window holds 10): say so before
     // walking a larger map -- and before the pointer table below, which has no room for 256 frames
@@ -312,6 +314,7 @@ void flatten(Map *map, Config *config, bool use_inertial, bool for_marginalizati
         F.lm_ptr.push_back((int32_t)F.obs_frame.size());
     };
     for (int i = 0; i < N; ++i) {
+        if (victim >= 0 && i != victim) continue;
         Frame *f = map->get_frame(i);
         for (size_t j = 0; j < f->keypoint_num(); ++j) {
             Track *track = f->get_track(j);
@@ -597,7 +600,10 @@ struct BundleAdjustor::BundleAdjustorSolver { // the pimpl of bundle_adjustor.h:
         pvio_hip_ctx *ctx = process_ctx();
         if (!ctx || index >= map->frame_num() || map->frame_num() < 2) return;
         DefaultConfig dc;
-        flatten(map, &dc, true, true, F, &obs_cache()); // the tracks were flattened by the last solve: their lists are replayed
+        static const bool timing = std::getenv("PVIO_HIP_TIMING") != nullptr; // diagnostics: host share of a marginalization
+        const auto t0 = std::chrono::steady_clock::now();
+        flatten(map, &dc, true, true, F, &obs_cache(), (int)index); // the tracks were flattened by the last solve: their lists are replayed
+        const auto t1 = std::chrono::steady_clock::now();
         const size_t n = map->frame_num() - 1, D = 15 * n;
         std::vector<double> S(D * D, 0.0), s(D, 0.0); // row-major, like the C ABI
         pvio_ba_state st{F.fstate.data(), F.rho.data(), nullptr, nullptr};
@@ -608,6 +614,7 @@ struct BundleAdjustor::BundleAdjustorSolver { // the pimpl of bundle_adjustor.h:
             std::fprintf(stderr, "[pvio-hip] ba_marginalize failed: %s\n", pvio_hip_last_error(ctx));
             return;
         }
+        const auto t2 = std::chrono::steady_clock::now();
         matrix<> sqrt_infomat;
         vector<> sqrt_infovec;
         sqrt_infomat.resize((int)D, (int)D), sqrt_infovec.resize((int)D);
@@ -620,6 +627,11 @@ struct BundleAdjustor::BundleAdjustorSolver { // the pimpl of bundle_adjustor.h:
             if (i != index) remaining.emplace_back(map->get_frame(i));
         map->set_marginalization_factor(Factor::create_marginalization_error(sqrt_infomat, sqrt_infovec, std::move(remaining)));
         guard.armed = false;
+        if (timing) {
+            auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+            std::fprintf(stderr, "[pvio-hip] marginalize_frame: %d frames, %d landmarks: flatten %.1f us, pvio_hip_ba_marginalize %.1f us, new prior factor %.1f us\n",
+                         F.pb.n_frames, F.pb.n_landmarks, us(t0, t1), us(t1, t2), us(t2, std::chrono::steady_clock::now()));
+        }
     }
 
     double compute_reprojection_error(Map *map) {

@@ -12,6 +12,10 @@
 namespace pvba {
 void sym_eig_generic(const double *, int, double *, double *);
 void sym_eig_avx2(const double *, int, double *, double *);
+void eig_avx2_timed(const double *, int, double *, double *);
+void eig_avx2_hypot(const double *, int, double *, double *);
+void eig_avx512(const double *, int, double *, double *);
+extern double eig_times_a[3], eig_times_b[3], eig_times_c[3];
 } // namespace pvba
 int main(int argc, char **argv) {
     FILE *f = argc > 1 ? std::fopen(argv[1], "rb") : nullptr;
@@ -24,7 +28,8 @@ int main(int argc, char **argv) {
     struct { const char *name; void (*fn)(const double *, int, double *, double *); bool ok; double best; } runs[] = {
         {"round-2 strided layout", [](const double *a, int m, double *ww, double *vv) { pvold::sym_eig(a, m, ww, vv); }, true, 1e9},
         {"generic", pvba::sym_eig_generic, true, 1e9}, {"avx2", pvba::sym_eig_avx2, has2, 1e9},
-        {"dispatched", pvba::sym_eig, true, 1e9}};
+        {"dispatched", pvba::sym_eig, true, 1e9}, {"avx2 timed", pvba::eig_avx2_timed, has2, 1e9}, {"avx2 hypot()", pvba::eig_avx2_hypot, has2, 1e9},
+        {"avx512", pvba::eig_avx512, has2 && __builtin_cpu_supports("avx512f"), 1e9}};
     for (int r = 0; r < 50; ++r)
         for (auto &run : runs) {
             if (!run.ok) continue;
@@ -42,6 +47,8 @@ int main(int argc, char **argv) {
     std::printf("n=%d (dispatcher picked %s):", n, pvba::sym_eig_isa());
     for (auto &run : runs)
         if (run.ok) std::printf("  %s %.0f us", run.name, run.best);
+    std::printf("\n  phases (reduction / accumulation / QL, us): avx2 %.0f %.0f %.0f   avx2 with hypot() %.0f %.0f %.0f   avx512 %.0f %.0f %.0f\n", pvba::eig_times_a[0], pvba::eig_times_a[1],
+                pvba::eig_times_a[2], pvba::eig_times_b[0], pvba::eig_times_b[1], pvba::eig_times_b[2], pvba::eig_times_c[0], pvba::eig_times_c[1], pvba::eig_times_c[2]);
     std::printf("  max|A - V L V^T| %.2e of max|A| %.2e, max|V V^T - I| %.2e, eigenvalues %.3e .. %.3e\n", rec, amax, orth, w[0], w[n - 1]);
     return 0;
 }

@@ -45,6 +45,9 @@ def _matrices():
     out["zero_7"] = np.zeros((7, 7))
     T = np.diag(rng.uniform(1, 2, 40)) + np.diag(rng.uniform(0.1, 1, 39), 1)
     out["tridiagonal_40"] = T + T.T
+    B = rng.standard_normal((30, 30))
+    out["huge_30"] = (B @ B.T) * 1e150   # squares of the sweep's entries overflow 1e280: the hypot() branch of the rotation radius
+    out["tiny_30"] = (B @ B.T) * 1e-150  # ... and underflow 1e-280
     return {k: (v + v.T) / 2 for k, v in out.items()}
 
 
