@@ -131,8 +131,9 @@ PV_HD void q_expmap(double *q, const double *w) { // lie_algebra.h:32-37
             ax[0] = s0 * inv, ax[1] = s1 * inv, ax[2] = s2 * inv;
         }
     }
-    const double sh = sin(0.5 * angle);
-    q[0] = sh * ax[0], q[1] = sh * ax[1], q[2] = sh * ax[2], q[3] = cos(0.5 * angle);
+    double sh, ch;
+    sincos(0.5 * angle, &sh, &ch); // one argument reduction for both (this sits on the critical path of every k_linearize prologue)
+    q[0] = sh * ax[0], q[1] = sh * ax[1], q[2] = sh * ax[2], q[3] = ch;
 }
 PV_HD void q_logmap(double *w, const double *q) { // lie_algebra.h:39-42
     double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
