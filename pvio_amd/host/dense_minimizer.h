@@ -42,20 +42,26 @@ Summary minimize(const Problem &pb, double *x, int max_iterations) {
     }
     sum.initial_cost = sum.final_cost = x_cost;
     int rows = (int)r.size();
-    auto col_norm2 = [&](int c) {
-        double s = 0;
-        for (int i = 0; i < rows; ++i) s += J[(size_t)i * n + c] * J[(size_t)i * n + c];
-        return s;
+    // The sums over the rows of J walk J row by row (it is rows x n row-major, n <= 15: a walk down one column touches a cache line per
+    // element -- with 1500 factors that was most of a PnP's 2.5 ms); every entry is still summed over the rows in ascending order.
+    std::vector<double> cn2(n);
+    auto col_norms2 = [&]() {
+        std::fill(cn2.begin(), cn2.end(), 0.0);
+        for (int i = 0; i < rows; ++i) {
+            const double *Ji = &J[(size_t)i * n];
+            for (int c = 0; c < n; ++c) cn2[c] += Ji[c] * Ji[c];
+        }
     };
     auto apply_scale = [&]() {
         for (int i = 0; i < rows; ++i)
             for (int c = 0; c < n; ++c) J[(size_t)i * n + c] *= scale[c];
     };
     auto gradient = [&](std::vector<double> &out) { // J^T r with the current (possibly scaled) J
-        for (int c = 0; c < n; ++c) {
-            double s = 0;
-            for (int i = 0; i < rows; ++i) s += J[(size_t)i * n + c] * r[i];
-            out[c] = s;
+        std::fill(out.begin(), out.begin() + n, 0.0);
+        for (int i = 0; i < rows; ++i) {
+            const double *Ji = &J[(size_t)i * n];
+            const double ri = r[i];
+            for (int c = 0; c < n; ++c) out[c] += Ji[c] * ri;
         }
     };
     auto norm = [](const double *a, int m) {
@@ -72,13 +78,14 @@ Summary minimize(const Problem &pb, double *x, int max_iterations) {
         return m;
     };
     gradient(g); // unscaled
-    for (int c = 0; c < n; ++c) scale[c] = 1.0 / (1.0 + std::sqrt(col_norm2(c)));
+    col_norms2();
+    for (int c = 0; c < n; ++c) scale[c] = 1.0 / (1.0 + std::sqrt(cn2[c]));
     apply_scale();
     double gmax = grad_max(x), x_norm = norm(x, na);
     double radius = 1e4, mu = 1e-8, min_cost = DBL_MAX, alpha = 0, dogleg_norm = 0;
     bool reuse = false, success = true;
     int invalid = 0, it = 0;
-    std::vector<double> A((size_t)n * n), rhs(n), y(n);
+    std::vector<double> A((size_t)n * n), JtJ((size_t)n * n), rhs(n), y(n);
     while (true) {
         if (success && x_cost < min_cost) {
             min_cost = x_cost;
@@ -102,7 +109,8 @@ Summary minimize(const Problem &pb, double *x, int max_iterations) {
         double model_change = 0;
         if (!reuse) {
             reuse = true;
-            for (int c = 0; c < n; ++c) diag[c] = std::sqrt(std::min(std::max(col_norm2(c), 1e-6), 1e32));
+            col_norms2();
+            for (int c = 0; c < n; ++c) diag[c] = std::sqrt(std::min(std::max(cn2[c], 1e-6), 1e32));
             gradient(rhs); // scaled J^T r
             for (int c = 0; c < n; ++c) ghat[c] = rhs[c] / diag[c];
             double jg2 = 0; // |J (ghat / D)|^2
@@ -115,13 +123,18 @@ Summary minimize(const Problem &pb, double *x, int max_iterations) {
             for (int c = 0; c < n; ++c) g2 += ghat[c] * ghat[c];
             alpha = g2 / jg2;
             ok = false;
+            std::fill(JtJ.begin(), JtJ.end(), 0.0); // lower triangle of J^T J, once per linearization (a retry only changes mu)
+            for (int i = 0; i < rows; ++i) {
+                const double *Ji = &J[(size_t)i * n];
+                for (int a = 0; a < n; ++a) {
+                    const double ja = Ji[a];
+                    double *row = &JtJ[(size_t)a * n];
+                    for (int b = 0; b <= a; ++b) row[b] += ja * Ji[b];
+                }
+            }
             while (mu < 1.0) {
                 for (int a = 0; a < n; ++a)
-                    for (int b = 0; b <= a; ++b) {
-                        double s = 0;
-                        for (int i = 0; i < rows; ++i) s += J[(size_t)i * n + a] * J[(size_t)i * n + b];
-                        A[(size_t)a * n + b] = s + (a == b ? mu * diag[a] * diag[a] : 0.0);
-                    }
+                    for (int b = 0; b <= a; ++b) A[(size_t)a * n + b] = JtJ[(size_t)a * n + b] + (a == b ? mu * diag[a] * diag[a] : 0.0);
                 bool spd = true; // in-place Cholesky, lower
                 for (int a = 0; a < n && spd; ++a) {
                     for (int b = 0; b <= a; ++b) {

@@ -2,8 +2,41 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <cstdint>
 #include <cstdlib>
-#include <ucontext.h>
+
+// Fiber switch: callee-saved registers + the two floating-point control words on the fiber's own stack, then the stack pointers are
+// exchanged.  (swapcontext() makes a signal-mask system call on every switch: an emulated solve is tens of millions of switches, and the
+// CPU suite spent most of its eleven minutes in the kernel.)  x86-64 System V only -- like the rest of this emulator's build.
+extern "C" void hipemu_switch(void **save_sp, void *const *load_sp);
+asm(R"(
+    .text
+    .globl hipemu_switch
+    .type hipemu_switch,@function
+hipemu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    subq $8, %rsp
+    stmxcsr (%rsp)
+    fnstcw 4(%rsp)
+    movq %rsp, (%rdi)
+    movq (%rsi), %rsp
+    ldmxcsr (%rsp)
+    fldcw 4(%rsp)
+    addq $8, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+    .size hipemu_switch, .-hipemu_switch
+)");
 
 namespace hipemu {
 
@@ -15,7 +48,7 @@ char *g_dyn_smem = dyn_smem_pool;
 namespace {
 constexpr size_t kStack = 256 * 1024;
 struct Fiber {
-    ucontext_t ctx;
+    void *sp = nullptr; // saved stack pointer while the fiber is not running
     ThreadCtx tc;
     bool done = false;
     char *stack = nullptr;
@@ -26,7 +59,7 @@ struct WaveState {
 };
 std::vector<Fiber> fibers;
 std::vector<WaveState> waves;
-ucontext_t sched_ctx;
+void *sched_sp = nullptr;
 int n_threads = 0, bar_arrived = 0, bar_generation = 0, n_done = 0;
 long g_sync_events = 0; // completed barriers + wave exchanges (progress for the deadlock detector)
 long launch_counter = 0;
@@ -36,14 +69,26 @@ Fiber *cur_fiber = nullptr;
 
 void yield() {
     Fiber *f = cur_fiber;
-    swapcontext(&f->ctx, &sched_ctx);
+    hipemu_switch(&f->sp, &sched_sp);
 }
 void trampoline() {
     (*cur_body)();
     cur_fiber->done = true;
     ++n_done;
     waves[cur_fiber->tc.wave].alive--;
-    swapcontext(&cur_fiber->ctx, &sched_ctx);
+    hipemu_switch(&cur_fiber->sp, &sched_sp);
+    std::abort(); // a finished fiber is never resumed
+}
+// A fresh fiber: the frame hipemu_switch pops (control words, six registers, return address = trampoline) at the top of its stack, laid out
+// so that trampoline() starts with the stack alignment of a called function.
+void prepare(Fiber &f) {
+    uintptr_t top = (reinterpret_cast<uintptr_t>(f.stack) + kStack) & ~(uintptr_t)15;
+    uint64_t *p = reinterpret_cast<uint64_t *>(top);
+    *--p = 0;                                        // where a caller's return address would be
+    *--p = reinterpret_cast<uint64_t>(&trampoline);  // popped by `ret`
+    for (int k = 0; k < 6; ++k) *--p = 0;            // rbp rbx r12 r13 r14 r15
+    *--p = 0x1F80u | ((uint64_t)0x037Fu << 32);      // MXCSR, x87 control word: the defaults
+    f.sp = p;
 }
 } // namespace
 
@@ -131,11 +176,7 @@ void launch(dim3 grid, dim3 block, size_t shmem, Stream *s, std::function<void()
                         f.tc.lane = t & 63;
                         f.tc.wave = t >> 6;
                         waves[t >> 6].alive++;
-                        getcontext(&f.ctx);
-                        f.ctx.uc_stack.ss_sp = f.stack;
-                        f.ctx.uc_stack.ss_size = kStack;
-                        f.ctx.uc_link = &sched_ctx;
-                        makecontext(&f.ctx, trampoline, 0);
+                        prepare(f);
                     }
                     int remaining = nt;
                     long spins = 0, seen_events = g_sync_events;
@@ -149,7 +190,7 @@ void launch(dim3 grid, dim3 block, size_t shmem, Stream *s, std::function<void()
                             if (f.done) continue;
                             cur_fiber = &f;
                             g_cur = &f.tc;
-                            swapcontext(&sched_ctx, &f.ctx);
+                            hipemu_switch(&sched_sp, &f.sp);
                             if (f.done) {
                                 --remaining;
                                 ++progressed;

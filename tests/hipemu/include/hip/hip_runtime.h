@@ -7,7 +7,7 @@
 // with hipcc for gfx950 and never sees this file; the emulated build produces a differently named test
 // library (tests/hipemu/libpvio_hipemu.so) that pvio_amd/capi.py will not load by default.
 //
-// Model: one OS thread; every GPU thread of a block is a ucontext fiber; blocks run one after another;
+// Model: one OS thread; every GPU thread of a block is a fiber (own stack, hand-written register switch); blocks run one after another;
 // __syncthreads()/wave shuffles are cooperative yields.  Deterministic, no data races by construction
 // (so it cannot find memory-model bugs -- those are left to the GPU tests).
 #pragma once
