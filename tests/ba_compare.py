@@ -30,9 +30,8 @@ CASES = {
     "vio_20_frames_panels": dict(n_frames=20, n_landmarks=120, use_inertial=True, visibility=7),
     "vio_32_frames_narrow_panels": dict(n_frames=32, n_landmarks=160, use_inertial=True, visibility=8),
 }
-# too slow for the fiber emulator (half a minute and more): checked on the GPU only (the 13-frame window keeps the HBM-matrix
-# form of the dense kernel in the CPU suite)
-GPU_ONLY = {"vio_32_frames_narrow_panels", "vio_20_frames_panels"}
+# (these were too slow for the fiber emulator while it switched fibers with swapcontext(): GPU only, rounds 1-2)
+GPU_ONLY = set()  # (round 3: the emulator switches fibers without system calls; the 20- and 32-frame windows take 4 s and 8 s in it)
 BIG_CASES = {
     # the configuration the metric is quoted on (10 KF x 1000 landmarks), vision-only and full VIO
     "metric_10x1000_vision": dict(n_frames=10, n_landmarks=1000),

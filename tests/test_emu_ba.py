@@ -29,6 +29,13 @@ def test_emulated_kernels_match_oracle(emu_ctx, oracle, name):
     ba_compare.check_against_oracle(emu_ctx, oracle, pb)
 
 
+@pytest.mark.parametrize("name", sorted(ba_compare.BIG_CASES))
+def test_emulated_kernels_match_oracle_at_the_metric_size(emu_ctx, oracle, name):
+    """the windows the metric is quoted on (10 KF x 1000 landmarks) and their variants: the same checks the GPU tests make, without a GPU"""
+    pb = ba_compare.make(oracle, **ba_compare.BIG_CASES[name])
+    ba_compare.check_against_oracle(emu_ctx, oracle, pb)
+
+
 def test_emulated_eager_launches_match_graph_replay(emu_ctx, oracle):
     pb = ba_compare.make(oracle, **ba_compare.CASES["vio_partial"])
     eager = HipContext(lib=emu_ctx.lib, use_graph=False)

@@ -30,10 +30,30 @@ def emu_ctx():
     ctx.close()
 
 
-@pytest.mark.parametrize("name", ["vision_partial", "vio_partial", "vio_plane", "vio_zero_bias_quirk", "vio_duplicate_blocks"])
+@pytest.mark.parametrize("name", SMALL)
 def test_emulated_kernels_match_reference_sources(emu_ctx, ref, oracle, name):
     pb = ba_compare.make(oracle, **ba_compare.CASES[name])
     print(name, ba_compare.check_against_reference(emu_ctx, ref, pb))
+
+
+@pytest.mark.parametrize("name", ["metric_10x1000_vio", "vio_plane_10x600"])
+def test_emulated_kernels_match_reference_sources_metric_window(emu_ctx, ref, oracle, name):
+    """the kernels (in the emulator) against the reference's own sources on the window the metric is quoted on"""
+    pb = ba_compare.make(oracle, **ba_compare.BIG_CASES[name])
+    print(name, ba_compare.check_against_reference(emu_ctx, ref, pb))
+
+
+def test_emulated_marginalize_matches_reference_sources(emu_ctx, ref, oracle):
+    """pvio_hip_ba_marginalize (kernels in the emulator, host tail as shipped) against the reference's marginalize_frame (bundle_adjustor.cpp:348-599)"""
+    import marg_compare
+    for victim in (0, 3):
+        pb, st = marg_compare.solved_window(oracle, regular_prior=(victim != 0), n_frames=8, n_landmarks=200, use_inertial=True, visibility=5)
+        S1, s1 = emu_ctx.marginalize(pb, st, victim)[:2]
+        trk, _ = ref.tracks_of_problem(pb, inv_depth=st.lm_inv_depth)
+        S0, s0, IM0, iv0 = ref.marginalize(pb, st.frame_state, trk, victim)
+        scale = np.abs(IM0).max()
+        np.testing.assert_allclose(S1.T @ S1, IM0, rtol=1e-6, atol=1e-7 * scale)
+        np.testing.assert_allclose(S1.T @ s1, iv0, rtol=1e-6, atol=1e-6 * np.abs(iv0).max())
 
 
 @pytest.fixture(scope="module")
