@@ -58,24 +58,18 @@ __device__ long long g_stamp_t0[4], g_stamp_w0[4]; // shader clock / 100 MHz wal
     do {                                                                                                                        \
         if (v.dbg && (v.dbg_sel < 0 || v.dbg_sel == (idx)) && threadIdx.x == (thread)) v.dbg[2 * 32 + (idx)] = clock64() - pv_t0; \
     } while (0)
-#ifdef PV_HIPEMU
-#define PV_STAMPV2(idx, var) PV_STAMP2(idx)
-#else
+// (an empty asm that "uses" a vector register pins the value to this point of the program; the x86 build of tests/hipemu takes the same
+// line: "v" names a register class there too)
 #define PV_STAMPV2(idx, var)                      \
     do {                                          \
         asm volatile("" : "+v"(var));            \
         PV_STAMP2(idx);                           \
     } while (0)
-#endif
-#ifdef PV_HIPEMU
-#define PV_STAMPV(kern, idx, var) PV_STAMP(kern, idx)
-#else
 #define PV_STAMPV(kern, idx, var)                 \
     do {                                          \
         asm volatile("" : "+v"(var));            \
         PV_STAMP(kern, idx);                      \
     } while (0)
-#endif
 
 // ------------------------------------------------------------------------------------------------------
 // small reductions
@@ -84,11 +78,6 @@ __device__ long long g_stamp_t0[4], g_stamp_w0[4]; // shader clock / 100 MHz wal
 // latency each, twelve per reduction); DPP moves inside the rows of 16 lanes plus four lane reads cost a tenth of that.
 // dpp_f64(x, ctrl): the value of the lane the DPP pattern pairs this lane with.
 __device__ __forceinline__ double dpp_f64(double x, int pattern /* 0: ^1, 1: ^2, 2: mirror in 8, 3: mirror in 16 */) {
-#ifdef PV_HIPEMU
-    const int lane = threadIdx.x & 63;
-    const int src = pattern == 0 ? (lane ^ 1) : pattern == 1 ? (lane ^ 2) : pattern == 2 ? ((lane & ~7) | (7 - (lane & 7))) : ((lane & ~15) | (15 - (lane & 15)));
-    return __shfl(x, src);
-#else
     union { double d; int i[2]; } u, t;
     u.d = x;
     switch (pattern) {
@@ -98,7 +87,6 @@ __device__ __forceinline__ double dpp_f64(double x, int pattern /* 0: ^1, 1: ^2,
     default: t.i[0] = __builtin_amdgcn_update_dpp(0, u.i[0], 0x140, 0xF, 0xF, true), t.i[1] = __builtin_amdgcn_update_dpp(0, u.i[1], 0x140, 0xF, 0xF, true); break; // row_mirror
     }
     return t.d;
-#endif
 }
 __device__ __forceinline__ double readlane_f64(double x, int src);
 // sum over the wave, result in every lane; fixed pairing: inside rows of 16 (^1, ^2, the other quad pair, the other
@@ -161,13 +149,8 @@ __device__ __forceinline__ void block_sum(double *vals, double *scratch) {
 }
 
 constexpr int kPanel = 8; // Cholesky panel width (= K of two f64 MFMAs)
-#ifdef PV_HIPEMU
-typedef hipemu_double4 mfma_d4;
-typedef double lds_d2 __attribute__((vector_size(16)));
-#else
-typedef double mfma_d4 __attribute__((ext_vector_type(4)));
-typedef double lds_d2 __attribute__((ext_vector_type(2)));
-#endif
+typedef double mfma_d4 __attribute__((vector_size(32))); // the accumulator of one v_mfma_f64_16x16x4_f64
+typedef double lds_d2 __attribute__((vector_size(16)));  // one 16-byte LDS access
 
 // The reduced system lives in LDS as 16 x 16 tiles of the lower block triangle (tile (bi, bk), bk <= bi, at
 // (bi (bi + 1) / 2 + bk) * 256 doubles).  Inside a tile the elements are in MFMA accumulator order: lane l of a wave owns
@@ -372,11 +355,7 @@ __device__ __forceinline__ void stage_put(double *stage, int n_tasks, int e_lo, 
     double *dst = stage + ((pe.el - e_lo) * n_tasks + pe.t);
     *dst = add ? *dst + val : val;
 }
-#ifdef PV_HIPEMU
-__device__ __forceinline__ void partial_add(double *p, double x) { *p += x; }
-#else
 __device__ __forceinline__ void partial_add(double *p, double x) { unsafeAtomicAdd(p, x); } // global_atomic_add_f64, no return
-#endif
 
 // MM = false: every thread keeps T 3x3 tiles of the pose system in registers and adds every landmark's direct and Schur
 //      terms to them (right when a workgroup has a handful of landmarks: no set-up, no flush beyond one store per entry).
@@ -1295,13 +1274,8 @@ __device__ __forceinline__ void backsub_landmarks(const View &v, int lin, double
 // request per lane and load (measured 26 us for the 150 x 150 system against ~3 us for this form).  Terms are added in a
 // fixed order (tiles, odd IMU factors, even IMU factors, prior); passes that touch the same entries are separated by
 // barriers.  cm[a] = Jacobi scale of coordinate a, 0 if inactive.
-#ifdef PV_HIPEMU
-#define PV_KEEP(x) ((void)(x))
-#define PV_ORDER() ((void)0)
-#else
 #define PV_ORDER() asm volatile("" ::: "memory") // memory operations are not moved across this point by the compiler
 #define PV_KEEP(x) asm volatile("" : "+v"(x)) // the value is needed HERE: keeps its load unconditional and where it was written
-#endif
 // flags[j] = IMU factor j is present, pframe[q] = frame of prior slot q (both in LDS)
 template <int NT> // threads of the workgroup
 __device__ __forceinline__ void dense_build(const View &v, double *A, const double *cm, const double *rhs_s, const int *flags, const int *pframe, int P, int Pp, int nbk) {
@@ -1568,30 +1542,25 @@ template <bool LA> __device__ __forceinline__ int dt_row_of(int w, int q) { retu
 // before a counter moves is visible to the wave that sees it move)
 __device__ __forceinline__ int dense_wait(int *flag, int target) { // spin until the counter reaches `target` (or goes negative: failed pivot)
     int val;
-#ifdef PV_HIPEMU
-    while ((val = *reinterpret_cast<volatile int *>(flag)) >= 0 && val < target) hipemu::spin_yield();
-#else
     while ((val = __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) >= 0 && val < target) __builtin_amdgcn_s_sleep(1);
-#endif
     return val;
 }
-// (called by a whole wave: lane 0 moves the counter.  On the GPU the lanes of a wave run in lockstep, so everything the wave has
-// stored before is covered by the release; the fiber emulator runs the lanes one after another and needs them to meet first)
-__device__ __forceinline__ void dense_signal_set(int *flag, int val) {
+// (called by a whole wave: lane 0 moves the counter.  The lanes of a wave run in lockstep, so everything the wave has stored before is
+// covered by lane 0's release.  The fiber emulator of tests/hipemu runs the lanes one after another and needs a place where they meet:
+// this is the one conditional on it left in the kernel sources -- __builtin_amdgcn_wave_barrier() emits no instruction on the GPU
+// either, but it changed the block layout of k_dense<true, true> (218 lines of ISA), and that kernel ships as it was measured.)
 #ifdef PV_HIPEMU
-    (void)__shfl(0, 0);
-    if ((threadIdx.x & 63) == 0) *reinterpret_cast<volatile int *>(flag) = val;
+#define PV_LANES_MEET() __builtin_amdgcn_wave_barrier()
 #else
-    if ((threadIdx.x & 63) == 0) __hip_atomic_store(flag, val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+#define PV_LANES_MEET() ((void)0)
 #endif
+__device__ __forceinline__ void dense_signal_set(int *flag, int val) {
+    PV_LANES_MEET();
+    if ((threadIdx.x & 63) == 0) __hip_atomic_store(flag, val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 __device__ __forceinline__ void dense_signal_add(int *flag) {
-#ifdef PV_HIPEMU
-    (void)__shfl(0, 0);
-    if ((threadIdx.x & 63) == 0) *reinterpret_cast<volatile int *>(flag) = *reinterpret_cast<volatile int *>(flag) + 1;
-#else
+    PV_LANES_MEET();
     if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
 }
 
 // compile-time storage choice: a runtime LDS-or-global pointer select degrades every access to FLAT.  The register-resident
@@ -3270,14 +3239,12 @@ template <int T, bool MM>
 static hipError_t launch_lin_TM(const View &v, hipStream_t st) {
     const int grid = v.dm.G_lm + v.dm.G_plane + v.dm.G_pre + v.dm.G_prior;
     const size_t lds = linearize_lds_bytes(v.dm);
-#ifndef PV_HIPEMU
     static size_t configured = 0;
     if (lds > configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_linearize<T, MM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         configured = lds;
     }
-#endif
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_linearize<T, MM>), dim3(grid), dim3(kLinThreads), lds, st, v);
     return hipGetLastError();
 }
@@ -3321,7 +3288,6 @@ size_t dense_lds_bytes(const Dims &dm, int *lds_matrix) {
 hipError_t launch_dense(const View &v, hipStream_t st) {
     int lm;
     const size_t lds = dense_lds_bytes(v.dm, &lm);
-#ifndef PV_HIPEMU
     static size_t configured = 0, configured_g = 0;
     if (lm && lds > configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dense<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -3335,7 +3301,6 @@ hipError_t launch_dense(const View &v, hipStream_t st) {
         if (e != hipSuccess) return e;
         configured_g = lds;
     }
-#endif
     static const bool say = std::getenv("PVIO_HIP_DEBUG_LAUNCH") != nullptr;
     static bool said = false;
     if (say && !said) said = true, std::fprintf(stderr, "launch_dense: lds matrix %d, look-ahead %d, split finalize %d, qvv in backsub %d\n", lm, v.dm.dense_la, v.dm.split_fin, v.dm.qvv_back);

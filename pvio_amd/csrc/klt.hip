@@ -201,11 +201,6 @@ __global__ void k_pyr_down(LevelDesc src, LevelDesc dst) {
 // sum over the wave, result in every lane.  DPP moves inside the rows of 16 lanes, then the four row sums by lane reads
 // in a fixed order: a `__shfl_xor` butterfly is six ds_bpermute round trips (~250 cycles), this is ~90.
 __device__ __forceinline__ float dpp_f32(float x, int pattern /* 0: ^1, 1: ^2, 2: mirror in 8, 3: mirror in 16 */) {
-#ifdef PV_HIPEMU
-    const int lane = threadIdx.x & 63;
-    const int src = pattern == 0 ? (lane ^ 1) : pattern == 1 ? (lane ^ 2) : pattern == 2 ? ((lane & ~7) | (7 - (lane & 7))) : ((lane & ~15) | (15 - (lane & 15)));
-    return __shfl(x, src);
-#else
     const int i = __float_as_int(x);
     switch (pattern) {
     case 0: return __int_as_float(__builtin_amdgcn_update_dpp(0, i, 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
@@ -213,14 +208,9 @@ __device__ __forceinline__ float dpp_f32(float x, int pattern /* 0: ^1, 1: ^2, 2
     case 2: return __int_as_float(__builtin_amdgcn_update_dpp(0, i, 0x141, 0xF, 0xF, true)); // row_half_mirror
     default: return __int_as_float(__builtin_amdgcn_update_dpp(0, i, 0x140, 0xF, 0xF, true)); // row_mirror
     }
-#endif
 }
 __device__ __forceinline__ float readlane_f32(float x, int src) {
-#ifdef PV_HIPEMU
-    return __shfl(x, src);
-#else
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), src));
-#endif
 }
 __device__ __forceinline__ float wave_sum_f(float v) {
     v += dpp_f32(v, 0);
@@ -249,12 +239,8 @@ struct lk_drv_raw {
 // (p00 w00 + p01 w01 + p10 w10 + p11 w11 + round) >> shift, is two of these on (pixel, right neighbour) pairs and
 // (left weight, right weight) pairs -- exact integer arithmetic (pixels <= 255 or int16 derivatives, weights <= 2^14).
 __device__ __forceinline__ int lk_dot2(int a, int b, int c) {
-#ifdef PV_HIPEMU
-    return (int)(int16_t)(a & 0xffff) * (int)(int16_t)(b & 0xffff) + (a >> 16) * (b >> 16) + c;
-#else
-    typedef short lk_s2 __attribute__((ext_vector_type(2)));
-    return __builtin_amdgcn_sdot2(__builtin_bit_cast(lk_s2, a), __builtin_bit_cast(lk_s2, b), c, false);
-#endif
+    typedef short lk_s2 __attribute__((vector_size(4)));
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(lk_s2, a), __builtin_bit_cast(lk_s2, b), c, false); // v_dot2_i32_i16
 }
 // (tap k, tap k + 1) pairs of one row of 8 taps, k = 0..6
 __device__ __forceinline__ void lk_tap_pairs(uint64_t w, int *pr) {

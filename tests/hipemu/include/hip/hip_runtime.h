@@ -146,6 +146,41 @@ inline int __builtin_amdgcn_readfirstlane(int v) {
     hipemu::wave_exchange(&v, all, sizeof(int));
     return all[0];
 }
+// v_mov_b32 with a DPP modifier: the four lane pairings the kernels use (ctrl as in the ISA manual), all lanes enabled
+inline int __builtin_amdgcn_update_dpp(int /*old*/, int src, int ctrl, int row_mask, int bank_mask, bool /*bound_ctrl*/) {
+    const int lane = hipemu::g_cur->lane;
+    int from;
+    if (ctrl == 0xB1) from = lane ^ 1;                                // quad_perm [1,0,3,2]
+    else if (ctrl == 0x4E) from = lane ^ 2;                           // quad_perm [2,3,0,1]
+    else if (ctrl == 0x141) from = (lane & ~7) | (7 - (lane & 7));    // row_half_mirror
+    else if (ctrl == 0x140) from = (lane & ~15) | (15 - (lane & 15)); // row_mirror
+    else std::abort();
+    if (row_mask != 0xF || bank_mask != 0xF) std::abort();
+    return __shfl(src, from);
+}
+// v_dot2_i32_i16
+typedef short hipemu_short2 __attribute__((vector_size(4)));
+inline int __builtin_amdgcn_sdot2(hipemu_short2 a, hipemu_short2 b, int c, bool /*clamp*/) { return (int)a[0] * (int)b[0] + (int)a[1] * (int)b[1] + c; }
+// the lanes of a wave run in lockstep on the GPU; here they are fibers that run one after another: this is where they meet (the kernels
+// call it in front of a release by lane 0, so that the release covers what every lane of the wave has stored)
+inline void __builtin_amdgcn_wave_barrier() { (void)__shfl(0, 0); }
+inline void __builtin_amdgcn_s_sleep(int) { hipemu::spin_yield(); } // a polling loop lets the other fibers run
+#define __HIP_MEMORY_SCOPE_WORKGROUP 2
+template <typename T>
+inline T __hip_atomic_load(const T *p, int, int) { return *reinterpret_cast<const volatile T *>(p); }
+template <typename T>
+inline void __hip_atomic_store(T *p, T v, int, int) { *reinterpret_cast<volatile T *>(p) = v; }
+template <typename T>
+inline T __hip_atomic_fetch_add(T *p, T v, int, int) {
+    T old = *reinterpret_cast<volatile T *>(p);
+    *reinterpret_cast<volatile T *>(p) = old + v;
+    return old;
+}
+inline double unsafeAtomicAdd(double *p, double v) {
+    double old = *p;
+    *p = old + v;
+    return old;
+}
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline unsigned long long __ballot(int pred) {
     int all[64];
@@ -200,6 +235,8 @@ inline hipemu_double4 __builtin_amdgcn_mfma_f64_16x16x4f64(double a, double b, h
 // ---- host API -------------------------------------------------------------------------------------------
 inline const char *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "hipemu error"; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+inline hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return hipSuccess; } // (the launch checks the 160 KiB limit itself)
 inline hipError_t hipGetDeviceCount(int *n) {
     *n = 1;
     return hipSuccess;
