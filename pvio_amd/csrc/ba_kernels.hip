@@ -1546,20 +1546,16 @@ __device__ __forceinline__ int dense_wait(int *flag, int target) { // spin until
     return val;
 }
 // (called by a whole wave: lane 0 moves the counter.  The lanes of a wave run in lockstep, so everything the wave has stored before is
-// covered by lane 0's release.  The fiber emulator of tests/hipemu runs the lanes one after another and needs a place where they meet:
-// this is the one conditional on it left in the kernel sources -- __builtin_amdgcn_wave_barrier() emits no instruction on the GPU
-// either, but it changed the block layout of k_dense<true, true> (218 lines of ISA), and that kernel ships as it was measured.)
-#ifdef PV_HIPEMU
-#define PV_LANES_MEET() __builtin_amdgcn_wave_barrier()
-#else
-#define PV_LANES_MEET() ((void)0)
-#endif
+// covered by lane 0's release.  __builtin_amdgcn_wave_barrier() emits no instruction: it states that to the compiler -- and it is where
+// the fiber emulator of tests/hipemu, which runs the lanes one after another, lets them meet.  It does change the block layout of
+// k_dense<true, true> (218 lines of ISA): measured against the build without it on one box, 13 323 vs 13 275 iterations/s, same results
+// (tests/micro/build_variant.py no_wave_barrier).)
 __device__ __forceinline__ void dense_signal_set(int *flag, int val) {
-    PV_LANES_MEET();
+    __builtin_amdgcn_wave_barrier();
     if ((threadIdx.x & 63) == 0) __hip_atomic_store(flag, val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 __device__ __forceinline__ void dense_signal_add(int *flag) {
-    PV_LANES_MEET();
+    __builtin_amdgcn_wave_barrier();
     if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
