@@ -47,6 +47,12 @@ RECIPES = {
     # section -> the first factorization of every solve fails on the GPU (tests/micro/dbg_case.py shows the control block)
     "fin_copy": dict(subs=[(FIN_REF, FIN_COPY)]),
     "shipped": dict(),
+    # scheduler settings tried on the whole file at the end of round 3 (profiles/r3_ab_sched_flags.txt)
+    "sched_max_ilp": dict(flags=["-mllvm", "-amdgpu-sched-strategy=max-ilp"]),
+    "sched_max_clause": dict(flags=["-mllvm", "-amdgpu-sched-strategy=max-memory-clause"]),
+    "sched_no_cluster": dict(flags=["-mllvm", "-misched-cluster=false"]),
+    "sched_bias0": dict(flags=["-mllvm", "-amdgpu-schedule-metric-bias=0"]),
+    "sched_postra": dict(flags=["-mllvm", "-misched-postra"]),
     # round 3, clean-up of the emulator conditionals: the no-op wave barrier in front of lane 0's release moves 218 lines of k_dense<true, true>;
     # this is the build without it (the state up to commit 216133f)
     "no_wave_barrier": dict(subs=[("""    __builtin_amdgcn_wave_barrier();
