@@ -968,27 +968,46 @@ int BASolver::marginalize(const pvio_ba_problem *pb, const pvio_ba_state *st, in
     if (out->info_matrix) std::memcpy(out->info_matrix, C.data(), sizeof(double) * R * R);
     if (out->info_vector) std::memcpy(out->info_vector, cv.data(), sizeof(double) * R);
     // ---- sqrt information: sqrt(L) V^T and L^-1/2 V^T b, eigenvalues <= 1e-8 zeroed (:583-590) ----
-    std::vector<double> w(R);
-    V.resize((size_t)R * R);
+    // Coordinates without any information -- an exactly zero row and column: velocity / biases of a frame no IMU factor or prior reaches --
+    // are eigenvectors of eigenvalue 0 by themselves and stay out of the eigen-problem: a backward-stable solver would hand them back with
+    // an eigenvalue of a few eps |C| and a few eps of every other coordinate mixed in, which the 1e-8 cut then keeps or drops as the rounding
+    // falls.  Their rows of S are zero (they come first, like the zero eigenvalues of the full problem).
+    std::vector<int> keep;
+    keep.reserve(R);
+    for (int i = 0; i < R; ++i) {
+        bool zero = true;
+        for (int j = 0; j < R && zero; ++j) zero = C[(size_t)i * R + j] == 0.0 && C[(size_t)j * R + i] == 0.0;
+        if (!zero) keep.push_back(i);
+    }
+    const int Rk = (int)keep.size(), nz = R - Rk;
+    std::vector<double> w(std::max(Rk, 1));
+    V.resize((size_t)std::max(Rk, 1) * std::max(Rk, 1));
     const auto tm3 = std::chrono::steady_clock::now();
-    sym_eig(C.data(), R, w.data(), V.data());
+    if (nz > 0) { // compress the kept coordinates to the front of C's storage (the copies above have been made)
+        for (int a = 0; a < Rk; ++a)
+            for (int b = 0; b < Rk; ++b) C[(size_t)a * Rk + b] = C[(size_t)keep[a] * R + keep[b]];
+    }
+    if (Rk > 0) sym_eig(C.data(), Rk, w.data(), V.data());
     const auto tm4 = std::chrono::steady_clock::now();
     out->n = N - 1;
-    for (int k = 0; k < R; ++k) {
+    std::fill(out->S, out->S + (size_t)R * R, 0.0);
+    std::fill(out->s, out->s + R, 0.0);
+    for (int k = 0; k < Rk; ++k) {
         const double lam = w[k] > 1.0e-8 ? w[k] : 0.0, lam_inv = w[k] > 1.0e-8 ? 1.0 / w[k] : 0.0;
         const double sl = std::sqrt(lam), sli = std::sqrt(lam_inv);
         double acc = 0;
-        for (int i = 0; i < R; ++i) {
-            out->S[(size_t)k * R + i] = sl * V[(size_t)k * R + i];
-            acc += V[(size_t)k * R + i] * cv[i];
+        double *Srow = out->S + (size_t)(nz + k) * R;
+        for (int i = 0; i < Rk; ++i) {
+            Srow[keep[i]] = sl * V[(size_t)k * Rk + i];
+            acc += V[(size_t)k * Rk + i] * cv[keep[i]];
         }
-        out->s[k] = sli * acc;
+        out->s[nz + k] = sli * acc;
     }
     uploaded_ = false; // the device buffers now hold a marginalization pass, not a solvable window
     if (timing) {
         auto us = [](auto a, auto b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
         std::fprintf(stderr, "[pvio-hip] marginalize: upload %.0f us, kernels + read-back %.0f us, assembly + elimination %.0f us, eigen-decomposition (%d x %d) %.0f us, sqrt-information %.0f us\n",
-                     us(tm0, tm1), us(tm1, tm2), us(tm2, tm3), R, R, us(tm3, tm4), us(tm4, std::chrono::steady_clock::now()));
+                     us(tm0, tm1), us(tm1, tm2), us(tm2, tm3), Rk, Rk, us(tm3, tm4), us(tm4, std::chrono::steady_clock::now()));
     }
     return PVIO_OK;
 }
