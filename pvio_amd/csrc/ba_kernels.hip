@@ -3109,15 +3109,31 @@ __global__ void __launch_bounds__(256) k_backsub(View v) {
 // Landmark-sharded solves only: back_local keeps this rank's latest k_backsub sums (they stay valid across rejected
 // steps, when k_backsub does not run); every slot copies them into back_red, which the host then all-reduces IN PLACE --
 // so the collective can be issued unconditionally without accumulating stale values.
-__global__ void k_back_reduce(View v, int rows, double *back_local) {
+// (one wave.  The rows are summed the way the prologue of k_linearize sums them on one GPU -- lane-strided partial sums, then the wave
+// reduction -- with every load of a lane independent of the others: seven threads walking the rows one dependent load at a time took 21 us
+// for the 256 rows of a 10 x 50 000 window, inside the serial part of every sharded iteration)
+__global__ void __launch_bounds__(64) k_back_reduce(View v, int rows, double *back_local) {
     const Ctrl *c = v.ctrl;
-    if (threadIdx.x < kNumBackScal) {
-        if (!c->done && c->solve_ok) {
+    const int lane = threadIdx.x;
+    const bool live = !c->done && c->solve_ok; // uniform
+    double b[kNumBackScal];
+#pragma unroll
+    for (int k = 0; k < kNumBackScal; ++k) b[k] = 0.0;
+    if (live) {
+        for (int row = lane; row < rows; row += 64)
+#pragma unroll
+            for (int k = 0; k < kNumBackScal; ++k) b[k] += v.back_part[(size_t)row * kNumBackScal + k];
+#pragma unroll
+        for (int k = 0; k < kNumBackScal; ++k) b[k] = wave_sum(b[k]);
+    }
+    if (lane < kNumBackScal) {
+        if (live) {
             double s = 0;
-            for (int r = 0; r < rows; ++r) s += v.back_part[(size_t)r * kNumBackScal + threadIdx.x];
-            back_local[threadIdx.x] = s;
+#pragma unroll
+            for (int k = 0; k < kNumBackScal; ++k) s = lane == k ? b[k] : s;
+            back_local[lane] = s;
         }
-        v.back_red[threadIdx.x] = back_local[threadIdx.x];
+        v.back_red[lane] = back_local[lane];
     }
 }
 
