@@ -3029,7 +3029,7 @@ __global__ void __launch_bounds__(256) k_backsub(View v) {
     const int n_lm_wg = v.dm.split_fin ? v.dm.G_back : (int)gridDim.x; // landmark workgroups (the finalize workgroup is not one)
     double himg = 0;
     int hi = 0, hk = 0;
-    const int n_img_tiles = v.dm.qvv_back ? v.dm.img_sz >> 8 : 0;
+    const int n_img_tiles = (v.dm.qvv_back && (v.dm.world <= 1 || v.dm.rank == 0)) ? v.dm.img_sz >> 8 : 0; // (shards: rank 0's rows carry it)
     const int my_tile = (int)blockIdx.x;
     if (my_tile < n_img_tiles) himg = v.img[((size_t)my_tile << 8) + threadIdx.x];
     if (done || !solve_ok) return; // uniform (the loads above were only issued)

@@ -372,7 +372,9 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st, bool ma
         // and (register-resident factorization: the image is what it factors) the pose part of v^T H v to that launch.
         // PVIO_HIP_SPLIT_FIN=0 keeps everything in k_dense (A/B timing, tests of both forms).
         static const bool split_off = std::getenv("PVIO_HIP_SPLIT_FIN") != nullptr && std::atoi(std::getenv("PVIO_HIP_SPLIT_FIN")) == 0;
-        dm.split_fin = (!sharded_ && !dm.fuse_backsub && !split_off) ? 1 : 0;
+        // (landmark shards: every rank runs the same finalize workgroup on the same all-reduced data; the pose part of v^T H v is formed by
+        // rank 0's k_backsub alone -- the exchange step behind it sums the ranks' rows)
+        dm.split_fin = (!dm.fuse_backsub && !split_off) ? 1 : 0;
         dm.qvv_back = (dm.split_fin && dm.use_img && lds_matrix) ? 1 : 0;
         v.dm.split_fin = dm.split_fin, v.dm.qvv_back = dm.qvv_back;
         // look-ahead form of the register-resident factorization (PVIO_HIP_DENSE_LA=0 / 1 overrides the default)
