@@ -408,7 +408,14 @@ __device__ __forceinline__ void role_landmarks(const View &v, double *lds, const
     int tile_bb[TW]; // bi << 8 | bj of this wave's tiles, -1 past the last tile
     double Drow[6], Crow[6], aa = 0.0;
     int cur_anchor = -1;
-    const int myf = tid / 6, myi = tid - 6 * myf;
+    // Direct part (MM): thread `lt` = 6 f + i owns row i of frame f's two 6 x 6 blocks and the pose-vector entries.  P6 <= 64 (N <= 10):
+    // the four waves each hold the whole row set (lt = lane) and take every fourth landmark of a chunk -- one wave walking the landmarks
+    // one after another while three wait was half of the tile phase at 10 x 50 000 -- and the four partial sets are added in wave order
+    // (fixed) at every anchor flush and in front of the final flush.  Otherwise lt = tid as before.
+    const bool split4 = MM && P6 <= 64; // uniform
+    const int lt = split4 ? (tid & 63) : tid;
+    const int myf = lt / 6, myi = lt - 6 * myf;
+    double *xw = chunk + (size_t)slots * rec + slots + 2 * ((slots + 1) / 2) + 4; // [4][64][6] Crow, [4][36] aa (split4 only; linearize_lds_bytes)
     if constexpr (MM) {
 #pragma unroll
         for (int u = 0; u < TW; ++u) {
@@ -663,6 +670,18 @@ __device__ __forceinline__ void role_landmarks(const View &v, double *lds, const
                             __syncthreads();
                             row_dirty = true;
                         }
+                        if (split4) { // the four waves' (target, anchor) rows and anchor blocks -> wave 0, in wave order
+                            const int wq = tid >> 6, lq = tid & 63;
+#pragma unroll
+                            for (int j = 0; j < 6; ++j) xw[(wq * 64 + lq) * 6 + j] = Crow[j];
+                            if (lq < 36) xw[4 * 64 * 6 + wq * 36 + lq] = aa;
+                            __syncthreads();
+#pragma unroll
+                            for (int j = 0; j < 6; ++j)
+                                Crow[j] = wq == 0 ? ((xw[lq * 6 + j] + xw[(64 + lq) * 6 + j]) + xw[(128 + lq) * 6 + j]) + xw[(192 + lq) * 6 + j] : 0.0;
+                            aa = (wq == 0 && lq < 36) ? ((xw[4 * 64 * 6 + lq] + xw[4 * 64 * 6 + 36 + lq]) + xw[4 * 64 * 6 + 72 + lq]) + xw[4 * 64 * 6 + 108 + lq] : 0.0;
+                            __syncthreads();
+                        }
                         if (tid < P6 && myf != cur_anchor) {
 #pragma unroll
                             for (int j = 0; j < 6; ++j) {
@@ -679,7 +698,8 @@ __device__ __forceinline__ void role_landmarks(const View &v, double *lds, const
                     }
                     cur_anchor = a;
                 }
-                if (tid < P6) {
+                const bool mine = !split4 || (s & 3) == (tid >> 6);
+                if (lt < P6 && mine) {
                     // (records, field offsets and 12 f / 16 f + 4 are even: 16-byte loads)
                     const double *JTs = R + 6 * N + 12 * myf;
                     const lds_d2 *JT2 = reinterpret_cast<const lds_d2 *>(JTs), *JR2 = reinterpret_cast<const lds_d2 *>(R + 18 * N + 16 * myf + 4);
@@ -692,11 +712,11 @@ __device__ __forceinline__ void role_landmarks(const View &v, double *lds, const
                         Drow[j] += x0 * t0[j >> 1][j & 1] + x1 * t1[j >> 1][j & 1];
                         Crow[j] += x0 * q0[j >> 1][j & 1] + x1 * q1[j >> 1][j & 1];
                     }
-                    vg += R[34 * N + tid] + (a == myf ? HAA[36 + myi] : 0.0);
-                    vrhs += SC[0] * SC[1] * R[tid];
+                    vg += R[34 * N + lt] + (a == myf ? HAA[36 + myi] : 0.0);
+                    vrhs += SC[0] * SC[1] * R[lt];
                     vdiag += x0 * x0 + x1 * x1 + (a == myf ? HAA[7 * myi] : 0.0);
                 }
-                if (tid < 36) aa += HAA[tid];
+                if (lt < 36 && mine) aa += HAA[lt];
             }
         } else
         for (int s = 0; s < ns; ++s) {
@@ -749,6 +769,22 @@ __device__ __forceinline__ void role_landmarks(const View &v, double *lds, const
         // then the diagonal / (target, anchor) rows (disjoint blocks), then the last anchor's own block, then what earlier
         // anchor flushes (if any) left in the row.
         double *stage = chunk;
+        if (split4) { // the four waves' row sets and pose-vector entries -> wave 0, in wave order (the chunk area is free)
+            const int wq = tid >> 6, lq = tid & 63;
+            double *xs = chunk + (size_t)(wq * 64 + lq) * 16;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) xs[j] = Drow[j], xs[6 + j] = Crow[j];
+            xs[12] = vg, xs[13] = vrhs, xs[14] = vdiag, xs[15] = aa;
+            __syncthreads();
+            const double *x0s = chunk + (size_t)lq * 16, *x1s = x0s + 64 * 16, *x2s = x1s + 64 * 16, *x3s = x2s + 64 * 16;
+            if (wq == 0) {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) Drow[j] = ((x0s[j] + x1s[j]) + x2s[j]) + x3s[j], Crow[j] = ((x0s[6 + j] + x1s[6 + j]) + x2s[6 + j]) + x3s[6 + j];
+                vg = ((x0s[12] + x1s[12]) + x2s[12]) + x3s[12], vrhs = ((x0s[13] + x1s[13]) + x2s[13]) + x3s[13];
+                vdiag = ((x0s[14] + x1s[14]) + x2s[14]) + x3s[14], aa = ((x0s[15] + x1s[15]) + x2s[15]) + x3s[15];
+            }
+            __syncthreads(); // (the stage is cleared next)
+        }
         for (int h = 0; h < 2; ++h) {
             const int e_lo = 5 * h, e_n = h == 0 ? 5 : 4;
 
@@ -3234,7 +3270,9 @@ size_t linearize_lds_bytes(const Dims &dm) {
     size_t common = (size_t)(N * 16 + N * kFrameRec + 160 + 16);
     const size_t slots = dm.lm_mm ? (size_t)((dm.lm_slots + 3) & ~3) : (size_t)dm.lm_slots;
     size_t lm = slots * (40 * N + 46) + slots + 2 * ((slots + 1) / 2) + 4;
+    if (dm.lm_mm && dm.P6 <= 64) lm += 4 * 64 * 6 + 4 * 36; // the four waves' (target, anchor) rows / anchor blocks at an anchor flush
     if (dm.lm_mm && lm < (size_t)dm.n_tasks * 5) lm = (size_t)dm.n_tasks * 5; // staging of the final flush
+    if (dm.lm_mm && dm.P6 <= 64 && lm < 4 * 64 * 16) lm = 4 * 64 * 16;          // ... and the four waves' sets in front of it
     size_t pl = (size_t)dm.plane_slots * (dm.P6 + 2);
     size_t pre = 16 + 450 + 450 + 16 + 225;
     size_t pri = (size_t)dm.prior_n * (15 + 9) + 40;
