@@ -166,6 +166,9 @@ MM_CASES = {
     "vio_plane": ba_compare.CASES["vio_plane"],
     "vio_10x200_anchor_changes": dict(n_frames=10, n_landmarks=200, use_inertial=True, visibility=5),  # one workgroup, 8 chunks, 6 anchors
     "vision_16x120_twelve_tiles_per_wave": dict(n_frames=16, n_landmarks=120, visibility=9),
+    # N <= 10: the direct part is dealt to the four waves (partial row sets added in wave order at anchor flushes and at the end)
+    "vio_4x150_four_wave_direct_part": dict(n_frames=4, n_landmarks=150, use_inertial=True, visibility=3),
+    "metric_10x1000_vio_four_wave_direct_part": dict(n_frames=10, n_landmarks=1000, use_inertial=True),
 }
 
 
