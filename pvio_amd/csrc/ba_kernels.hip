@@ -1446,40 +1446,58 @@ __device__ __forceinline__ void dense_build(const View &v, double *A, const doub
 // IMU blocks + prior, unscaled, in the layout of A, so the build is one coalesced sweep (32 bytes per lane and step)
 // instead of four passes whose read-modify-writes each wait on a global round trip when A lives in HBM.
 template <int NT>
-__device__ __forceinline__ void dense_build_image(const View &v, double *A, const double *cm, const double *rhs_s, int P, int Pp, int nbk) {
+__device__ __forceinline__ double dense_build_image(const View &v, double *A, const double *cm, const double *rhs_s, const double *vvec, int P, int Pp, int nbk) {
+    // Four tiles of a wave are requested before the first one is used (one tile per pass was one trip to L2 / HBM per pass: 55 passes
+    // per wave at P = 450), and the pose quadratic form v^T S v = sum_ik S_ik v_i v_k is taken from the values on their way out instead
+    // of by a second sweep over the 1.6 MB matrix this workgroup has just written.  Returns this thread's share of it.
     const int tid = threadIdx.x;
-    constexpr int nthr = NT;
+    constexpr int nthr = NT, NW = NT / 64, kAhead = 4;
     const int ntile = (nbk * (nbk + 1)) >> 1;
     const int ln = tid & 63, lr = ln & 15, lk = ln >> 4;
     int ti = tid >> 6, bi = 0, bk = ti;
     while (bk > bi) bk -= bi + 1, ++bi;
-    for (; ti < ntile; ti += nthr / 64) {
-        const double *src = v.img + ((size_t)ti << 8) + 4 * ln;
-        double *dst = A + ((size_t)ti << 8) + 4 * ln;
-        const lds_d2 s01 = *reinterpret_cast<const lds_d2 *>(src), s23 = *reinterpret_cast<const lds_d2 *>(src + 2);
-        const int k = 16 * bk + lr;
-        const double ck = k < P ? cm[k] : 0.0;
-        double o[4];
+    double q = 0.0;
+    for (; ti < ntile; ti += kAhead * NW) {
+        lds_d2 s01[kAhead], s23[kAhead];
+        int tbi[kAhead], tbk[kAhead];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int i = 16 * bi + lk + 4 * r;
-            const double val = r < 2 ? s01[r & 1] : s23[r & 1];
-            if (i == Pp) o[r] = k < P ? -rhs_s[k] : 0.0;                                   // augmented row: scaled rhs
-            else if (i > Pp || k > i) o[r] = 0.0;
-            else if (i == k) o[r] = (i < P && ck != 0.0) ? -(val * ck * ck) : -1.0;        // unit rows: inactive coordinates, panel padding
-            else {
-                const double sc = (i < P ? cm[i] : 0.0) * ck;
-                o[r] = sc != 0.0 ? -(val * sc) : 0.0;
-            }
+        for (int u = 0; u < kAhead; ++u) {
+            const int tu = ti + u * NW;
+            tbi[u] = bi, tbk[u] = bk;
+            const double *src = v.img + ((size_t)(tu < ntile ? tu : ti) << 8) + 4 * ln;
+            s01[u] = *reinterpret_cast<const lds_d2 *>(src), s23[u] = *reinterpret_cast<const lds_d2 *>(src + 2);
+            bk += NW;
+            while (bk > bi) bk -= bi + 1, ++bi;
         }
-        lds_d2 w01, w23;
-        w01[0] = o[0], w01[1] = o[1], w23[0] = o[2], w23[1] = o[3];
-        *reinterpret_cast<lds_d2 *>(dst) = w01;
-        *reinterpret_cast<lds_d2 *>(dst + 2) = w23;
-        bk += nthr / 64;
-        while (bk > bi) bk -= bi + 1, ++bi;
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u) {
+            const int tu = ti + u * NW;
+            if (tu >= ntile) break; // wave-uniform
+            double *dst = A + ((size_t)tu << 8) + 4 * ln;
+            const int k = 16 * tbk[u] + lr;
+            const double ck = k < P ? cm[k] : 0.0, vk = vvec[k];
+            double o[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * tbi[u] + lk + 4 * r;
+                const double val = r < 2 ? s01[u][r & 1] : s23[u][r & 1];
+                if (i == Pp) o[r] = k < P ? -rhs_s[k] : 0.0;                                   // augmented row: scaled rhs
+                else if (i > Pp || k > i) o[r] = 0.0;
+                else if (i == k) o[r] = (i < P && ck != 0.0) ? -(val * ck * ck) : -1.0;        // unit rows: inactive coordinates, panel padding
+                else {
+                    const double sc = (i < P ? cm[i] : 0.0) * ck;
+                    o[r] = sc != 0.0 ? -(val * sc) : 0.0;
+                }
+                q -= ((i == k ? o[r] : 2.0 * o[r]) * vk) * vvec[i]; // (stored negated; v is zero past P: the augmented row and the padding add nothing)
+            }
+            lds_d2 w01, w23;
+            w01[0] = o[0], w01[1] = o[1], w23[0] = o[2], w23[1] = o[3];
+            *reinterpret_cast<lds_d2 *>(dst) = w01;
+            *reinterpret_cast<lds_d2 *>(dst + 2) = w23;
+        }
     }
     __syncthreads();
+    return q;
 }
 
 // Trailing sweep of the generic (matrix in HBM) factorization: (-C)(16x16) += L_i (16 x W) L_k^T for every tile of the
@@ -2069,12 +2087,18 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
         for (int e = tid; e < 8 * LDV; e += nthr) Lp[e] = 0.0;
         __syncthreads();
         PV_STAMP2(21);
-        if (!LDSMAT && v.dm.use_img) dense_build_image<nthr>(v, A, cpl, yv, P, Pp, nbk);
+        const bool fused_qvv = !LDSMAT && v.dm.use_img; // (uniform) the build from the image forms v^T S v on the way
+        double q_build = 0.0;
+        if (fused_qvv) q_build = dense_build_image<nthr>(v, A, cpl, yv, vv, P, Pp, nbk);
         else dense_build<nthr>(v, A, cpl, yv, pvalid, pframe, P, Pp, nbk);
         PV_STAMP2(22);
         // pose quadratic form with the Schur-reduced scaled matrix (mu D^2 not yet added): v^T S v = sum S_ik v_i v_k
         // (thread = one (row, column) of every tile; the vector S v itself is not needed: v^T S y' follows from the solve)
-        {
+        if (fused_qvv) {
+            double s1[1] = {q_build};
+            block_sum<1>(s1, red_scratch);
+            if (tid == 0) c->pose_qvv = s1[0];
+        } else {
             const int r = (tid & 255) >> 4, cc = tid & 15, off = tile_off(r, cc);
             double q = 0;
             for (int bi = tid >> 8; bi < nbk; bi += nthr / 256) { // 256 threads cover a tile; a second half takes every other tile row
