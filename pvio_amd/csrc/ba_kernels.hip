@@ -3267,22 +3267,34 @@ __global__ void k_quality(View v, int buf_from_ctrl, double *err_sum /* [2] opti
 }
 
 // Lambda = S^T S, eta = S^T s of the marginalization prior (once per upload)
-__global__ void k_prior_prep(const double *S, const double *s, int D, double *Lambda, double *eta, double *ST) {
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < D * (D + 1); e += gridDim.x * blockDim.x) {
-        const int a = e / (D + 1), b = e - a * (D + 1);
-        double acc = 0;
-        // D dependent trips through L2 when the loop is left rolled (63 us at D = 150): fifteen rows requested at a time, summed
-        // in the same order
-        if (b < D) {
-#pragma unroll 15
-            for (int r = 0; r < D; ++r) acc += S[(size_t)r * D + a] * S[(size_t)r * D + b];
-            Lambda[(size_t)a * D + b] = acc;
-            ST[(size_t)a * D + b] = S[(size_t)b * D + a];
-        } else {
-#pragma unroll 15
-            for (int r = 0; r < D; ++r) acc += S[(size_t)r * D + a] * s[r];
-            eta[a] = acc;
+// One workgroup = one 16 x 16 tile of Lambda (or, in the last tile column, sixteen entries of eta): the two column blocks of S it needs
+// go through LDS 128 rows at a time, coalesced, so that a thread's D-long sum reads LDS instead of making D / 15 dependent trips to L2
+// (15 us per upload at D = 150, 94 us at D = 435 that way).  Every entry is still summed over the rows in ascending order.
+__global__ void __launch_bounds__(256) k_prior_prep(const double *S, const double *s, int D, double *Lambda, double *eta, double *ST) {
+    constexpr int kRows = 128;
+    __shared__ double Sa[kRows][16], Sb[kRows][16];
+    const int tid = threadIdx.x, i = tid >> 4, j = tid & 15;
+    const int nt = (D + 15) >> 4, ta = blockIdx.y, tb = blockIdx.x; // tb == nt: the eta column
+    const int a = 16 * ta + i, b = 16 * tb + j;
+    const bool is_eta = tb == nt;
+    double acc = 0;
+    for (int r0 = 0; r0 < D; r0 += kRows) {
+        const int nr = D - r0 < kRows ? D - r0 : kRows;
+        for (int rr = i; rr < nr; rr += 16) { // 16 rows per pass, 16 consecutive doubles (128 bytes) per row and block
+            const size_t row = (size_t)(r0 + rr) * D;
+            Sa[rr][j] = 16 * ta + j < D ? S[row + 16 * ta + j] : 0.0;
+            Sb[rr][j] = is_eta ? (j == 0 ? s[r0 + rr] : 0.0) : (b < D ? S[row + b] : 0.0);
         }
+        __syncthreads();
+        for (int rr = 0; rr < nr; ++rr) acc += Sa[rr][i] * Sb[rr][j];
+        __syncthreads();
+    }
+    if (a >= D) return;
+    if (is_eta) {
+        if (j == 0) eta[a] = acc;
+    } else if (b < D) {
+        Lambda[(size_t)a * D + b] = acc;
+        ST[(size_t)a * D + b] = S[(size_t)b * D + a];
     }
 }
 
@@ -3430,8 +3442,8 @@ hipError_t launch_gather(const GatherArgs &a, void *dst, hipStream_t st) {
     return hipGetLastError();
 }
 hipError_t launch_prior_prep(const double *S, const double *s, int D, double *Lambda, double *eta, double *ST, hipStream_t st) {
-    int grid = (D * (D + 1) + 255) / 256;
-    hipLaunchKernelGGL(k_prior_prep, dim3(grid), dim3(256), 0, st, S, s, D, Lambda, eta, ST);
+    const int nt = (D + 15) / 16;
+    hipLaunchKernelGGL(k_prior_prep, dim3(nt + 1, nt), dim3(256), 0, st, S, s, D, Lambda, eta, ST);
     return hipGetLastError();
 }
 
