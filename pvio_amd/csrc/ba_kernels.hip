@@ -3268,10 +3268,10 @@ __global__ void k_quality(View v, int buf_from_ctrl, double *err_sum /* [2] opti
 
 // Lambda = S^T S, eta = S^T s of the marginalization prior (once per upload)
 // One workgroup = one 16 x 16 tile of Lambda (or, in the last tile column, sixteen entries of eta): the two column blocks of S it needs
-// go through LDS 128 rows at a time, coalesced, so that a thread's D-long sum reads LDS instead of making D / 15 dependent trips to L2
+// go through LDS 160 rows at a time, coalesced, so that a thread's D-long sum reads LDS instead of making D / 15 dependent trips to L2
 // (15 us per upload at D = 150, 94 us at D = 435 that way).  Every entry is still summed over the rows in ascending order.
 __global__ void __launch_bounds__(256) k_prior_prep(const double *S, const double *s, int D, double *Lambda, double *eta, double *ST) {
-    constexpr int kRows = 128;
+    constexpr int kRows = 160; // (one pass for the 150 x 150 prior of a ten-frame window; 40 KB of LDS)
     __shared__ double Sa[kRows][16], Sb[kRows][16];
     const int tid = threadIdx.x, i = tid >> 4, j = tid & 15;
     const int nt = (D + 15) >> 4, ta = blockIdx.y, tb = blockIdx.x; // tb == nt: the eta column

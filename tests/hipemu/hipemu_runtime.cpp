@@ -49,6 +49,9 @@ namespace {
 constexpr size_t kStack = 256 * 1024;
 struct Fiber {
     void *sp = nullptr; // saved stack pointer while the fiber is not running
+    // what the fiber waits for (the scheduler does not resume it before that has happened: a barrier of 256 fibers was 256 pointless
+    // switches per scheduler pass otherwise): the block barrier's / its wave exchange's generation it arrived in, -1 = runnable
+    int wait_bar_gen = -1, wait_wave_gen = -1;
     ThreadCtx tc;
     bool done = false;
     char *stack = nullptr;
@@ -105,7 +108,9 @@ void syncthreads() {
         ++bar_generation;
         ++g_sync_events;
     } else {
+        cur_fiber->wait_bar_gen = gen;
         while (bar_generation == gen) yield();
+        cur_fiber->wait_bar_gen = -1;
     }
 }
 
@@ -123,7 +128,9 @@ void wave_exchange(const void *in, void *out_all, size_t elem) {
         ++w.generation;
         ++g_sync_events;
     } else {
+        cur_fiber->wait_wave_gen = gen;
         while (w.generation == gen) yield();
+        cur_fiber->wait_wave_gen = -1;
     }
     std::memcpy(out_all, w.buf, 64 * elem);
     --w.readers;
@@ -168,6 +175,7 @@ void launch(dim3 grid, dim3 block, size_t shmem, Stream *s, std::function<void()
                     for (int t = 0; t < nt; ++t) {
                         Fiber &f = fibers[t];
                         f.done = false;
+                        f.wait_bar_gen = -1, f.wait_wave_gen = -1;
                         f.tc.tIdx = {(unsigned)(t % block.x), (unsigned)((t / block.x) % block.y), (unsigned)(t / (block.x * block.y))};
                         f.tc.bIdx = {bx, by, bz};
                         f.tc.bDim = block;
@@ -188,6 +196,8 @@ void launch(dim3 grid, dim3 block, size_t shmem, Stream *s, std::function<void()
                             const int t = g_order == 1 ? nt - 1 - tt : (g_order == 2 ? ((tt & 1) ? nt - 1 - (tt >> 1) : (tt >> 1)) : tt);
                             Fiber &f = fibers[t];
                             if (f.done) continue;
+                            if (f.wait_bar_gen >= 0 && f.wait_bar_gen == bar_generation) continue;               // still at the barrier
+                            if (f.wait_wave_gen >= 0 && f.wait_wave_gen == waves[f.tc.wave].generation) continue; // still in the exchange
                             cur_fiber = &f;
                             g_cur = &f.tc;
                             hipemu_switch(&sched_sp, &f.sp);
