@@ -9,7 +9,16 @@ import ba_compare
 from oracle import oracle_py as O
 from pvio_amd.solver import HipContext
 O.build()
-ctx = HipContext(device=0)
+# `sharded` as first argument: the same sweep through the landmark-sharded code path with a one-rank communicator (tests/test_gpu_ba.py shows how)
+SHARDED = len(sys.argv) > 1 and sys.argv[1] == "sharded"
+if SHARDED:
+    from pvio_amd import capi
+    import ctypes as C
+    ctx = HipContext(device=0, rank=0, world_size=1, force_sharded=True)
+    uid = (C.c_uint8 * 128)()
+    assert capi.load().pvio_hip_comm_unique_id(uid) == 0 and capi.load().pvio_hip_comm_init(ctx.ctx, uid, 0, 1) == 0
+else:
+    ctx = HipContext(device=0)
 bad = 0
 for seed in range(60):
     rng = np.random.default_rng(5000 + seed)
