@@ -36,7 +36,7 @@ def main():
     lib.hipemu_set_allreduce(allreduce)
     timeout = case.endswith("@timeout")  # a time limit that only ONE rank's clock exceeds (PVIO_HIP_DEBUG_TIMEOUT_RANK): nobody may hang
     case = case.split("@")[0]
-    pb = ba_compare.make(O, **ba_compare.CASES[case])
+    pb = ba_compare.make(O, **{**ba_compare.CASES, **ba_compare.BIG_CASES}[case])
     if timeout:
         pb.max_solver_time = 100.0  # a real-time style limit: the clock is looked at every two slots
     shard = pb.shard(rank, world)

@@ -17,10 +17,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # mode 2 = the matrix-core form of k_linearize (what sharded large windows run: bench.py's scaling_window leg)
 @pytest.mark.parametrize("case,world,mode", [("vio_plane", 2, 0), ("vision_partial", 3, 0), ("vio_partial", 2, 2),
                                              ("vio_partial", 4, 0), ("vio_partial", 8, 0), ("vio_13_frames_global_matrix", 2, 0),
-                                             ("vio_duplicate_blocks", 2, 2)])
+                                             ("vio_duplicate_blocks", 2, 2),
+                                             # round 3 (the emulator got fast enough): the metric window on four ranks, rejected steps /
+                                             # the bias quirk / rotation priors on shards, the 20-frame HBM-matrix window on three
+                                             ("metric_10x1000_vio", 4, 0), ("vio_zero_bias_quirk", 2, 0), ("config1_10x200", 3, 0),
+                                             ("vio_20_frames_panels", 3, 0), ("vio_rot_prior", 2, 0)])
 def test_sharded_solve_matches_oracle(oracle, case, world, mode):
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "hipemu"), "libpvio_hipemu.so"])
-    pb = ba_compare.make(oracle, **ba_compare.CASES[case])
+    pb = ba_compare.make(oracle, **{**ba_compare.CASES, **ba_compare.BIG_CASES}[case])
     st0, sm0 = BAState(pb), BASummary(pb)
     oracle.solve(pb, st0, sm0)
     with tempfile.TemporaryDirectory() as d:
