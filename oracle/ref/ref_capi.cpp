@@ -12,269 +12,19 @@
 // oracle/ref/{eigen,ceres}: ceres::Solve is a restatement (A8 stays unpinned), the rest of the arithmetic is the reference's
 // source text compiled as it is.
 #include <ceres/ceres.h>
-#include <pvio/common.h>
-#include <pvio/estimation/bundle_adjustor.h>
+#include "ref_window.h"
 #include <pvio/estimation/ceres/augmented_plane_distance_error_cost.h>
 #include <pvio/estimation/ceres/marginalization_error_cost.h>
 #include <pvio/estimation/ceres/preintegration_error_cost.h>
 #include <pvio/estimation/ceres/quaternion_parameterization.h>
 #include <pvio/estimation/ceres/reprojection_error_cost.h>
-#include <pvio/estimation/factor.h>
-#include <pvio/estimation/pnp.h>
-#include <pvio/estimation/preintegrator.h>
-#include <pvio/geometry/lie_algebra.h>
-#include <pvio/map/frame.h>
-#include <pvio/map/map.h>
-#include <pvio/map/plane.h>
-#include <pvio/map/track.h>
-
-#include <pvio_hip.h>
-
-#include <cstring>
+#include <pvio/utility/poisson_disk_filter.h>
 
 using namespace pvio;
 
-extern "C" {
-// Track table: every track of the map with ALL its observations (anchor first, ascending frame index) -- the layout of
-// oracle_post_passes (oracle/oracle_post.cpp).  in/out fields are updated by the calls like the reference updates its objects.
-typedef struct ref_tracks {
-    int32_t n_tracks;
-    int32_t n_planes;
-    const int32_t *obs_ptr;      /* [T+1] */
-    const int32_t *obs_frame;    /* [..]  */
-    const double *obs_z;         /* [..][2] normalized keypoints */
-    double *inv_depth;           /* [T] in/out: Track::landmark.inv_depth */
-    uint8_t *valid;              /* [T] in/out: TF_VALID */
-    uint8_t *plane;              /* [T] in/out: TF_PLANE */
-    const int64_t *life;         /* [T] Track::life */
-    const int32_t *best_plane;   /* [T] index of the plane landmark.plane_id names, -1 = nil */
-    double *quality;             /* [T] in/out: landmark.quality */
-    const double *plane_normal;  /* [P][3] */
-    const double *plane_distance;/* [P] */
-    uint8_t *membership;         /* [P][T] in/out: track in Plane::tracks */
-    int32_t pad_small_planes;    /* 0: planes are what `membership` says.  k > 0: planes with >= 1 member are padded with empty
-                                    tracks up to k members (the flat pvio_ba_problem lists plane FACTORS, i.e. tracks of planes the
-                                    reference found >= 20 tracks in: bundle_adjustor.cpp:180) */
-    int32_t reserved;
-    const uint8_t *keep_small;   /* [P] or NULL: 1 = this plane is NOT padded (a plane with < 20 tracks: its tracks get their reprojection
-                                    blocks a second time, bundle_adjustor.cpp:165-179) */
-} ref_tracks;
-
-// Raw IMU samples per frame (BundleAdjustorSolver::solve re-integrates them at :224): samples ptr[j] .. ptr[j+1]-1 lie between
-// frame j-1 and frame j.  NULL -> the pre-integrated blocks of the pvio_ba_problem are copied into Frame::preintegration and
-// `data` stays empty (marginalize_frame and the single-factor calls never integrate).
-typedef struct ref_imu {
-    const double *frame_t; /* [N] image timestamps */
-    const int32_t *ptr;    /* [N+1] */
-    const double *t;       /* [..] */
-    const double *w;       /* [..][3] */
-    const double *a;       /* [..][3] */
-    const pvio_imu_noise *noise;
-} ref_imu;
-}
+using namespace ref_window;
 
 namespace {
-
-struct DummyImage : public Image {
-    size_t width() const override { return 0; }
-    size_t height() const override { return 0; }
-    double evaluate(const vector<2> &, int) const override { return 0; }
-    double evaluate(const vector<2> &, vector<2> &, int) const override { return 0; }
-    void detect_keypoints(std::vector<vector<2>> &, size_t, double) const override {}
-    void track_keypoints(const Image *, const std::vector<vector<2>> &, std::vector<vector<2>> &, std::vector<char> &) const override {}
-};
-
-struct FlatConfig : public Config {
-    size_t max_iter = 10;
-    double max_time = 1.0e6, plane_cov = 1.0e-4;
-    matrix<3> camera_intrinsic() const override { return matrix<3>::Identity(); }
-    quaternion camera_to_body_rotation() const override { return quaternion::Identity(); }
-    vector<3> camera_to_body_translation() const override { return vector<3>::Zero(); }
-    quaternion imu_to_body_rotation() const override { return quaternion::Identity(); }
-    vector<3> imu_to_body_translation() const override { return vector<3>::Zero(); }
-    matrix<2> keypoint_noise_cov() const override { return matrix<2>::Identity(); }
-    matrix<3> gyroscope_noise_cov() const override { return matrix<3>::Identity(); }
-    matrix<3> accelerometer_noise_cov() const override { return matrix<3>::Identity(); }
-    matrix<3> gyroscope_bias_noise_cov() const override { return matrix<3>::Identity(); }
-    matrix<3> accelerometer_bias_noise_cov() const override { return matrix<3>::Identity(); }
-    double plane_distance_cov() const override { return plane_cov; }
-    size_t solver_iteration_limit() const override { return max_iter; }
-    double solver_time_limit() const override { return max_time; }
-};
-
-matrix<3> m3_rowmajor(const double *p) {
-    matrix<3> m;
-    for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j) m(i, j) = p[3 * i + j];
-    return m;
-}
-void set_state(Frame *f, const double *s) {
-    f->pose.q = quaternion(s[3], s[0], s[1], s[2]);
-    f->pose.p = vector<3>(s[4], s[5], s[6]);
-    f->motion.v = vector<3>(s[7], s[8], s[9]);
-    f->motion.bg = vector<3>(s[10], s[11], s[12]);
-    f->motion.ba = vector<3>(s[13], s[14], s[15]);
-}
-void get_state(const Frame *f, double *s) {
-    s[0] = f->pose.q.x(), s[1] = f->pose.q.y(), s[2] = f->pose.q.z(), s[3] = f->pose.q.w();
-    for (int k = 0; k < 3; ++k) s[4 + k] = f->pose.p(k), s[7 + k] = f->motion.v(k), s[10 + k] = f->motion.bg(k), s[13 + k] = f->motion.ba(k);
-}
-ExtrinsicParams ext(const double *e) {
-    ExtrinsicParams x;
-    x.q_cs = quaternion(e[3], e[0], e[1], e[2]);
-    x.p_cs = vector<3>(e[4], e[5], e[6]);
-    return x;
-}
-
-// The reference's object graph of one window.
-struct Window {
-    std::unique_ptr<Map> map = std::make_unique<Map>();
-    std::vector<Frame *> frames;
-    std::vector<Track *> tracks;   // table order
-    std::vector<Plane *> planes;   // table order
-    std::vector<size_t> plane_ids; // Plane::id() per table index (planes may be erased by the reference)
-    FlatConfig config;
-
-    Frame *add_frame(const double *state, const double *cam, const double *imu, const double *W, const double *K4, double t, bool fixed) {
-        std::unique_ptr<Frame> f = std::make_unique<Frame>();
-        f->K = matrix<3>::Identity();
-        if (K4) f->K(0, 0) = K4[0], f->K(1, 1) = K4[1], f->K(0, 2) = K4[2], f->K(1, 2) = K4[3];
-        f->sqrt_inv_cov(0, 0) = W[0], f->sqrt_inv_cov(0, 1) = W[1], f->sqrt_inv_cov(1, 0) = W[2], f->sqrt_inv_cov(1, 1) = W[3];
-        auto img = std::make_shared<DummyImage>();
-        img->t = t;
-        f->image = img;
-        set_state(f.get(), state);
-        f->camera = ext(cam), f->imu = ext(imu);
-        f->preintegration.reset();
-        f->preintegration.cov_w.setZero(), f->preintegration.cov_a.setZero(), f->preintegration.cov_bg.setZero(), f->preintegration.cov_ba.setZero();
-        f->flag(FrameFlag::FF_FIX_POSE) = fixed;
-        Frame *raw = f.get();
-        map->put_frame(std::move(f));
-        frames.push_back(raw);
-        return raw;
-    }
-    void set_preintegration(int j, const double *delta, const double *U, const double *jac) {
-        PreIntegrator &pre = frames[j]->preintegration;
-        pre.delta.t = delta[0];
-        pre.delta.q = quaternion(delta[4], delta[1], delta[2], delta[3]);
-        pre.delta.p = vector<3>(delta[5], delta[6], delta[7]);
-        pre.delta.v = vector<3>(delta[8], delta[9], delta[10]);
-        for (int a = 0; a < 15; ++a)
-            for (int b = 0; b < 15; ++b) pre.delta.sqrt_inv_cov(a, b) = U[15 * a + b];
-        pre.jacobian.dq_dbg = m3_rowmajor(jac), pre.jacobian.dp_dbg = m3_rowmajor(jac + 9), pre.jacobian.dp_dba = m3_rowmajor(jac + 18);
-        pre.jacobian.dv_dbg = m3_rowmajor(jac + 27), pre.jacobian.dv_dba = m3_rowmajor(jac + 36);
-    }
-    void set_imu(int j, int n, const double *t, const double *w, const double *a, const pvio_imu_noise *nz) {
-        PreIntegrator &pre = frames[j]->preintegration;
-        pre.cov_w = m3_rowmajor(nz->cov_w), pre.cov_a = m3_rowmajor(nz->cov_a), pre.cov_bg = m3_rowmajor(nz->cov_bg), pre.cov_ba = m3_rowmajor(nz->cov_ba);
-        pre.data.clear();
-        for (int k = 0; k < n; ++k) {
-            ImuData d;
-            d.t = t[k], d.w = vector<3>(w[3 * k], w[3 * k + 1], w[3 * k + 2]), d.a = vector<3>(a[3 * k], a[3 * k + 1], a[3 * k + 2]);
-            pre.data.push_back(d);
-        }
-    }
-    Track *add_track(int n_obs, const int32_t *obs_frame, const double *obs_z) {
-        Track *t = map->create_track();
-        for (int k = 0; k < n_obs; ++k) {
-            Frame *f = frames[obs_frame[k]];
-            const size_t idx = f->keypoint_num();
-            f->append_keypoint(vector<2>(obs_z[2 * k], obs_z[2 * k + 1]));
-            t->add_keypoint(f, idx); // Frame::tracks / reprojection factor / Track::keypoint_refs (track.cpp:35-40)
-        }
-        tracks.push_back(t);
-        return t;
-    }
-    void set_prior(int n, const int32_t *pframes, const double *S, const double *s, const double *lin) {
-        if (n <= 0) return;
-        std::vector<Frame *> rel;
-        std::vector<double> keep((size_t)16 * n);
-        for (int i = 0; i < n; ++i) {
-            Frame *f = frames[pframes[i]];
-            get_state(f, &keep[(size_t)16 * i]);
-            set_state(f, lin + 16 * i); // the constructor captures pose_0 / motion_0 from the frames (marginalization_error_cost.h:45-46)
-            rel.push_back(f);
-        }
-        matrix<> Sm;
-        vector<> sv;
-        Sm.resize(15 * n, 15 * n), sv.resize(15 * n);
-        for (int a = 0; a < 15 * n; ++a) {
-            sv(a) = s[a];
-            for (int b = 0; b < 15 * n; ++b) Sm(a, b) = S[(size_t)a * 15 * n + b];
-        }
-        map->set_marginalization_factor(Factor::create_marginalization_error(Sm, sv, std::move(rel)));
-        for (int i = 0; i < n; ++i) set_state(frames[pframes[i]], &keep[(size_t)16 * i]);
-    }
-};
-
-int build_window(Window &W, const pvio_ba_problem *pb, const double *frame_state, const ref_tracks *trk, const ref_imu *imu) {
-    if (pb->n_rot_priors > 0) return PVIO_ERR_UNSUPPORTED; // RotationPriorFactor has no reference counterpart
-    const int N = pb->n_frames;
-    for (int i = 0; i < N; ++i)
-        W.add_frame(frame_state + 16 * i, pb->cam_extrinsic + 7 * i, pb->imu_extrinsic + 7 * i, pb->sqrt_inv_cov + 4 * i, pb->intrinsics ? pb->intrinsics + 4 * i : nullptr,
-                    imu ? imu->frame_t[i] : double(i), pb->frame_fixed && pb->frame_fixed[i]);
-    for (int j = 1; j < N; ++j) {
-        if (imu) {
-            const int b = imu->ptr[j], e = imu->ptr[j + 1];
-            if (e > b) W.set_imu(j, e - b, imu->t + b, imu->w + 3 * b, imu->a + 3 * b, imu->noise);
-        } else if (pb->preint_valid && pb->preint_valid[j]) {
-            W.set_preintegration(j, pb->preint_delta + 11 * j, pb->preint_sqrt_inv_cov + 225 * j, pb->preint_jacobian + 45 * j);
-        }
-    }
-    if (trk) {
-        const int T = trk->n_tracks, P = trk->n_planes;
-        for (int p = 0; p < P; ++p) {
-            std::unique_ptr<Plane> pl = std::make_unique<Plane>();
-            pl->parameter.normal = vector<3>(trk->plane_normal[3 * p], trk->plane_normal[3 * p + 1], trk->plane_normal[3 * p + 2]);
-            pl->parameter.distance = trk->plane_distance[p];
-            pl->parameter.reference_point = pl->parameter.normal * pl->parameter.distance;
-            W.planes.push_back(pl.get());
-            W.plane_ids.push_back(pl->id());
-            W.map->put_plane(std::move(pl)); // no tracks yet: nothing overlaps, nothing merges (map.cpp:140-160)
-        }
-        for (int t = 0; t < T; ++t) {
-            const int b = trk->obs_ptr[t], e = trk->obs_ptr[t + 1];
-            Track *tr = W.add_track(e - b, trk->obs_frame + b, trk->obs_z + 2 * b);
-            tr->landmark.inv_depth = trk->inv_depth[t];
-            tr->landmark.quality = trk->quality ? trk->quality[t] : 0.0;
-            tr->flag(TrackFlag::TF_VALID) = trk->valid[t] != 0;
-            tr->flag(TrackFlag::TF_PLANE) = trk->plane[t] != 0;
-            tr->life = trk->life ? (size_t)trk->life[t] : (size_t)(e - b);
-            if (trk->best_plane && trk->best_plane[t] >= 0) tr->landmark.plane_id = W.plane_ids[trk->best_plane[t]];
-        }
-        for (int p = 0; p < P; ++p) {
-            size_t members = 0;
-            for (int t = 0; t < T; ++t)
-                if (trk->membership[(size_t)p * T + t]) W.planes[p]->tracks.insert(W.tracks[t]), ++members;
-            if (trk->keep_small && trk->keep_small[p]) continue;
-            for (; members > 0 && members < (size_t)trk->pad_small_planes; ++members) W.planes[p]->tracks.insert(W.map->create_track());
-        }
-    }
-    W.set_prior(pb->prior_n, pb->prior_frames, pb->prior_S, pb->prior_s, pb->prior_lin_state);
-    W.config.max_iter = (size_t)pb->max_iterations;
-    W.config.max_time = pb->max_solver_time > 0 ? pb->max_solver_time : 1.0e6;
-    if (pb->plane_sqrt_inv_cov > 0) W.config.plane_cov = 1.0 / (pb->plane_sqrt_inv_cov * pb->plane_sqrt_inv_cov);
-    return PVIO_OK;
-}
-
-void read_back(const Window &W, double *frame_state, ref_tracks *trk) {
-    for (size_t i = 0; i < W.frames.size(); ++i) get_state(W.frames[i], frame_state + 16 * i);
-    if (!trk) return;
-    const int T = trk->n_tracks, P = trk->n_planes;
-    for (int t = 0; t < T; ++t) {
-        const Track *tr = W.tracks[t];
-        trk->inv_depth[t] = tr->landmark.inv_depth;
-        trk->valid[t] = tr->flag(TrackFlag::TF_VALID) ? 1 : 0;
-        trk->plane[t] = tr->flag(TrackFlag::TF_PLANE) ? 1 : 0;
-        if (trk->quality) trk->quality[t] = tr->landmark.quality;
-    }
-    for (int p = 0; p < P; ++p) {
-        Plane *pl = nullptr;
-        for (size_t k = 0; k < W.map->plane_num(); ++k)
-            if (W.map->get_plane(k)->id() == W.plane_ids[p]) pl = W.map->get_plane(k);
-        for (int t = 0; t < T; ++t) trk->membership[(size_t)p * T + t] = (pl && pl->tracks.count(W.tracks[t])) ? 1 : 0;
-    }
-}
 
 // local (tangent) Jacobian of a q block: J_global (rows x 4, row-major) * QuaternionParameterization::ComputeJacobian (4 x 3)
 void q_local(const double *q, const double *Jg, int rows, double *out /* rows x 3 */, int out_stride) {
@@ -561,6 +311,12 @@ int32_t ref_ba_marginalize(const pvio_ba_problem *pb, const double *frame_state,
     return PVIO_OK;
 }
 
+// the keyframe cycle (ref_window.h: Map::marginalize_frame + solve on one Map), the reference's code behind both calls
+int32_t ref_marginalize_then_solve(const pvio_ba_problem *pb, const double *frame_state, ref_tracks *trk, const ref_imu *imu, int32_t victim, double *out_state,
+                                   int32_t *usable) {
+    return cycle_marginalize_then_solve(pb, frame_state, trk, imu, victim, out_state, usable);
+}
+
 // BundleAdjustor::compute_reprojection_error (bundle_adjustor.cpp:321-336)
 int32_t ref_ba_reprojection_error(const pvio_ba_problem *pb, const double *frame_state, ref_tracks *trk, double *out) {
     Window W;
@@ -600,4 +356,111 @@ int32_t ref_pnp(const pvio_ba_problem *pb, const double *frame_state, ref_tracks
     return PVIO_OK;
 }
 
+
+// ---- K3 / K5 of SURVEY.md section 8: Frame::track_keypoints (map/frame.cpp:89-139) and PoissonDiskFilter<2> (utility/poisson_disk_filter.h:25-130),
+// the reference's own, behind the signatures of the oracle's restatement (oracle/oracle_front.cpp) and the product's (pvio_amd/host/feature_front.cpp,
+// tests/host/front_shim.cpp) so that tests/test_host_frontend.py holds all three against each other. ----
+
+// PoissonDiskFilter<2>: presets (preset_point, :40-44) then candidates in order (permit_point + preset_point = what frame.cpp:123-129 does;
+// insert_point of :56-63 is the same two steps)
+void ref_poisson_insert(double radius, int n_preset, const double *preset_xy, int n, const double *xy, uint8_t *accepted) {
+    PoissonDiskFilter<2> filter(radius);
+    for (int i = 0; i < n_preset; ++i) filter.preset_point(vector<2>(preset_xy[2 * i], preset_xy[2 * i + 1]));
+    for (int i = 0; i < n; ++i) accepted[i] = filter.insert_point(vector<2>(xy[2 * i], xy[2 * i + 1])) ? 1 : 0;
+}
+}
+
+namespace {
+struct ScriptedImage : public DummyImage { // plays back a given LK result; remembers the initial guess it was handed
+    std::vector<vector<2>> result, guess;
+    std::vector<char> result_status;
+    void track_keypoints(const Image *, const std::vector<vector<2>> &curr, std::vector<vector<2>> &next, std::vector<char> &status) const override {
+        const_cast<ScriptedImage *>(this)->guess = next;
+        next.resize(curr.size());
+        status.assign(curr.size(), 0);
+        for (size_t i = 0; i < curr.size() && i < result.size(); ++i) next[i] = result[i], status[i] = result_status[i];
+    }
+};
+struct FrontConfig : public FlatConfig {
+    double distance = 20.0;
+    bool predict = false;
+    double feature_tracker_min_keypoint_distance() const override { return distance; }
+    bool feature_tracker_predict_keypoints() const override { return predict; }
+};
+// a feature-tracking map whose LAST frame has n keypoints, keypoint i on a track of track_length[i] observations (0: no track)
+struct FrontWindow {
+    Window W;
+    Frame *curr = nullptr;
+    std::shared_ptr<ScriptedImage> image = std::make_shared<ScriptedImage>();
+    FrontWindow(int n, const double *kp_xy, const uint64_t *track_length, const double *K4, const double *cam, const double *imu) {
+        uint64_t longest = 1;
+        for (int i = 0; i < n; ++i) longest = std::max<uint64_t>(longest, track_length ? track_length[i] : 0);
+        longest = std::min<uint64_t>(longest, 64); // the order only depends on the lengths' ORDER: lengths above 64 are capped by the caller
+        const double st[16] = {0, 0, 0, 1};
+        for (uint64_t f = 0; f < longest; ++f) W.add_frame(st, cam ? cam : kId7, imu ? imu : kId7, kW2, K4, double(f), false);
+        curr = W.frames.back();
+        curr->image = image;
+        for (int i = 0; i < n; ++i) {
+            const size_t idx = curr->keypoint_num();
+            curr->append_keypoint(vector<2>(kp_xy[2 * i], kp_xy[2 * i + 1]));
+            const uint64_t len = track_length ? track_length[i] : 1;
+            if (len == 0) continue;
+            Track *t = W.map->create_track();
+            for (uint64_t f = longest - len; f + 1 < longest; ++f) { // earlier observations, oldest first
+                Frame *fr = W.frames[f];
+                const size_t k = fr->keypoint_num();
+                fr->append_keypoint(vector<2>(0.0, 0.0));
+                t->add_keypoint(fr, k);
+            }
+            t->add_keypoint(curr, idx);
+        }
+    }
+};
+} // namespace
+
+extern "C" {
+// Frame::track_keypoints :108-130 -- survivors of the LK call sorted by track length (std::sort), Poisson-disk acceptance in that order.
+// next_xy: pixels (K = identity here); track_length[i] = 0: keypoint without a track; lengths must be <= 64 (ties and order are what matters).
+void ref_select_tracked(int n, const double *next_xy, const uint64_t *track_length, double min_distance, uint8_t *status) {
+    if (n <= 0) return;
+    std::vector<double> zeros(2 * (size_t)n, 0.0);
+    FrontWindow F(n, zeros.data(), track_length, nullptr, nullptr, nullptr);
+    FrontConfig cfg;
+    cfg.distance = min_distance, cfg.predict = false;
+    F.image->result.resize((size_t)n), F.image->result_status.resize((size_t)n);
+    for (int i = 0; i < n; ++i) F.image->result[(size_t)i] = vector<2>(next_xy[2 * i], next_xy[2 * i + 1]), F.image->result_status[(size_t)i] = (char)status[i];
+    std::unique_ptr<Frame> next = std::make_unique<Frame>();
+    next->K = matrix<3>::Identity();
+    next->image = std::make_shared<DummyImage>();
+    next->preintegration.reset();
+    F.curr->track_keypoints(next.get(), &cfg);
+    // which keypoints went on: those whose track (or, for a trackless keypoint, a new track) now has an observation in `next`
+    for (int i = 0; i < n; ++i) {
+        Track *t = F.curr->get_track((size_t)i);
+        const bool kept = t && t->has_keypoint(next.get());
+        // a trackless keypoint whose LK status was 1 is appended as well (:132-137 create_if_empty): oracle_select_tracked / select_tracked leave its status alone
+        status[i] = kept ? 1 : 0;
+    }
+    for (int i = 0; i < n; ++i)
+        if (Track *t = F.curr->get_track((size_t)i); t && t->has_keypoint(next.get())) t->remove_keypoint(next.get(), false); // `next` dies before the map
+}
+
+// Frame::track_keypoints :97-103 -- the gyro-only prediction handed to Image::track_keypoints as the initial guess (pixels of the next frame)
+void ref_predict_keypoints(const double q_cam_i[4], const double q_imu_i[4], const double dq[4], const double q_imu_j[4], const double q_cam_j[4],
+                           const double K_next[4], int n, const double *kp_xy, double *out_xy) {
+    if (n <= 0) return;
+    double cam_i[7] = {q_cam_i[0], q_cam_i[1], q_cam_i[2], q_cam_i[3], 0, 0, 0}, imu_i[7] = {q_imu_i[0], q_imu_i[1], q_imu_i[2], q_imu_i[3], 0, 0, 0};
+    FrontWindow F(n, kp_xy, nullptr, K_next, cam_i, imu_i);
+    FrontConfig cfg;
+    cfg.predict = true;
+    std::unique_ptr<Frame> next = std::make_unique<Frame>();
+    next->K = matrix<3>::Identity();
+    next->K(0, 0) = K_next[0], next->K(1, 1) = K_next[1], next->K(0, 2) = K_next[2], next->K(1, 2) = K_next[3];
+    next->image = std::make_shared<DummyImage>();
+    next->camera.q_cs = quaternion(q_cam_j[3], q_cam_j[0], q_cam_j[1], q_cam_j[2]), next->imu.q_cs = quaternion(q_imu_j[3], q_imu_j[0], q_imu_j[1], q_imu_j[2]);
+    next->preintegration.reset();
+    next->preintegration.delta.q = quaternion(dq[3], dq[0], dq[1], dq[2]);
+    F.curr->track_keypoints(next.get(), &cfg); // the scripted image reports every track lost: nothing is appended
+    for (int i = 0; i < n; ++i) out_xy[2 * i] = F.image->guess[(size_t)i][0], out_xy[2 * i + 1] = F.image->guess[(size_t)i][1];
+}
 } // extern "C"

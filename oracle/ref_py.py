@@ -68,12 +68,8 @@ def lib():
         L.ref_eval_prior.restype = None
         L.ref_eval_plane.argtypes = [C.c_int32, dp, dp, dp, dp, C.c_double, C.c_double, dp, dp]
         L.ref_eval_plane.restype = None
-        L.ref_ba_solve.argtypes = [C.POINTER(capi.BAProblemC), dp, C.POINTER(RefTracksC), C.POINTER(RefImuC), C.POINTER(capi.BASummaryC)]
-        L.ref_ba_marginalize.argtypes = [C.POINTER(capi.BAProblemC), dp, C.POINTER(RefTracksC), C.POINTER(RefImuC), C.c_int32, C.POINTER(capi.BAPriorC)]
-        L.ref_ba_reprojection_error.argtypes = [C.POINTER(capi.BAProblemC), dp, C.POINTER(RefTracksC), dp]
         L.ref_fault_injection.argtypes = [C.c_int32, C.c_int32]
         L.ref_fault_injection.restype = None
-        L.ref_pnp.argtypes = [C.POINTER(capi.BAProblemC), dp, C.POINTER(RefTracksC), dp, dp, dp, dp, dp, C.c_int32, i32p, dp, dp, dp, dp, C.c_int32, i32p]
     return _lib
 
 
@@ -207,69 +203,143 @@ def imu_of_problem(pb, kf_dt=0.25):
     return c, keep
 
 
+class Harness:
+    """The window-level entry points of one of the two libraries oracle/ref/Makefile builds on the reference's REAL object graph:
+    libpvio_ref.so (prefix ref_: the reference's own BundleAdjustor / visual_inertial_pnp) or libpvio_dropin[_emu].so (prefix dropin_: the
+    product's pvio_amd/host adapter linked in their place above the HIP C ABI / the kernel emulator).  Same flat layout on both sides."""
+
+    def __init__(self, L, prefix):
+        self.L, self.prefix = L, prefix
+        f = lambda n: getattr(L, prefix + n)  # noqa: E731
+        f("ba_solve").argtypes = [C.POINTER(capi.BAProblemC), dp, C.POINTER(RefTracksC), C.POINTER(RefImuC), C.POINTER(capi.BASummaryC)]
+        f("ba_marginalize").argtypes = [C.POINTER(capi.BAProblemC), dp, C.POINTER(RefTracksC), C.POINTER(RefImuC), C.c_int32, C.POINTER(capi.BAPriorC)]
+        f("ba_reprojection_error").argtypes = [C.POINTER(capi.BAProblemC), dp, C.POINTER(RefTracksC), dp]
+        f("marginalize_then_solve").argtypes = [C.POINTER(capi.BAProblemC), dp, C.POINTER(RefTracksC), C.POINTER(RefImuC), C.c_int32, dp, i32p]
+        f("pnp").argtypes = [C.POINTER(capi.BAProblemC), dp, C.POINTER(RefTracksC), dp, dp, dp, dp, dp, C.c_int32, i32p, dp, dp, dp, dp, C.c_int32, i32p]
+        self._f = f
+
+    def solve(self, pb, tracks=None, use_raw_imu=True, trace=True):
+        """BundleAdjustor::solve on the window `pb` describes.  Returns (frame_state, Tracks, summary)."""
+        from pvio_amd.problem import BASummary
+        if tracks is None:
+            tracks, _ = tracks_of_problem(pb)
+        pbc = pb.as_c()
+        fs = f64(pb.frame_state).copy()
+        tc = tracks.as_c()
+        imu_c, keep = (None, None)
+        if pb.use_inertial:
+            assert use_raw_imu and "imu" in pb.meta, "solve() re-integrates the raw IMU samples (bundle_adjustor.cpp:224)"
+            imu_c, keep = imu_of_problem(pb)
+        T = len(tracks.ptr) - 1
+
+        class _Shape:  # BASummary sizes its trace buffer from these
+            max_iterations = pb.max_iterations
+
+            @staticmethod
+            def state_dim():
+                return pb.n_frames * 16 + T
+        sm = BASummary(_Shape, trace=trace)
+        rc = self._f("ba_solve")(C.byref(pbc), _d(fs), C.byref(tc), C.byref(imu_c) if imu_c is not None else None, C.byref(sm.c))
+        assert rc == 0, rc
+        return fs, tracks, sm
+
+    def marginalize(self, pb, frame_state, tracks, victim):
+        """BundleAdjustor::marginalize_frame; the pre-integration blocks are the ones in `pb` (what the last solve integrated)."""
+        pbc = pb.as_c()
+        fs = f64(frame_state)
+        tc = tracks.as_c()
+        n = pb.n_frames - 1
+        S, s = np.zeros((15 * n, 15 * n)), np.zeros(15 * n)
+        IM, iv = np.zeros((15 * n, 15 * n)), np.zeros(15 * n)
+        pr = capi.BAPriorC()
+        pr.S, pr.s, pr.info_matrix, pr.info_vector = _d(S), _d(s), _d(IM), _d(iv)
+        rc = self._f("ba_marginalize")(C.byref(pbc), _d(fs), C.byref(tc), None, int(victim), C.byref(pr))
+        assert rc == 0, rc
+        return S, s, IM, iv
+
+    def marginalize_then_solve(self, pb, frame_state, tracks, victim):
+        """The keyframe cycle on ONE Map: Map::marginalize_frame(victim) (map.cpp:73-88) then BundleAdjustor::solve of the N - 1 frames left,
+        the new prior included (sliding_window_tracker.cpp:91-113).  Returns (states [(N-1)][16], usable); `tracks` is updated in place."""
+        pbc = pb.as_c()
+        fs = f64(frame_state)
+        tc = tracks.as_c()
+        imu_c, keep = (None, None)
+        if pb.use_inertial:
+            imu_c, keep = imu_of_problem(pb)
+        out = np.zeros((pb.n_frames - 1, 16))
+        usable = C.c_int32(0)
+        rc = self._f("marginalize_then_solve")(C.byref(pbc), _d(fs), C.byref(tc), C.byref(imu_c) if imu_c is not None else None, int(victim), _d(out), C.byref(usable))
+        assert rc == 0, rc
+        return out, bool(usable.value)
+
+    def reprojection_error(self, pb, frame_state, tracks):
+        pbc = pb.as_c()
+        fs = f64(frame_state)
+        tc = tracks.as_c()
+        out = np.zeros(1)
+        rc = self._f("ba_reprojection_error")(C.byref(pbc), _d(fs), C.byref(tc), _d(out))
+        assert rc == 0
+        return out[0]
+
+    def pnp(self, pb_window, frame_state, tracks, new_state, new_cam, new_imu, new_W, new_K, obs_track, obs_z, delta=None, U=None, jac=None, use_inertial=False):
+        """visual_inertial_pnp (pnp.cpp:32-100) of a NEW frame against the window; returns (state16, iterations)"""
+        pbc = pb_window.as_c()
+        fs = f64(frame_state)
+        tc = tracks.as_c()
+        x = f64(new_state).copy()
+        ot = np.ascontiguousarray(obs_track, np.int32)
+        oz = f64(obs_z).reshape(-1, 2)
+        z = np.zeros(225)
+        it = C.c_int32(0)
+        rc = self._f("pnp")(C.byref(pbc), _d(fs), C.byref(tc), _d(x), _d(f64(new_cam)), _d(f64(new_imu)), _d(f64(new_W)), _d(f64(new_K)), len(ot),
+                            ot.ctypes.data_as(i32p), _d(oz), _d(f64(delta) if delta is not None else z), _d(f64(U) if U is not None else z),
+                            _d(f64(jac) if jac is not None else z), 1 if use_inertial else 0, C.byref(it))
+        assert rc == 0, rc
+        return x, it.value
+
+
+_ref_harness = None
+
+
+def reference():
+    """the reference's own code (libpvio_ref.so)"""
+    global _ref_harness
+    if _ref_harness is None:
+        _ref_harness = Harness(lib(), "ref_")
+    return _ref_harness
+
+
+DROPIN_LIB = {"gpu": os.path.join(HERE, "_ref", "libpvio_dropin.so"), "emu": os.path.join(HERE, "_ref", "libpvio_dropin_emu.so")}
+_dropin = {}
+
+
+def build_dropin():
+    if os.path.isdir(os.path.join(REF, "pvio", "src")):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "ref"), "REF=" + REF, "dropin"])
+    return all(os.path.exists(p) for p in DROPIN_LIB.values())
+
+
+def dropin(kind):
+    """the PRODUCT's host adapter on the reference's Map: kind = "gpu" (libpvio_hip.so below it; needs a GPU: the adapter reports every solve
+    as unusable without one) or "emu" (the kernel sources in the fiber emulator).  One GPU context per process (process_ctx())."""
+    if kind not in _dropin:
+        if not build_dropin():
+            raise RuntimeError("oracle/_ref/libpvio_dropin*.so are not built and %s is absent" % REF)
+        _dropin[kind] = Harness(C.CDLL(DROPIN_LIB[kind]), "dropin_")
+    return _dropin[kind]
+
+
 def solve(pb, tracks=None, use_raw_imu=True, trace=True):
-    """BundleAdjustor::solve of the reference on the window `pb` describes.  Returns (frame_state, Tracks, summary dict)."""
-    from pvio_amd.problem import BASummary
-    if tracks is None:
-        tracks, _ = tracks_of_problem(pb)
-    pbc = pb.as_c()
-    fs = f64(pb.frame_state).copy()
-    tc = tracks.as_c()
-    imu_c, keep = (None, None)
-    if pb.use_inertial:
-        assert use_raw_imu and "imu" in pb.meta, "solve() re-integrates the raw IMU samples (bundle_adjustor.cpp:224)"
-        imu_c, keep = imu_of_problem(pb)
-    T = len(tracks.ptr) - 1
-
-    class _Shape:  # BASummary sizes its trace buffer from these
-        max_iterations = pb.max_iterations
-
-        @staticmethod
-        def state_dim():
-            return pb.n_frames * 16 + T
-    sm = BASummary(_Shape, trace=trace)
-    rc = lib().ref_ba_solve(C.byref(pbc), _d(fs), C.byref(tc), C.byref(imu_c) if imu_c is not None else None, C.byref(sm.c))
-    assert rc == 0, rc
-    return fs, tracks, sm
+    return reference().solve(pb, tracks, use_raw_imu, trace)
 
 
 def marginalize(pb, frame_state, tracks, victim):
-    """BundleAdjustor::marginalize_frame; the pre-integration blocks are the ones in `pb` (what the last solve integrated)."""
-    pbc = pb.as_c()
-    fs = f64(frame_state)
-    tc = tracks.as_c()
-    n = pb.n_frames - 1
-    S, s = np.zeros((15 * n, 15 * n)), np.zeros(15 * n)
-    IM, iv = np.zeros((15 * n, 15 * n)), np.zeros(15 * n)
-    pr = capi.BAPriorC()
-    pr.S, pr.s, pr.info_matrix, pr.info_vector = _d(S), _d(s), _d(IM), _d(iv)
-    rc = lib().ref_ba_marginalize(C.byref(pbc), _d(fs), C.byref(tc), None, int(victim), C.byref(pr))
-    assert rc == 0, rc
-    return S, s, IM, iv
+    return reference().marginalize(pb, frame_state, tracks, victim)
 
 
 def reprojection_error(pb, frame_state, tracks):
-    pbc = pb.as_c()
-    fs = f64(frame_state)
-    tc = tracks.as_c()
-    out = np.zeros(1)
-    rc = lib().ref_ba_reprojection_error(C.byref(pbc), _d(fs), C.byref(tc), _d(out))
-    assert rc == 0
-    return out[0]
+    return reference().reprojection_error(pb, frame_state, tracks)
 
 
-def pnp(pb_window, frame_state, tracks, new_state, new_cam, new_imu, new_W, new_K, obs_track, obs_z, delta=None, U=None, jac=None, use_inertial=False):
-    """visual_inertial_pnp (pnp.cpp:32-100) of a NEW frame against the window; returns (state16, iterations)"""
-    pbc = pb_window.as_c()
-    fs = f64(frame_state)
-    tc = tracks.as_c()
-    x = f64(new_state).copy()
-    ot = np.ascontiguousarray(obs_track, np.int32)
-    oz = f64(obs_z).reshape(-1, 2)
-    z = np.zeros(225)
-    it = C.c_int32(0)
-    rc = lib().ref_pnp(C.byref(pbc), _d(fs), C.byref(tc), _d(x), _d(f64(new_cam)), _d(f64(new_imu)), _d(f64(new_W)), _d(f64(new_K)), len(ot),
-                       ot.ctypes.data_as(i32p), _d(oz), _d(f64(delta) if delta is not None else z), _d(f64(U) if U is not None else z),
-                       _d(f64(jac) if jac is not None else z), 1 if use_inertial else 0, C.byref(it))
-    assert rc == 0, rc
-    return x, it.value
+def pnp(*a, **kw):
+    return reference().pnp(*a, **kw)

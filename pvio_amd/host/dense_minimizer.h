@@ -10,6 +10,7 @@
 // gradient tolerances 1e-6 / 1e-8 / 1e-10 (the tolerance exits drop the candidate), five consecutive invalid steps =
 // failure, the best accepted point is returned.
 #pragma once
+#include "host_namespace.h"
 #include <algorithm>
 #include <cfloat>
 #include <cmath>

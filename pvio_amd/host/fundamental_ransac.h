@@ -11,6 +11,7 @@
 //     log(1 - confidence) / log(1 - (1 - eps)^7), capped at 1000.
 // Host code (a few hundred points, a few hundred samples): SURVEY.md section 8f row 2.
 #pragma once
+#include "host_namespace.h"
 #include <cstdint>
 #include <vector>
 

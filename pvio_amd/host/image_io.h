@@ -6,6 +6,7 @@
 // 0.587): (9798 r + 19235 g + 3735 b + 16384) >> 15, r = g = b passing through (the datasets themselves are gray).
 // PGM (P5, maxval <= 255) is read too.  Failures throw std::runtime_error: there is no silent fallback.
 #pragma once
+#include "host_namespace.h"
 #include <cstdint>
 #include <string>
 #include <vector>

@@ -8,6 +8,7 @@
 // rows: not worth a kernel; it runs on the host with the same factor code the kernels use
 // (pvio_amd/csrc/pv_factors.h compiles for the host) and the dense trust-region loop of dense_minimizer.h.
 #pragma once
+#include "host_namespace.h"
 #include <vector>
 
 #include "dense_minimizer.h"

@@ -1,7 +1,9 @@
 """Runs ONE chain (tests/host/libpvio_chain_*.so) over the rendered sequence of tests/test_host_headless.py in its own process (track
 and frame ids come from process-wide counters; the emulated and the real kernels cannot share a process) and leaves the record stream of
 tests/host/chain_log.h plus the reported trajectory in TUM format.
-usage: python tests/chain_run.py <library> <out prefix> <n_frames> <window> <gap> <distance> <small|full>"""
+usage: python tests/chain_run.py <library> <out prefix> <n_frames> <window> <gap> <distance> <small|full>
+(the libraries of oracle/ref/Makefile export the same entry point: the reference's own pvio::PVIO over the sequence, oracle/ref/seq_capi.cpp;
+PVIO_SEQ_IMAGE=oracle|hip picks their pvio::Image)"""
 import ctypes as C
 import os
 import sys

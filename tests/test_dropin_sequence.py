@@ -1,0 +1,100 @@
+"""The drop-in over a SEQUENCE, inside the reference's own pipeline: `pvio::PVIO` (pvio/include/pvio/pvio.h:135-148) -- the object pvio-pc's main
+loop drives -- compiled from the reference's unedited sources (pvio.cpp, core/{core,feature_tracker,frontend_worker,sliding_window_tracker,
+plane_extractor}.cpp, map/*.cpp, estimation/{factor,preintegrator}.cpp; oracle/ref/Makefile) and run over the rendered sequence of
+test_host_headless.py twice:
+
+  libpvio_ref.so           ... with the reference's own estimation/bundle_adjustor.cpp + pnp.cpp (mini-Ceres below them)
+  libpvio_dropin[_emu].so  ... with the PRODUCT's pvio_amd/host/{bundle_adjustor,pnp,pnp_solve}.cpp linked in their place, above libpvio_hip.so
+                               (the kernel emulator in the CPU suite); with PVIO_SEQ_IMAGE=hip the pvio::Image is the product's HipImage as well
+
+Everything between PVIO::track_camera and the hot path is the reference's: IMU pairing, FeatureTracker::work, Frame::track_keypoints /
+detect_keypoints, FrontendWorker::work, SlidingWindowTracker::track (PnP, keyframe check, Map::marginalize_frame, plane extraction and casting,
+solve, pruning).  The one substitution is the SfM initializer (out of scope, beyond the mini-Eigen): the first window is bootstrapped from supplied
+poses (oracle/ref/gt_initializer.cpp), on both sides alike.  tests/chain_compare.py::compare_seq holds the two record streams together after
+every camera frame.  Also here: the same reference run against the ORACLE CHAIN of test_chain_parity.py (restated control flow + oracle_front.cpp):
+that pins K3 / K5 / K6 -- which tracks survive, which corners are added, frame by frame -- to the reference's own Frame::track_keypoints."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import chain_compare
+import test_host_headless as hh
+from chain_run import parse_log
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REFDIR = os.path.join(ROOT, "oracle", "_ref")
+
+
+def _libs():
+    from oracle import ref_py
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "hipemu"), "libpvio_hipemu.so"])
+    if not ref_py.available() or not ref_py.build_dropin():
+        pytest.skip("oracle/_ref libraries not built and /root/reference absent")
+
+
+def _run(lib, prefix, n_frames, window, gap, distance, size, timeout, image="oracle"):
+    env = dict(os.environ, PVIO_SEQ_IMAGE=image)
+    r = subprocess.run([sys.executable, os.path.join(HERE, "chain_run.py"), lib, prefix, str(n_frames), str(window), str(gap), str(distance), size],
+                       capture_output=True, text=True, timeout=timeout, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    return r.stdout.strip().splitlines()[-1]
+
+
+def test_reference_pvio_with_product_backend_emulated(tmp_path):
+    """30 frames at 352 x 264: bootstrap solve, 24 PnP, keyframe solves + marginalizations, planes extracted and cast -- the reference's pvio::PVIO with the
+    reference's back-end against the same with the product's (kernels in the emulator); the CPU oracle's front end behind pvio::Image on both sides"""
+    _libs()
+    a, b = str(tmp_path / "ref"), str(tmp_path / "dropin")
+    print(_run(os.path.join(REFDIR, "libpvio_ref.so"), a, 30, 3, 2, 18.0, "small", 600))
+    print(_run(os.path.join(REFDIR, "libpvio_dropin_emu.so"), b, 30, 3, 2, 18.0, "small", 900))
+    info = chain_compare.compare_seq(a + ".log", b + ".log", hh.SMALL[2][0])
+    print("reference pvio::PVIO, reference back-end vs product back-end:", info)
+    assert info["frames"] == 30 and info["identical_frames"] == 30 and info["window_records"] >= 20 and info["planes_seen"] >= 1
+    assert info["max_state_before_flip"] < 1e-8
+
+
+def test_reference_pvio_pins_the_restated_front_end_bookkeeping(tmp_path):
+    """SURVEY K3 / K5 / K6 against the reference's own code at sequence level: the oracle chain (tests/host/oracle_chain.cpp: restated FeatureTracker::work
+    order, oracle_front.cpp's survivor selection / Poisson filter / prediction) and the reference's pvio::PVIO (its own feature_tracker.cpp, frame.cpp,
+    poisson_disk_filter.h) see the same images through the same oracle front end: same track ids, track lengths and keypoints in every frame, until
+    the reference's plane extractor -- which the restated driver does not have -- changes the window."""
+    _libs()
+    subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "host"), "libpvio_chain_oracle.so"])
+    a, b = str(tmp_path / "ref"), str(tmp_path / "oracle")
+    print(_run(os.path.join(REFDIR, "libpvio_ref.so"), a, 30, 3, 2, 18.0, "small", 600))
+    print(_run(os.path.join(HERE, "host", "libpvio_chain_oracle.so"), b, 30, 3, 2, 18.0, "small", 600))
+    A = [r for r in parse_log(a + ".log") if r[0] == 1]
+    B = [r for r in parse_log(b + ".log") if r[0] == 1]
+    R9 = [r for r in parse_log(a + ".log") if r[0] == 9]
+    first_planes = min([int(I[0]) for _, I, _ in R9 if int(I[2 + 4 * int(I[1])]) > 0] + [len(A)])
+    assert first_planes >= 12, first_planes
+    tracked = 0
+    for (_, Ia, Da), (_, Ib, Db) in zip(A[:first_planes], B[:first_planes]):
+        assert Ia.shape == Ib.shape and (Ia == Ib).all(), "frame %d: surviving tracks / new corners differ" % int(Ia[0])
+        n = int(Ia[4])
+        assert (Da[:2 * n] == Db[:2 * n]).all()                 # same keypoints, bit for bit
+        assert np.abs(Da[-8:] - Db[-8:]).max() < 1e-9          # same reported pose
+        tracked += int((Ia[5:].reshape(n, 2)[:, 1] > 1).sum())
+    assert tracked > 1000
+    print("identical track ids / lengths / keypoints for %d frames (%d tracked keypoints), until the reference's plane extractor acts" % (first_planes, tracked))
+
+
+@pytest.mark.gpu
+def test_reference_pvio_with_product_backend_gpu(tmp_path):
+    """60 frames at 512 x 384, window of 6 keyframes: the reference's pvio::PVIO with its own back-end against the same with the product's on the MI355X"""
+    _libs()
+    a, b = str(tmp_path / "ref"), str(tmp_path / "dropin")
+    print(_run(os.path.join(REFDIR, "libpvio_ref.so"), a, 60, 6, 3, 25.0, "full", 1500))
+    print(_run(os.path.join(REFDIR, "libpvio_dropin.so"), b, 60, 6, 3, 25.0, "full", 900))
+    info = chain_compare.compare_seq(a + ".log", b + ".log", hh.K4[0])
+    print("reference pvio::PVIO, reference back-end vs product back-end (GPU):", info)
+    assert info["frames"] == 60 and info["identical_frames"] == 60 and info["window_records"] >= 30
+    out = os.environ.get("PVIO_SEQ_REPORT")
+    if out:
+        import json
+        json.dump(info, open(out, "w"), indent=1)

@@ -125,6 +125,74 @@ def test_keypoint_prediction_matches_oracle_and_rotates_bearings(host, ora):
     assert 15 < np.abs(out["host"] - (kp * K[:2] + K[2:])).max() < 60
 
 
+# ---- the same three pieces against the REFERENCE'S OWN code: Frame::track_keypoints (map/frame.cpp:89-139) and
+# PoissonDiskFilter<2> (utility/poisson_disk_filter.h:25-130) compiled unedited into oracle/_ref/libpvio_ref.so, driven through a scripted
+# pvio::Image (oracle/ref/ref_capi.cpp: ref_poisson_insert / ref_select_tracked / ref_predict_keypoints, same signatures) --------------
+
+@pytest.fixture(scope="module")
+def refl():
+    from oracle import ref_py
+    if not ref_py.available():
+        pytest.skip("oracle/_ref/libpvio_ref.so not built and /root/reference absent")
+    return ref_py.lib()
+
+
+@pytest.mark.parametrize("seed,radius,n,extent,n_preset", [(1, 20.0, 400, 300.0, 0), (2, 7.5, 1500, 200.0, 0), (3, 20.0, 50, 2000.0, 0), (4, 1.0, 300, 6.0, 0), (5, 10.0, 300, 100.0, 40),
+                                                           (6, 25.0, 1000, 752.0, 150)])
+def test_poisson_filter_matches_reference_source(host, ora, refl, seed, radius, n, extent, n_preset):
+    """product PoissonDisk2 == oracle restatement == the reference's PoissonDiskFilter<2> (its probe-order quirk included), candidate by candidate"""
+    rng = np.random.default_rng(seed)
+    pts = rng.uniform(-extent / 3, extent, (n, 2))
+    preset = rng.uniform(0, extent, (n_preset, 2))
+    a_ref = poisson(refl, "ref", radius, preset, pts)
+    assert (poisson(host, "host", radius, preset, pts) == a_ref).all()
+    assert (poisson(ora, "oracle", radius, preset, pts) == a_ref).all()
+    assert 0 < a_ref.sum() < n
+    # the overwrite quirk of preset_point (:40-44), on the reference itself
+    r = 10.0
+    cell = r / np.sqrt(2.0)
+    first, second = np.array([0.1 * cell, 0.1 * cell]), np.array([0.9 * cell, 0.9 * cell])
+    cand = np.array([[-0.5 * cell, 0.1 * cell]])
+    assert poisson(refl, "ref", r, [first], cand)[0] == False  # noqa: E712
+    assert poisson(refl, "ref", r, [first, second], cand)[0] == True  # noqa: E712
+
+
+@pytest.mark.parametrize("seed,n,max_len", [(11, 300, 40), (12, 800, 4), (13, 5, 3), (15, 1500, 12), (16, 200, 2)])
+def test_survivor_selection_matches_reference_source(host, ora, refl, seed, n, max_len):
+    """Frame::track_keypoints' survivor selection (:108-130): LK survivors ordered by track length (std::sort: ties in the library's order), accepted by
+    the Poisson-disk filter in that order.  The reference runs on real Frame / Track objects with tracks of the given lengths."""
+    rng = np.random.default_rng(seed)
+    nxt = np.ascontiguousarray(rng.uniform(20, 500, (n, 2)))
+    length = rng.integers(0, max_len + 1, n).astype(np.uint64)  # 0 = keypoint without a track
+    status0 = (rng.uniform(size=n) < 0.8).astype(np.uint8)
+    out = {}
+    for lib, prefix in ((host, "host"), (ora, "oracle"), (refl, "ref")):
+        st = status0.copy()
+        getattr(lib, prefix + "_select_tracked")(C.c_int(n), _p(nxt, f64p), _p(length, u64p), C.c_double(20.0), _p(st, u8p))
+        out[prefix] = st
+    assert (out["host"] == out["ref"]).all(), np.nonzero(out["host"] != out["ref"])
+    assert (out["oracle"] == out["ref"]).all()
+    assert 0 < out["ref"].sum() <= status0.sum() and (n < 100 or out["ref"].sum() < status0.sum())
+
+
+def test_keypoint_prediction_matches_reference_source(host, ora, refl):
+    """Frame::track_keypoints' gyro-only prediction (:97-103): what the reference hands to Image::track_keypoints as the initial guess"""
+    rng = np.random.default_rng(5)
+    kp = np.ascontiguousarray(rng.uniform(-0.6, 0.6, (200, 2)))
+    K = np.array([458.654, 457.296, 367.215, 248.375])
+    for trial in range(5):
+        q_ci, q_ii, dq, q_ij, q_cj = (_rand_q(rng, a) for a in (0.3, 0.1 * trial, 0.05 * (trial + 1), 0.1 * trial, 0.3))
+        out = {}
+        for lib, prefix in ((host, "host"), (ora, "oracle"), (refl, "ref")):
+            o = np.zeros_like(kp)
+            getattr(lib, prefix + "_predict_keypoints")(_p(q_ci, f64p), _p(q_ii, f64p), _p(dq, f64p), _p(q_ij, f64p), _p(q_cj, f64p), _p(K, f64p),
+                                                        C.c_int(len(kp)), _p(kp, f64p), _p(o, f64p))
+            out[prefix] = o
+        assert np.abs(out["host"] - out["ref"]).max() < 1e-9
+        assert np.abs(out["oracle"] - out["ref"]).max() < 1e-9
+        assert np.abs(out["ref"] - (kp * K[:2] + K[2:])).max() > 1.0
+
+
 def _image_seam(lib, oracle, w, h, n):
     img0, img1, p, truth, init = synth.make_image_pair(w, h, n)
     P0, P1 = oracle.build_pyramid(oracle.clahe(img0)), oracle.build_pyramid(oracle.clahe(img1))
