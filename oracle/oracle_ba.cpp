@@ -280,7 +280,11 @@ struct Evaluator {
             pre.dv_dbg = m3load(pj + 27);
             pre.dv_dba = m3load(pj + 36);
             double r[15], J[450];
-            eval_preintegration(fs + 16 * i, fs + 16 * j, vload(user + 16 * i + 10), vload(user + 16 * i + 13), pre, imu[i], imu[j], r,
+            // ORACLE_NO_LIVE_BIAS=1 (experiment only, tests/probe_rejections.py): what the factor would be WITHOUT the reference's read of the live
+            // frame_i->motion.bg / ba (preintegration_error_cost.h:57-58) -- the bias correction taken at the evaluation point itself
+            static const bool no_live_bias = getenv("ORACLE_NO_LIVE_BIAS") != nullptr;
+            const double *bias_src = no_live_bias ? fs : user;
+            eval_preintegration(fs + 16 * i, fs + 16 * j, vload(bias_src + 16 * i + 10), vload(bias_src + 16 * i + 13), pre, imu[i], imu[j], r,
                                 lin ? J : nullptr);
             double sq = 0;
             for (int k = 0; k < 15; ++k) sq += r[k] * r[k];

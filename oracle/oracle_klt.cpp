@@ -10,9 +10,20 @@
 // OpenCV is an unpinned find_package (depends/CMakeLists.txt:9) and is NOT in /root/reference, so these are
 // restatements of the published algorithms (imgproc/clahe.cpp, imgproc/pyramids.cpp, video/lkpyramid.cpp: scalar,
 // non-SIMD code paths) -- SURVEY.md App. C.  PARITY UNPINNED: no OpenCV here, no reference tests; pinned only by
-// invariants (tests/test_oracle_klt.py).  A SIMD OpenCV build sums the float accumulators in a different order, so
-// even the real reference is only reproducible up to float rounding; the contract is identical status bytes and
-// |position difference| <= 1e-3 px.
+// invariants (tests/test_oracle_klt.py).
+//
+// THE ORDER OF THE FLOAT SUMS (round 4).  LK accumulates 441 products per window into float accumulators (A11, A12, A22 once per level,
+// b1, b2 every iteration).  OpenCV itself has no single order: its scalar LKTrackerInvoker adds left to right, row by row; its SSE2 / NEON /
+// AVX paths add four or eight lanes side by side and fold them at the end -- so even the real reference is reproducible only up to float
+// rounding across builds.  This oracle therefore DEFINES the order the product implements and is held to it bit for bit
+// (tests/test_gpu_klt.py, tests/test_chain_parity.py: positions identical, not "within 1e-3 px"):
+//   * the window is cut into 63 runs of 7 pixels (run l = row l / 3, columns 7 (l % 3) .. 7 (l % 3) + 6); a run is summed left to right
+//     from 0.0f -- a 64th, empty run holds 0.0f;
+//   * the 64 run sums are folded by a fixed tree: within each group of 16 runs  s += s[i ^ 1];  s += s[i ^ 2];  s += s[mirror in 8];
+//     s += s[mirror in 16]  (every run of the group then holds the group's sum), and the four group sums are added as ((g0 + g1) + g2) + g3.
+// That is pvio_amd/csrc/klt.hip: lane = run, wave_sum_f = the tree (DPP quad_perm / row_half_mirror / row_mirror + four lane reads).
+// oracle_klt_track_scalar_order keeps OpenCV's scalar left-to-right order; the two agree in every status byte and to <= 1e-3 px on textured
+// windows (tests/test_oracle_klt.py), which is what "the same tracker" can mean across summation orders.
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -37,6 +48,33 @@ constexpr int kMaxLevel = 3;    // level_num()
 constexpr int kMaxCount = 30;
 constexpr float kEps2 = 0.01f * 0.01f; // criteria.epsilon is squared by calcOpticalFlowPyrLK
 constexpr float kMinEig = 1e-4f;
+
+// the defined fold of 64 run sums (see the header): returns what every lane of the wave holds after klt.hip's wave_sum_f
+constexpr int kRun = 7, kRuns = 64;
+inline int run_of(int x, int y) { return 3 * y + x / kRun; }
+inline float fold_runs(const float *run) {
+    float s[kRuns], t[kRuns];
+    for (int i = 0; i < kRuns; ++i) s[i] = run[i];
+    for (int i = 0; i < kRuns; ++i) t[i] = s[i] + s[i ^ 1];
+    for (int i = 0; i < kRuns; ++i) s[i] = t[i] + t[i ^ 2];
+    for (int i = 0; i < kRuns; ++i) t[i] = s[i] + s[(i & ~7) | (7 - (i & 7))];
+    for (int i = 0; i < kRuns; ++i) s[i] = t[i] + t[(i & ~15) | (15 - (i & 15))];
+    return ((s[0] + s[16]) + s[32]) + s[48];
+}
+// one accumulator: either 64 run sums folded by the tree (the defined order) or one running sum (OpenCV's scalar order)
+struct Acc {
+    bool runs;
+    float r[kRuns];
+    float scalar;
+    explicit Acc(bool by_runs) : runs(by_runs), scalar(0.f) {
+        for (float &v : r) v = 0.f;
+    }
+    inline void add(int x, int y, float v) {
+        if (runs) r[run_of(x, y)] += v;
+        else scalar += v;
+    }
+    inline float total() const { return runs ? fold_runs(r) : scalar; }
+};
 
 } // namespace
 
@@ -168,8 +206,8 @@ static inline int der(const Level &L, int x, int y, int c) {
 
 // calcOpticalFlowPyrLK (LKTrackerInvoker, scalar path) over prebuilt pyramids + the reference's 20-px border kill.
 // imgs/drvs: per level pointers (level 0 first); next_xy in/out; status out.
-void oracle_klt_track(int n_levels, const int *ws, const int *hs, const uint8_t *const *prev_img, const int16_t *const *prev_drv,
-                      const uint8_t *const *next_img, int n, const float *prev_xy, float *next_xy, uint8_t *status) {
+static void klt_track_impl(bool by_runs, int n_levels, const int *ws, const int *hs, const uint8_t *const *prev_img, const int16_t *const *prev_drv,
+                           const uint8_t *const *next_img, int n, const float *prev_xy, float *next_xy, uint8_t *status) {
     const float half = (kWin - 1) * 0.5f;
     const float FLT_SCALE = 1.f / (1 << 20);
     for (int p = 0; p < n; ++p) status[p] = 1;
@@ -198,7 +236,7 @@ void oracle_klt_track(int n_levels, const int *ws, const int *hs, const uint8_t 
             int iw01 = cv_round(a * (1.f - b) * (1 << W_BITS));
             int iw10 = cv_round((1.f - a) * b * (1 << W_BITS));
             int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
-            float iA11 = 0, iA12 = 0, iA22 = 0;
+            Acc accA11(by_runs), accA12(by_runs), accA22(by_runs);
             for (int y = 0; y < kWin; ++y)
                 for (int x = 0; x < kWin; ++x) {
                     const int X = ipx + x, Y = ipy + y;
@@ -208,11 +246,11 @@ void oracle_klt_track(int n_levels, const int *ws, const int *hs, const uint8_t 
                     Iwin[y * kWin + x] = (int16_t)ival;
                     dIwin[2 * (y * kWin + x)] = (int16_t)ixval;
                     dIwin[2 * (y * kWin + x) + 1] = (int16_t)iyval;
-                    iA11 += (float)(ixval * ixval);
-                    iA12 += (float)(ixval * iyval);
-                    iA22 += (float)(iyval * iyval);
+                    accA11.add(x, y, (float)(ixval * ixval));
+                    accA12.add(x, y, (float)(ixval * iyval));
+                    accA22.add(x, y, (float)(iyval * iyval));
                 }
-            float A11 = iA11 * FLT_SCALE, A12 = iA12 * FLT_SCALE, A22 = iA22 * FLT_SCALE;
+            float A11 = accA11.total() * FLT_SCALE, A12 = accA12.total() * FLT_SCALE, A22 = accA22.total() * FLT_SCALE;
             float D = A11 * A22 - A12 * A12;
             float minEig = (A22 + A11 - std::sqrt((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (2 * kWin * kWin);
             if (minEig < kMinEig || D < 1.1920929e-07f /* FLT_EPSILON */) {
@@ -233,15 +271,15 @@ void oracle_klt_track(int n_levels, const int *ws, const int *hs, const uint8_t 
                 iw01 = cv_round(a * (1.f - b) * (1 << W_BITS));
                 iw10 = cv_round((1.f - a) * b * (1 << W_BITS));
                 iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
-                float ib1 = 0, ib2 = 0;
+                Acc accb1(by_runs), accb2(by_runs);
                 for (int y = 0; y < kWin; ++y)
                     for (int x = 0; x < kWin; ++x) {
                         const int X = inx + x, Y = iny + y;
                         int diff = ((pix(J, X, Y) * iw00 + pix(J, X + 1, Y) * iw01 + pix(J, X, Y + 1) * iw10 + pix(J, X + 1, Y + 1) * iw11 + (1 << (W_BITS - 5 - 1))) >> (W_BITS - 5)) - Iwin[y * kWin + x];
-                        ib1 += (float)(diff * dIwin[2 * (y * kWin + x)]);
-                        ib2 += (float)(diff * dIwin[2 * (y * kWin + x) + 1]);
+                        accb1.add(x, y, (float)(diff * dIwin[2 * (y * kWin + x)]));
+                        accb2.add(x, y, (float)(diff * dIwin[2 * (y * kWin + x) + 1]));
                     }
-                float b1 = ib1 * FLT_SCALE, b2 = ib2 * FLT_SCALE;
+                float b1 = accb1.total() * FLT_SCALE, b2 = accb2.total() * FLT_SCALE;
                 float dx = (float)((A12 * b2 - A22 * b1) * D), dy = (float)((A12 * b1 - A11 * b2) * D);
                 nx += dx, ny += dy;
                 next_xy[2 * p] = nx + half, next_xy[2 * p + 1] = ny + half;
@@ -262,6 +300,17 @@ void oracle_klt_track(int n_levels, const int *ws, const int *hs, const uint8_t 
     // opencv_image.cpp:104-109: tracks within 20 px of the border of the full-resolution image are dropped
     for (int p = 0; p < n; ++p)
         if (next_xy[2 * p] < 20 || next_xy[2 * p] >= ws[0] - 20 || next_xy[2 * p + 1] < 20 || next_xy[2 * p + 1] >= hs[0] - 20) status[p] = 0;
+}
+
+// the defined order of the float sums (header): what the parity tests hold the HIP kernel to, bit for bit
+void oracle_klt_track(int n_levels, const int *ws, const int *hs, const uint8_t *const *prev_img, const int16_t *const *prev_drv,
+                      const uint8_t *const *next_img, int n, const float *prev_xy, float *next_xy, uint8_t *status) {
+    klt_track_impl(true, n_levels, ws, hs, prev_img, prev_drv, next_img, n, prev_xy, next_xy, status);
+}
+// OpenCV's scalar LKTrackerInvoker order: one running sum, left to right, row by row
+void oracle_klt_track_scalar_order(int n_levels, const int *ws, const int *hs, const uint8_t *const *prev_img, const int16_t *const *prev_drv,
+                                   const uint8_t *const *next_img, int n, const float *prev_xy, float *next_xy, uint8_t *status) {
+    klt_track_impl(false, n_levels, ws, hs, prev_img, prev_drv, next_img, n, prev_xy, next_xy, status);
 }
 
 } // extern "C"

@@ -206,7 +206,9 @@ def build_pyramid(img):
     return levels
 
 
-def klt_track(prev_levels, next_levels, prev_xy, next_xy_init):
+def klt_track(prev_levels, next_levels, prev_xy, next_xy_init, scalar_order=False):
+    """oracle_klt_track: the float sums in the DEFINED order (63 runs of 7 pixels folded by a fixed tree = what klt.hip implements; bit-exact
+    contract).  scalar_order=True: OpenCV's scalar left-to-right order (oracle_klt_track_scalar_order), for the order-sensitivity tests."""
     L = lib()
     n_levels = len(prev_levels)
     ws = np.array([lv[0].shape[1] for lv in prev_levels], np.int32)
@@ -218,9 +220,10 @@ def klt_track(prev_levels, next_levels, prev_xy, next_xy_init):
     nxt = np.array(next_xy_init, dtype=np.float32, order="C", copy=True)
     n = prev_xy.shape[0]
     status = np.zeros(n, np.uint8)
-    L.oracle_klt_track.argtypes = [C.c_int, i32p, i32p, C.POINTER(u8p), C.POINTER(i16p), C.POINTER(u8p), C.c_int, f32p, f32p, u8p]
-    L.oracle_klt_track.restype = None
-    L.oracle_klt_track(n_levels, ws.ctypes.data_as(i32p), hs.ctypes.data_as(i32p), PI, PD, NI, n, prev_xy.ctypes.data_as(f32p),
+    fn = L.oracle_klt_track_scalar_order if scalar_order else L.oracle_klt_track
+    fn.argtypes = [C.c_int, i32p, i32p, C.POINTER(u8p), C.POINTER(i16p), C.POINTER(u8p), C.c_int, f32p, f32p, u8p]
+    fn.restype = None
+    fn(n_levels, ws.ctypes.data_as(i32p), hs.ctypes.data_as(i32p), PI, PD, NI, n, prev_xy.ctypes.data_as(f32p),
                        nxt.ctypes.data_as(f32p), status.ctypes.data_as(u8p))
     return nxt, status
 

@@ -74,11 +74,13 @@ def write_front(name, width, height, n_points):
     img0, img1, p, truth, init = synth.make_image_pair(width, height, n_points)
     c0, c1 = oracle.clahe(img0), oracle.clahe(img1)
     P0, P1 = oracle.build_pyramid(c0), oracle.build_pyramid(c1)
-    nxt, status = oracle.klt_track(P0, P1, p, init)
+    nxt, status = oracle.klt_track(P0, P1, p, init)  # the float sums in the defined order (oracle_klt.cpp header): the bit-exact contract
+    nxt_scalar, status_scalar = oracle.klt_track(P0, P1, p, init, scalar_order=True)  # OpenCV's scalar left-to-right order
+    assert (status == status_scalar).all()
     resp = oracle.harris_response(c0)
     xy, r = oracle.good_features(resp, 200, 1.0e-3, 12.0)
     d = dict(in_img0=img0, in_img1=img1, in_prev_xy=p, in_init_xy=init, in_truth_xy=truth,
-             out_clahe0=c0, out_next_xy=nxt, out_status=status, out_harris=resp, out_corners_xy=xy, out_corners_resp=r,
+             out_clahe0=c0, out_next_xy=nxt, out_next_xy_scalar_order=nxt_scalar, out_status=status, out_harris=resp, out_corners_xy=xy, out_corners_resp=r,
              in_detect_params=np.array([200, 1.0e-3, 12.0]))
     for l in range(1, len(P0)):          # level 0 image is the CLAHE output; its derivative and the rest are stored as is
         d["out_level%d_image" % l] = P0[l][0]

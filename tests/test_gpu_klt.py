@@ -1,7 +1,8 @@
 """GPU parity tests of the KLT front end (C-ABI of libpvio_hip.so) against the CPU oracle.
 
-Bar: CLAHE / pyramid / Scharr levels bit-exact (integer + strictly ordered float32); LK status bytes identical and
-positions within 1e-3 px (float32 accumulators are reduced as a wave butterfly instead of left-to-right)."""
+Bar: CLAHE / pyramid / Scharr levels bit-exact (integer + strictly ordered float32); LK status bytes identical and positions
+BIT-IDENTICAL: the kernel reduces its float32 accumulators in the order oracle/oracle_klt.cpp defines (63 runs of 7 pixels, a fixed fold
+tree), so nothing is left to "rounding" between the two -- OpenCV's own scalar order is a third rounding of the same sums (<= 1e-3 px)."""
 import numpy as np
 import pytest
 
@@ -38,7 +39,7 @@ def test_gpu_klt_no_clahe_and_empty(gpu_ctx, oracle):
     assert q.shape == (0, 2) and st.shape == (0,)
     # identical images: zero motion
     q, st, _ = klt_track(gpu_ctx, A, A, p, p)
-    assert st.all() and np.abs(q - p).max() < 1e-3
+    assert st.all() and np.abs(q - p).max() < 1e-3  # (LK does not return the start exactly: its first step is a few 1e-5 px)
 
 
 def test_gpu_corner_detection_matches_oracle(gpu_ctx, oracle):
@@ -58,14 +59,13 @@ def test_gpu_corner_distance_filter_is_exact(gpu_ctx, oracle, md, cap):
 @pytest.mark.gpu
 def test_gpu_lk_random_pairs_status_exact_positions_bounded(oracle):
     """Eight random pairs (sizes, motion up to 25 px, noise, a flat patch in every third pair, 300 extra points anywhere with poor
-    initial guesses; ~8 800 points): the status bytes are IDENTICAL to the oracle's; positions agree to 1e-3 px except in
-    nearly flat regions, where the iteration may take another exit under a different float summation order -- those points
-    are asserted explicitly: few (<= 0.2 % of the tracked ones), still tracked on both sides, within 0.15 px."""
+    initial guesses; ~8 800 points): status bytes AND positions are identical to the oracle's, bit for bit -- the nearly flat regions included,
+    where under another summation order the iteration takes another exit (the scalar-order oracle shows that: a handful of points, 0.1 px)."""
     from pvio_amd import synth
     from pvio_amd.solver import HipContext, HipImage, klt_track
     ctx = HipContext(device=0)
-    tot = outl = 0
-    worst = 0.0
+    tot = outl = scalar_flips = scalar_outl = 0
+    worst = scalar_worst = 0.0
     for seed in (0, 1, 2, 3, 6, 9, 12, 15):
         rng = np.random.default_rng(9000 + seed)
         w, h = int(rng.choice([320, 512, 640, 752])), int(rng.choice([240, 384, 480, 512]))
@@ -92,11 +92,19 @@ def test_gpu_lk_random_pairs_status_exact_positions_bounded(oracle):
         ok = s0 > 0
         d = np.abs(n0 - n1)[ok].max(axis=1) if ok.any() else np.zeros(0)
         tot += int(ok.sum())
-        outl += int((d > 1e-3).sum())
+        outl += int((d > 0).sum())
         worst = max(worst, float(d.max(initial=0.0)))
+        n0s, s0s = oracle.klt_track(P0, P1, p2, init2, scalar_order=True)  # OpenCV's scalar order: same decisions, other rounding
+        both = ok & (s0s > 0)
+        ds = np.abs(n0s - n1)[both].max(axis=1) if both.any() else np.zeros(0)
+        scalar_flips += int((s0s != s1).sum())
+        scalar_outl += int((ds > 1e-3).sum())
+        scalar_worst = max(scalar_worst, float(ds.max(initial=0.0)))
     ctx.close()
-    print("LK sweep: %d tracked points, %d beyond 1e-3 px, worst %.3g px" % (tot, outl, worst))
-    assert tot > 4000 and outl <= 0.002 * tot and worst < 0.15
+    print("LK sweep: %d tracked points, %d not bit-identical (worst %.3g px); against the scalar order: %d status flips, %d beyond 1e-3 px, worst %.3g px" % (
+        tot, outl, worst, scalar_flips, scalar_outl, scalar_worst))
+    assert tot > 4000 and outl == 0 and worst == 0.0
+    assert scalar_flips <= 0.002 * tot and scalar_outl <= 0.002 * tot and scalar_worst < 0.15
 
 
 @pytest.mark.gpu
