@@ -69,11 +69,14 @@ def test_chain_parity_gpu(tmp_path):
     rep = chain_compare.compare_replay(a + ".log")
     print("replay:", rep)
     assert rep["solves"] >= 4 and rep["pnps"] >= 30
-    # identical decisions for 48 frames on this sequence (the tie that ends them is described in chain_compare.py); the floor leaves room
-    # for a kernel change that moves the LK rounding, not for a wrong result: poses are compared over all 60 frames either way
-    free = chain_compare.compare_free(a + ".log", b + ".log", hh.K4[0], a + ".tum", b + ".tum", min_identical_frames=30)
+    # round 4: the LK kernel sums in the order the oracle defines (oracle/oracle_klt.cpp header), so the chains no longer drift apart by the
+    # tracker's rounding: identical decisions over ALL 60 frames (round 3: 48, ended by a 25.000 px Poisson-radius tie between keypoints that
+    # differed by 1e-3 px).  What is left between them is the back-end's 1e-10, which reaches the tracker only through the float32 cast of
+    # the predicted keypoints: a keypoint may still move by one float ulp of its prediction on rare frames (max_kp_px is reported, 0 expected)
+    free = chain_compare.compare_free(a + ".log", b + ".log", hh.K4[0], a + ".tum", b + ".tum")
     print("free running:", free)
-    assert free["frames"] == 60 and free["solves"] >= 3 and free["margs"] >= 1
+    assert free["frames"] == 60 and free["identical_frames"] == 60 and free["solves"] >= 3 and free["margs"] >= 1
+    assert free["max_kp_px"] <= 1e-3 and free["max_state_free"] <= 1e-6
     assert _follows_ground_truth(a, 0.15)
     out = os.environ.get("PVIO_CHAIN_REPORT")  # profiles/collect.sh: keep the numbers of the run
     if out:
