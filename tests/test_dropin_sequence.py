@@ -53,9 +53,16 @@ def test_reference_pvio_with_product_backend_emulated(tmp_path):
     print(_run(os.path.join(REFDIR, "libpvio_ref.so"), a, 30, 3, 2, 18.0, "small", 600))
     print(_run(os.path.join(REFDIR, "libpvio_dropin_emu.so"), b, 30, 3, 2, 18.0, "small", 900))
     info = chain_compare.compare_seq(a + ".log", b + ".log", hh.SMALL[2][0])
-    print("reference pvio::PVIO, reference back-end vs product back-end:", info)
-    assert info["frames"] == 30 and info["identical_frames"] == 30 and info["window_records"] >= 20 and info["planes_seen"] >= 1
-    assert info["max_state_before_flip"] < 1e-8
+    print("reference pvio::PVIO, reference back-end vs product back-end (wall scene):", info)
+    # strict until the reference's best-plane coin flip (chain_compare.compare_seq): bootstrap solve, PnP of every frame, the first keyframe cycles
+    assert info["frames"] == 30 and info["strict_frames"] >= 16 and info["window_records"] >= 10 and info["max_state"] < 1e-8
+    # the relief scene has no planes: strict over the whole sequence
+    a, b = str(tmp_path / "ref_r"), str(tmp_path / "dropin_r")
+    print(_run(os.path.join(REFDIR, "libpvio_ref.so"), a, 30, 3, 2, 18.0, "small_relief", 600))
+    print(_run(os.path.join(REFDIR, "libpvio_dropin_emu.so"), b, 30, 3, 2, 18.0, "small_relief", 900))
+    info = chain_compare.compare_seq(a + ".log", b + ".log", hh.SMALL[2][0])
+    print("reference pvio::PVIO, reference back-end vs product back-end (relief scene):", info)
+    assert info["frames"] == 30 and info["strict_frames"] == 30 and info["window_records"] >= 20 and info["keyframes"] >= 2 and info["max_state"] < 1e-8
 
 
 def test_reference_pvio_pins_the_restated_front_end_bookkeeping(tmp_path):
@@ -92,9 +99,52 @@ def test_reference_pvio_with_product_backend_gpu(tmp_path):
     print(_run(os.path.join(REFDIR, "libpvio_ref.so"), a, 60, 6, 3, 25.0, "full", 1500))
     print(_run(os.path.join(REFDIR, "libpvio_dropin.so"), b, 60, 6, 3, 25.0, "full", 900))
     info = chain_compare.compare_seq(a + ".log", b + ".log", hh.K4[0])
-    print("reference pvio::PVIO, reference back-end vs product back-end (GPU):", info)
-    assert info["frames"] == 60 and info["identical_frames"] == 60 and info["window_records"] >= 30
+    print("reference pvio::PVIO, reference back-end vs product back-end (GPU, wall scene):", info)
+    assert info["frames"] == 60 and info["strict_frames"] >= 27 and info["window_records"] >= 10
     out = os.environ.get("PVIO_SEQ_REPORT")
     if out:
         import json
         json.dump(info, open(out, "w"), indent=1)
+
+
+def _full_product(tmp_path, lib, n_frames, window, gap, distance, size, fx, timeout):
+    _libs()
+    a, b = str(tmp_path / ("ref_" + size)), str(tmp_path / ("product_" + size))
+    print(_run(os.path.join(REFDIR, "libpvio_ref.so"), a, n_frames, window, gap, distance, size, timeout))
+    print(_run(os.path.join(REFDIR, lib), b, n_frames, window, gap, distance, size, timeout, image="hip"))
+    keep = os.environ.get("PVIO_SEQ_KEEP")
+    if keep:
+        import shutil
+        os.makedirs(keep, exist_ok=True)
+        for f in (a + ".log", b + ".log"):
+            shutil.copy(f, keep)
+    return chain_compare.compare_seq(a + ".log", b + ".log", fx)
+
+
+def test_reference_pvio_with_the_whole_product_emulated(tmp_path):
+    """the reference's pvio::PVIO with EVERYTHING below its seams the product's: pvio::Image = HipImage (CLAHE, pyramid, LK, corner detection and F-RANSAC
+    kernels; pvio_amd/host/feature_front.cpp), BundleAdjustor and visual_inertial_pnp = pvio_amd/host above the C ABI (kernels in the emulator) -- against the
+    same pvio::PVIO with the reference's back-end and the CPU oracle's front end.  The LK sums are in the defined order: keypoints are bit-identical.
+    Relief scene (no planes): strict over the whole sequence."""
+    info = _full_product(tmp_path, "libpvio_dropin_emu.so", 30, 3, 2, 18.0, "small_relief", hh.SMALL[2][0], 1500)
+    print("reference pvio::PVIO: reference back-end + oracle front end vs the whole product:", info)
+    assert info["frames"] == 30 and info["strict_frames"] == 30 and info["max_kp_px"] == 0.0 and info["max_state"] < 1e-8 and info["keyframes"] >= 2
+
+
+@pytest.mark.gpu
+def test_reference_pvio_with_the_whole_product_gpu(tmp_path):
+    """the same on the MI355X: 60 frames at 512 x 384, window of 6 keyframes; the relief scene strictly over all 60 frames, the wall scene (planes
+    extracted, cast and constrained) strictly until the reference's best-plane coin flip"""
+    out = {}
+    info = _full_product(tmp_path, "libpvio_dropin.so", 60, 6, 3, 25.0, "full_relief", hh.K4[0], 1500)
+    print("reference pvio::PVIO: reference back-end + oracle front end vs the whole product (GPU, relief scene):", info)
+    assert info["frames"] == 60 and info["strict_frames"] == 60 and info["max_kp_px"] <= 1e-3 and info["keyframes"] >= 3
+    out["relief"] = info
+    info = _full_product(tmp_path, "libpvio_dropin.so", 60, 6, 3, 25.0, "full", hh.K4[0], 1500)
+    print("reference pvio::PVIO: reference back-end + oracle front end vs the whole product (GPU, wall scene):", info)
+    assert info["frames"] == 60 and info["strict_frames"] >= 27 and info["max_kp_px"] <= 1e-3
+    out["wall"] = info
+    path = os.environ.get("PVIO_SEQ_REPORT_FULL")
+    if path:
+        import json
+        json.dump(out, open(path, "w"), indent=1)

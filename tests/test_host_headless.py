@@ -39,8 +39,15 @@ def _texture():
     return tex
 
 
-def render_sequence(n_frames, fps=20.0, imu_rate=200.0, t_start=0.0, size=None):
-    """images (n, H, W) u8, image times, IMU (t, w, a), body poses at the image times (t p q)"""
+def _relief(u, v):
+    """height [m] of the relief scene above the wall plane at wall coordinates (u, v) [m]: smooth, +-0.45 m over ~1.5 m -- no patch of it large enough to
+    hold 30 tracks lies within the 3 cm of the reference's plane RANSAC (core/plane_extractor.cpp:55-57), so PlaneExtractor never reports a plane"""
+    return 0.25 * np.sin(4.1 * u + 0.3) * np.cos(3.3 * v - 0.8) + 0.2 * np.sin(2.2 * u - 1.9 * v + 1.1)
+
+
+def render_sequence(n_frames, fps=20.0, imu_rate=200.0, t_start=0.0, size=None, relief=False):
+    """images (n, H, W) u8, image times, IMU (t, w, a), body poses at the image times (t p q).  relief: the textured surface is the wall plus _relief()
+    (ray / surface intersection by fixed-point iteration) instead of the wall itself: a scene without planes."""
     W, H, K4 = size if size is not None else (globals()["W"], globals()["H"], globals()["K4"])
     q_bc = synth.Q_BC / np.linalg.norm(synth.Q_BC)
     R_bc, p_bc = synth.qmat(q_bc), synth.P_BC
@@ -67,6 +74,10 @@ def render_sequence(n_frames, fps=20.0, imu_rate=200.0, t_start=0.0, size=None):
         rays = rays_c @ R_wc.T
         s = (d - nrm @ p_wc) / (rays @ nrm)
         X = p_wc + rays * s[..., None]
+        if relief:  # n . X = d + h(u, v): six fixed-point steps (the rays are within 40 degrees of the normal, |grad h| < 1.5)
+            for _ in range(6):
+                s = (d + _relief(X @ e1, X @ e2) - nrm @ p_wc) / (rays @ nrm)
+                X = p_wc + rays * s[..., None]
         img = tex(TEX_PPM * (X @ e1), TEX_PPM * (X @ e2)) + rng.normal(0, 1.5, (H, W))
         images.append(np.clip(np.rint(img), 0, 255).astype(np.uint8))
         times.append(t)
