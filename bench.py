@@ -46,7 +46,7 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 FP64_PEAK_TFLOPS = 78.6  # MI355X FP64 (vector = matrix) peak: 256 CUs x 4 SIMDs x 32 flop/clk x 2.4 GHz -- the rate of the measured
                          # 64-cycle v_mfma_f64_16x16x4_f64 (profiles/r2_ubench_mfma_valu_overlap.txt); the guide lists no FP64 figure
 
-_PMC = {"done": False, "kernels": None, "note": None}
+_PMC = {"done": False, "kernels": None, "note": None, "stats": None}
 
 
 def live_pmc(args):
@@ -74,11 +74,22 @@ def live_pmc(args):
                 cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable,
                        os.path.join(ROOT, "bench.py"), "--pmc-child", "--workload", args.workload]
                 env = dict(os.environ, TMPDIR="/tmp", PVIO_BENCH_NO_PMC="1")
-                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=150)
+                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=90)
                 if r.returncode != 0:
                     _PMC["note"] = "rocprofv3 --pmc %s failed (rc %d)" % (counter, r.returncode)
                     return None
                 res[counter] = summarize_pmc.per_kernel(out, counter)
+            # third pass, no counters: rocprofv3 --kernel-trace --stats of the same child -- per-kernel durations INSIDE hipGraph replays (the
+            # hipEvent figures of `kernel_us` come from eager launches with a host synchronization per slot and run ~10 % longer)
+            try:
+                out = os.path.join(td, "stats")
+                cmd = ["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", out, "--", sys.executable,
+                       os.path.join(ROOT, "bench.py"), "--pmc-child", "--workload", args.workload]
+                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=90)
+                if r.returncode == 0:
+                    _PMC["stats"] = summarize_pmc.kernel_stats(out)
+            except Exception:
+                _PMC["stats"] = None
         kernels = {}
         for k in set(res["FETCH_SIZE"]) | set(res["WRITE_SIZE"]):
             f, nf = res["FETCH_SIZE"].get(k, (0.0, 0))
@@ -432,6 +443,32 @@ def main():
                "solves": n_api, "what": "pvio_hip_ba_solve: upload (one staged DMA) + iterations + download of the states, same window; median over the solves"}
         ctx.upload(pb)  # back to the resident state the legs below expect
 
+    # ---- pvio_hip_opts::reuse_identical_candidates (NOT the headline: `value` above evaluates every candidate, like the reference) ----
+    # The same resident solves with the short-circuit on: a candidate that is bit-identical to the one just rejected is not evaluated again.
+    # Same iterations, records and results; the window's last four iterations re-evaluate one rejected point (|gn| << radius), three of the
+    # evaluations are saved.  Reported because it is what the host adapter runs by default -- the reference's keyframe solves consist of such runs.
+    reuse = None
+    if rank == 0 and world == 1 and not args.force_sharded:
+        try:
+            c2 = HipContext(device=local_rank, use_graph=not args.no_graph, reuse_identical_candidates=True)
+            c2.upload(pb)
+            sm2 = BASummary(pb, trace=False)
+            for _ in range(3):
+                c2.solve_resident(sm2)
+            n2 = max(5, min(args.steps, 100))
+            torch.cuda.synchronize()
+            t1, it2 = time.perf_counter(), 0
+            for _ in range(n2):
+                c2.solve_resident(sm2)
+                it2 += sm2.num_iterations
+            dt2 = time.perf_counter() - t1
+            reuse = {"value": it2 / dt2, "unit": "iterations/s", "ms_per_step": 1e3 * dt2 / n2, "steps": n2, "iterations_per_solve": it2 / n2,
+                     "candidate_evaluations_saved_per_solve": c2.last_candidate_repeats(), "final_cost": sm2.final_cost,
+                     "what": "pvio_hip_opts::reuse_identical_candidates = 1: bit-identical re-evaluations of a rejected candidate skipped; results identical; not the headline"}
+            c2.close()
+        except Exception as e:
+            reuse = {"error": repr(e)}
+
     # ---- roofline leg: per-kernel durations from hipEvents on the solver's stream ----
     prof = ctx.profile_resident(BASummary(pb, trace=False))
     prof = ctx.profile_resident(BASummary(pb, trace=False))
@@ -444,6 +481,8 @@ def main():
         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("k_linearize", args),
         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": avg_s * 1e6,
         "kernel_us": {k: (v[0] / max(v[1], 1)) * 1e3 for k, v in prof.items()},
+        "kernel_us_what": "hipEvents on the solver's stream around EAGER launches (one slot at a time, host synchronization per slot): their sum exceeds "
+                          "device_ms_per_step / slots, which is a hipGraph replay; kernel_us_rocprof = the same kernels inside graph replays",
         "exchange_us": {k: (v[0] / max(v[1], 1)) * 1e3 for k, v in ctx.last_comm.items()} if sharded else None,
         "note": "working set < 1 MB: L2/Infinity-Cache resident, the iteration is launch/dependency-latency bound",
     }
@@ -452,6 +491,12 @@ def main():
     # roofline worth quoting (P^3/3 flops in its time is < 0.1 % of the FP64 peak)
     roofline["longest_kernel"] = max(roofline["kernel_us"], key=roofline["kernel_us"].get)
     roofline["traffic_source"] = _PMC["note"]
+    if _PMC.get("stats"):  # rocprofv3 --kernel-trace --stats child pass of this run (graph replays): what profiles/*kernel_stats*.csv holds
+        roofline["kernel_us_rocprof"] = {k: v["avg_us"] for k, v in _PMC["stats"].items() if k in roofline["kernel_us"]}
+        lin_r = _PMC["stats"].get("k_linearize")
+        if lin_r:
+            roofline["achieved_rocprof"] = alg_bytes / (lin_r["avg_us"] * 1e-6) / 1e9
+            roofline["frac_rocprof"] = roofline["achieved_rocprof"] / HBM_PEAK_GBS
     # the dense kernel against the only roofline it has, FP64 arithmetic: P^3 / 3 + 2 P^2 flops (Cholesky of the reduced system with the
     # right-hand side carried along + back substitution) per FACTORING launch.  Its average duration over all launches of a solve
     # (rejected steps do not factor) is a lower bound of a factoring launch's: the fraction quoted is an upper bound -- and still
@@ -526,6 +571,8 @@ def main():
             "iterations_per_solve": iters / args.steps,
             "device_ms_per_step": 1e3 * dev_s / args.steps,
             "api": api,
+            "identical_candidate_reuse": reuse,
+            "final_cost": sm.final_cost,
             "roofline": roofline,
             "roofline_dense": roofline_dense,
             "cpu_baseline": cpu,

@@ -74,6 +74,14 @@ typedef struct pvio_hip_opts {
      * pvio_hip_comm_init, the reduced system assembled from the all-reduced buffer) even with world_size == 1 -- a one-rank
      * RCCL communicator exercises the collectives on a single-GPU box.  0 in production. */
     int32_t debug_force_sharded;
+    /* 1: a trust-region candidate that is bit-identical to the one the previous iteration evaluated and rejected is not evaluated again.
+     * Ceres does evaluate it again -- after a rejected step DoglegStrategy keeps its Gauss-Newton step and only halves the radius, so while
+     * |step| <= radius the next candidate IS the rejected one -- and with the reference's live-bias read (preintegration_error_cost.h:57-58)
+     * such runs are the rule: the keyframe solves of a VIO sequence spend most of their ten iterations re-evaluating one rejected point.
+     * The iterations, their records and every result are unchanged (same cost, same decision, same radius update); only the repeated
+     * evaluation is skipped.  0 (default): every candidate is evaluated, like the reference -- what bench.py's headline measures.
+     * Ignored on landmark shards. */
+    int32_t reuse_identical_candidates;
 } pvio_hip_opts;
 
 /* ------------------------------------------------------------------------------------------------
@@ -233,6 +241,8 @@ typedef struct pvio_ba_kernel_times {
     int32_t comm_launches[2];
 } pvio_ba_kernel_times;
 int32_t pvio_hip_ba_profile_resident(pvio_hip_ctx *ctx, pvio_ba_summary *summary, pvio_ba_kernel_times *times);
+/* candidate evaluations the last solve short-circuited (pvio_hip_opts::reuse_identical_candidates; 0 when the option is off) */
+int32_t pvio_hip_ba_last_candidate_repeats(const pvio_hip_ctx *ctx);
 
 /* multi-GPU (landmark shards, one process per GPU): RCCL communicator bootstrap.
  * rank 0 creates the 128-byte unique id, the launcher broadcasts it (torch.distributed), every rank inits. */

@@ -27,6 +27,19 @@ def per_kernel(directory, counter):
     return {k: (s / n, n) for k, (s, n) in acc.items() if n}
 
 
+def kernel_stats(directory):
+    """per-kernel {avg_us, launches} of a `rocprofv3 --kernel-trace --stats --output-format csv` pass (its *kernel_stats.csv)"""
+    st = {}
+    for path in glob.glob(os.path.join(directory, "**", "*kernel_stats.csv"), recursive=True):
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                short = next((k for k in KERNELS if re.search(r"\b%s\b" % k, row.get("Name", ""))), None)
+                if short:
+                    n0, t0 = st.get(short, (0, 0.0))
+                    st[short] = (n0 + int(row["Calls"]), t0 + float(row["TotalDurationNs"]))
+    return {k: {"avg_us": t / n / 1e3, "launches": n} for k, (n, t) in st.items() if n}
+
+
 def source_sha256():
     """Fingerprint of the kernel sources the counters were collected on (bench.py prints `traffic` only when it matches the
     sources it runs: the GPU box has no .git, so the commit hash is not available there)"""

@@ -22,7 +22,7 @@ c_int16_p = C.POINTER(C.c_int16)
 
 class HipOpts(C.Structure):
     _fields_ = [("device", C.c_int32), ("rank", C.c_int32), ("world_size", C.c_int32), ("use_graph", C.c_int32),
-                ("debug_fail_factorizations", C.c_int32), ("debug_invalid_steps", C.c_int32), ("linearize_mode", C.c_int32), ("debug_force_sharded", C.c_int32)]
+                ("debug_fail_factorizations", C.c_int32), ("debug_invalid_steps", C.c_int32), ("linearize_mode", C.c_int32), ("debug_force_sharded", C.c_int32), ("reuse_identical_candidates", C.c_int32)]
 
 
 class BAProblemC(C.Structure):
@@ -84,7 +84,7 @@ class ImuNoiseC(C.Structure):
 EXPORTS = [
     "pvio_hip_create", "pvio_hip_destroy", "pvio_hip_last_error", "pvio_hip_version",
     "pvio_hip_ba_solve", "pvio_hip_ba_marginalize", "pvio_hip_ba_reprojection_error",
-    "pvio_hip_ba_upload", "pvio_hip_ba_solve_resident", "pvio_hip_ba_download", "pvio_hip_ba_profile_resident",
+    "pvio_hip_ba_upload", "pvio_hip_ba_solve_resident", "pvio_hip_ba_download", "pvio_hip_ba_profile_resident", "pvio_hip_ba_last_candidate_repeats",
     "pvio_hip_comm_unique_id", "pvio_hip_comm_init", "pvio_preintegrate",
     "pvio_hip_image_create", "pvio_hip_image_release", "pvio_hip_image_download_level", "pvio_hip_klt_track", "pvio_hip_image_detect", "pvio_hip_image_download_response",
     "pvio_hip_klt_last_device_ms", "pvio_hip_fundamental_ransac", "pvio_hip_ransac_last_hypotheses",

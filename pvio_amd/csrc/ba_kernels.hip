@@ -168,7 +168,7 @@ __device__ __forceinline__ int mat_at(int i, int k) { return tile_base(i >> 4, k
 // k_linearize
 // ------------------------------------------------------------------------------------------------------
 struct Pro { // prologue result, one copy in LDS per WG
-    int mode, cur, lin, out_set, eval_buf, valid, done, pad_;
+    int mode, cur, lin, out_set, eval_buf, valid, done, repeat;
     double mu_schur, ca, cb;
 };
 
@@ -191,8 +191,9 @@ __device__ __forceinline__ void lin_prologue(const View &v, double *lds, Pro *&p
         const int lane = tid, f = lane < N ? lane : N - 1;
         // (1) control block
         const int done = c->done; // (tested after everything has been requested: a test up front is a fabric trip of its own)
-        const int mode = c->mode, cur = c->cur, lin = c->lin, dbg_invalid_left = c->dbg_invalid_left;
+        const int mode = c->mode, cur = c->cur, lin = c->lin, dbg_invalid_left = c->dbg_invalid_left, iter = c->iter;
         const double c_mu = c->mu, radius = c->radius;
+        const double recv = v.cand_rec[lane & 15]; // the candidate records of both iteration parities (Dims::reuse_cand), one double per lane
         const double c_g2 = c->pose_g2, c_lm_g2 = c->lm_g2, c_gn2 = c->pose_gn2, c_gdot = c->pose_gdot, c_qvv = c->pose_qvv, c_qvy = c->pose_qvy,
                      c_qyy = c->pose_qyy, c_gy = c->pose_gy;
         // (2) partial sums of the landmark back-substitution (<= 64 rows unless the window is large)
@@ -220,7 +221,7 @@ __device__ __forceinline__ void lin_prologue(const View &v, double *lds, Pro *&p
         for (int k = 0; k < 4; ++k) w4[k] = v.sic[4 * f + k];
 
         if (done) { // the solve has terminated: this launch is a no-op slot of the graph; nothing is written
-            if (lane == 0) pro->done = 1, pro->valid = 0;
+            if (lane == 0) pro->done = 1, pro->valid = 0, pro->repeat = 0;
             goto prologue_out;
         }
         double ca = 0, cb = 0;
@@ -262,9 +263,30 @@ __device__ __forceinline__ void lin_prologue(const View &v, double *lds, Pro *&p
             ca = readlane_f64(ca, 0), cb = readlane_f64(cb, 0);
             valid = __builtin_amdgcn_readlane(valid, 0);
         }
+        // ---- Dims::reuse_cand: is this the candidate the last iteration evaluated and rejected? ----
+        // Ceres evaluates it again: after a rejected step DoglegStrategy keeps the Gauss-Newton step and the gradient and only halves the
+        // radius, so while |gn| <= radius the step -- and with it the candidate x (+) step, its cost and its Jacobian -- is bit for bit the one
+        // just rejected (the benchmark window ends in four such iterations, the keyframe solves of the rendered sequence consist of them).
+        // Same coefficients on the same accepted iterate, linearization set and mu = same candidate: nothing of the evaluation is redone, the
+        // partial rows, the reduced system and the candidate buffers of the last launch stand, and k_dense takes the same decision again.
+        int repeat = 0;
+        {
+            const int po = 8 * ((iter + 1) & 1); // the previous iteration's record
+            const double p_ca = readlane_f64(recv, po), p_cb = readlane_f64(recv, po + 1), p_mu = readlane_f64(recv, po + 2), p_lin = readlane_f64(recv, po + 3),
+                         p_cur = readlane_f64(recv, po + 4), p_it = readlane_f64(recv, po + 5), p_ev = readlane_f64(recv, po + 6);
+            repeat = v.dm.reuse_cand && mode == MODE_CANDIDATE && valid && dbg_invalid_left <= 0 && p_ev == 1.0 && p_it == (double)(iter - 1) && p_lin == (double)lin &&
+                     p_cur == (double)cur && p_mu == c_mu && p_ca == ca && p_cb == cb;
+            if (lane == 0 && blockIdx.x == 0 && v.dm.reuse_cand) {
+                double *mine = v.cand_rec + 8 * (iter & 1);
+                mine[0] = ca, mine[1] = cb, mine[2] = c_mu, mine[3] = (double)lin, mine[4] = (double)cur, mine[5] = (double)iter;
+                mine[6] = (mode == MODE_CANDIDATE && valid) ? 1.0 : 0.0;
+                v.cand_rec[16] = repeat ? 1.0 : 0.0;
+                if (repeat) v.ctrl->cand_repeats += 1;
+            }
+        }
         if (lane == 0) {
             pro->mode = mode, pro->cur = cur, pro->lin = lin;
-            pro->valid = valid, pro->done = 0;
+            pro->valid = valid, pro->done = 0, pro->repeat = repeat;
             pro->ca = ca, pro->cb = cb;
             pro->out_set = (mode == MODE_CANDIDATE) ? 1 - lin : lin;
             pro->eval_buf = (mode == MODE_CANDIDATE) ? 1 - cur : cur;
@@ -1080,6 +1102,7 @@ __global__ void __launch_bounds__(kLinThreads) k_linearize(View v) {
     lin_prologue(v, lds, pro);
     PV_STAMP(0, 1);
     if (!pro->valid) return; // terminated solve (no-op slot), or invalid trust-region step: k_dense handles it (HandleInvalidStep)
+    if (pro->repeat) return; // the candidate the last launch evaluated (Dims::reuse_cand): its partial rows and candidate buffers stand
     if (blockIdx.x == 0 && v.dm.n_rot > 0) {
         // rotation priors (RotationPriorFactor, no reference counterpart): one thread per frame, at the evaluation point the
         // prologue left in LDS; k_reduce / k_dense add the 3 x 3 blocks, the gradient and the cost like the IMU / prior terms
@@ -1158,6 +1181,7 @@ __device__ __forceinline__ double reduced_entry_terms(const View &v, double val,
 __global__ void __launch_bounds__(kRedElems *kRedGroups) k_reduce(View v, int nb_red, int phase) {
     // the control word is only needed before anything is written: its load travels together with the partials
     const int ctl_done = v.ctrl->done, ctl_result = v.ctrl->lin_result;
+    if (v.dm.reuse_cand && v.cand_rec[16] != 0.0) return; // k_linearize found the candidate of the last slot again: `red` and the image stand (uniform)
     // Dims::img_scaled: once the Jacobi scaling of the solve exists the image is written as -(C S C) -- entry by entry the product
     // k_dense formed when it loaded the tile, (S_ik (c_i c_k)) negated: what its accumulators hold, so that it loads without touching
     const bool scale_img = v.dm.img_scaled && v.ctrl->scaling_ready;
@@ -3028,6 +3052,11 @@ __device__ void backsub_finalize(const View &v) {
                 c->grad_max = gmax;
                 if (slot >= 0) v.trace[slot].gradient_max_norm = gmax;
                 if (!was_done && gmax <= 1e-10) { // GradientToleranceReached: the iteration k_dense has started does not happen
+                    // INVARIANT: this write races with the landmark workgroups of the same launch, which read c->done at their
+                    // start -- one that starts late may see it and return without its back_part row while others have written theirs.  That is
+                    // allowed because NOTHING reads back_part, gnl or the k_backsub scalars once done is set: k_linearize's prologue returns on
+                    // `done` before it touches them, k_dense's control section returns on it, and the host reads states only.  A consumer that
+                    // is added later must test `done` first, like those do.
                     c->termination = 0, c->done = 1, c->mode = MODE_DONE, c->iter = c->iter - 1;
                 }
             }
@@ -3423,6 +3452,7 @@ __global__ void __launch_bounds__(256) k_reset(View v, const double *fs_init, co
     for (size_t e = i; e < M; e += stride) v.rho[e] = rho_init[e];
     if (blockIdx.x == 0 && threadIdx.x < sizeof(Ctrl) / sizeof(double))
         reinterpret_cast<double *>(v.ctrl)[threadIdx.x] = reinterpret_cast<const double *>(tmpl)[threadIdx.x];
+    if (blockIdx.x == 0 && threadIdx.x < 24) v.cand_rec[threadIdx.x] = (threadIdx.x & 7) == 5 && threadIdx.x < 16 ? -2.0 : 0.0; // no candidate on record
 }
 hipError_t launch_reset(const View &v, const double *fs_init, const double *rho_init, const Ctrl *tmpl, hipStream_t st) {
     int grid = (int)(((size_t)v.dm.M + 255) / 256);

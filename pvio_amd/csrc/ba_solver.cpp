@@ -242,6 +242,9 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st, bool ma
     dm.G_lm = std::max(1, std::min(dm.n_chunks, lm_cus));
     // A workgroup that walks many chunks spends its time in the Schur outer products: those go to the matrix cores then
     dm.lm_mm = lin_mode_ == 2 || (lin_mode_ == 0 && dm.n_chunks > 2 * dm.G_lm);
+    // pvio_hip_opts::reuse_identical_candidates.  Not on landmark shards: their k_reduce feeds an all-reduce that sums IN PLACE, a skipped slot
+    // would add the last slot's sums to themselves.
+    dm.reuse_cand = (reuse_cand_ && !sharded_) ? 1 : 0;
     if (dm.lm_mm) { // contiguous chunk ranges (a range mostly shares one anchor frame): no more workgroups than ranges
         const int per_wg = (dm.n_chunks + dm.G_lm - 1) / dm.G_lm;
         dm.G_lm = std::max(1, (dm.n_chunks + per_wg - 1) / per_wg);
@@ -323,6 +326,7 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st, bool ma
     stage.add(pb->rot_prior_sqrt_info, (size_t)dm.n_rot * 9, &v.rot_W);
     // state + work
     ok &= dev(pool_, "ctrl", 1, &v.ctrl, &grew);
+    ok &= dev(pool_, "cand_rec", 24, &v.cand_rec, &grew);
     ok &= dev(pool_, "fs", 2 * Ns * 16, &v.fs, &grew);
     ok &= dev(pool_, "fs_user", Ns * 16, &v.fs_user, &grew);
     ok &= dev(pool_, "bias0_lin", Ns * 6, &v.bias0_lin, &grew);
@@ -422,6 +426,12 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st, bool ma
             if (it.bytes >= kDirect) it.off = total, total += (it.bytes + 255) & ~(size_t)255;
         char *slab = static_cast<char *>(pool_.get("inputs", total, &grew));
         if (!slab) return fail(PVIO_ERR_OUT_OF_MEMORY, "device allocation failed");
+        if (stage_in_flight_) {
+            // the last upload returned with its staged copy queued and the call that was to synchronize behind it ended early (an error in
+            // solve() / marginalize() before their own synchronization): drain the stream before the staging buffer is written again
+            if (check(hipStreamSynchronize(stream_), "staging buffer still in flight")) return PVIO_ERR_HIP;
+            stage_in_flight_ = false;
+        }
         if (staged > h_stage_cap_) {
             if (h_stage_) (void)hipHostFree(h_stage_);
             h_stage_ = nullptr, h_stage_cap_ = 0;
@@ -452,7 +462,11 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st, bool ma
     // lay (>= 1 MB; some of them temporaries of this function) must have left: wait.  A solve that follows immediately on the same stream
     // (pvio_hip_ba_solve: may_return_early) synchronizes anyway before ITS caller gets the arrays back; the staged part was copied into the
     // pinned buffer above, which is not written again before the next upload.
-    if (may_return_early && !sent_directly) return PVIO_OK;
+    if (may_return_early && !sent_directly) {
+        stage_in_flight_ = true; // the DMA may still be reading h_stage_: the next upload waits for it before it writes there
+        return PVIO_OK;
+    }
+    stage_in_flight_ = false;
     return check(hipStreamSynchronize(stream_), "upload sync");
 }
 
@@ -667,6 +681,7 @@ int BASolver::solve(pvio_ba_summary *sum, pvio_ba_kernel_times *prof, pvio_ba_st
             if (check(hipMemcpyAsync(h_pack_, d_pack, n_pack * sizeof(double), hipMemcpyDeviceToHost, stream_), "results D2H")) return PVIO_ERR_HIP;
         }
         if (check(hipStreamSynchronize(stream_), "solve sync")) return PVIO_ERR_HIP;
+        stage_in_flight_ = false;
         if (h_ctrl_->done || ++rounds > (time_limited ? 16 * (dm.max_iter + 1) : 16)) break;
         // max_solver_time_in_seconds (solver_options.h:30): the state machine runs on the device, so the wall clock is looked at
         // between replays of the slot graph only (one replay covers every iteration of an ordinary solve): NO_CONVERGENCE at
@@ -702,6 +717,7 @@ int BASolver::solve(pvio_ba_summary *sum, pvio_ba_kernel_times *prof, pvio_ba_st
     }
     ++solves_since_upload_;
     if (!h_ctrl_->done) return fail(PVIO_ERR_HIP, "device state machine did not terminate");
+    last_repeats_ = h_ctrl_->cand_repeats;
     float ms = 0;
     (void)hipEventElapsedTime(&ms, ev0_, ev1_);
     if (sum) {
@@ -886,6 +902,7 @@ int BASolver::marginalize(const pvio_ba_problem *pb, const pvio_ba_state *st, in
     if (check(launch_gather(ga, d_back, stream_), "k_gather")) return PVIO_ERR_HIP;
     if (check(hipMemcpyAsync(h_back_, d_back, off_back[8] * sizeof(double), hipMemcpyDeviceToHost, stream_), "D2H")) return PVIO_ERR_HIP;
     if (check(hipStreamSynchronize(stream_), "marginalize sync")) return PVIO_ERR_HIP;
+    stage_in_flight_ = false;
     const auto tm2 = std::chrono::steady_clock::now();
 
     // ---- assemble the 15N information matrix / vector ----

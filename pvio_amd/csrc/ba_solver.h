@@ -39,6 +39,8 @@ class BASolver {
     void set_force_sharded(bool on) { sharded_ = world_ > 1 || on; }
     void set_fault_injection(int fail_factorizations, int invalid_steps) { dbg_fail_ = fail_factorizations, dbg_invalid_ = invalid_steps; }
     void set_linearize_mode(int m) { lin_mode_ = m; }
+    void set_reuse_candidates(bool on) { reuse_cand_ = on; }
+    int last_candidate_repeats() const { return last_repeats_; }
     ~BASolver();
     int upload(const pvio_ba_problem *pb, const pvio_ba_state *st, bool may_return_early = false);   // H2D of the flat problem + initial state
     // runs from the uploaded initial state; `read_back`: the accepted iterate + quality pass land in the caller's arrays as part of the same
@@ -62,6 +64,8 @@ class BASolver {
     bool sharded_; // world_ > 1, or forced for tests: eager launches + all-reduces + assembly from the reduced buffer
     bool use_graph_;
     int lin_mode_ = 0; // pvio_hip_opts::linearize_mode
+    bool reuse_cand_ = false; // pvio_hip_opts::reuse_identical_candidates
+    int last_repeats_ = 0;    // Ctrl::cand_repeats of the last solve
     int dbg_fail_ = 0, dbg_invalid_ = 0; // tests only: forced factorization failures / invalid steps per solve
     hipStream_t stream_ = nullptr;
     hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
@@ -73,6 +77,7 @@ class BASolver {
     int cus_ = 0;
     void *h_stage_ = nullptr; // pinned staging of one upload's inputs
     size_t h_stage_cap_ = 0;
+    bool stage_in_flight_ = false; // upload(may_return_early) left its staged copy queued; cleared by the next stream synchronization
     double *h_back_ = nullptr; // pinned read-back of one marginalization pass
     size_t h_back_cap_ = 0;    // in doubles
     std::vector<double> marg_H_, marg_C_, marg_V_; // host work arrays of a marginalization (15N x 15N, twice 15(N-1) x 15(N-1))

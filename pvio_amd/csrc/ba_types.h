@@ -74,7 +74,8 @@ struct Ctrl {
     double fin_lm_gmax;      // max |b_l| of the accepted linearization (landmark part of the gradient max-norm)
     // Dims::img_scaled: the tile image k_dense factored in this slot was the SCALED, negated system -(C S C) (k_reduce applies the
     // Jacobi scaling once it exists); k_backsub forms v^T S v from the same image and has to know which one it is
-    int32_t img_scaled_now, reserved0;
+    int32_t img_scaled_now;
+    int32_t cand_repeats;    // Dims::reuse_cand: candidate evaluations short-circuited in this solve (written by workgroup 0 of k_linearize)
 };
 enum : int32_t { kFinTrace = 1, kFinAccepted = 2, kFinFirst = 4 };
 
@@ -104,6 +105,7 @@ struct Dims {
     int32_t dense_la;     // register-resident factorization in its look-ahead form (wave 0 factors panel p + 1 while waves 1..3 apply panel p)
     int32_t img_scaled;   // look-ahead form: once the Jacobi scaling exists (after the first factoring launch of a solve) k_reduce writes the
                           // image as -(C S C), the form the accumulators hold, and k_dense loads it without touching it (Ctrl::img_scaled_now)
+    int32_t reuse_cand;   // a candidate that is bit-identical to the one just rejected is not evaluated again (View::cand_rec)
     int32_t lm_mm;        // landmark workgroups accumulate the Schur complement as 16x16 f64 MFMA tiles and walk a contiguous chunk range
 };
 
@@ -153,6 +155,9 @@ struct View { // passed by value to every kernel
     double *img;       // the unscaled reduced system as a tile image (lower block triangle, MFMA accumulator order), written by
                        // k_reduce; zero wherever nothing is ever written
     double *cp, *Dp, *gtot, *ghp, *vstep, *ystep; // [P] each
+    // Dims::reuse_cand: [2][8] the candidate of the last two trust-region iterations by iteration parity -- ca, cb, mu, lin, cur, iteration, evaluated,
+    // unused -- written by workgroup 0 of k_linearize, read by every workgroup of the NEXT launch; [16] = this slot repeats the last candidate
+    double *cand_rec;
     double *cpl, *vraw; // [P] each: Jacobi scale with 0 on inactive coordinates (img_scaled: read by k_reduce); v = g^ / D before C is applied
     // trace
     TraceRec *trace;

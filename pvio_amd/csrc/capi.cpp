@@ -37,7 +37,7 @@ int32_t pvio_hip_create(const pvio_hip_opts *opts, pvio_hip_ctx **out) {
     if (!c) return PVIO_ERR_OUT_OF_MEMORY;
     c->opts = o;
     c->ba = new (std::nothrow) pvba::BASolver(o.device, o.rank, o.world_size, o.use_graph != 0);
-    if (c->ba) c->ba->set_fault_injection(o.debug_fail_factorizations, o.debug_invalid_steps), c->ba->set_linearize_mode(o.linearize_mode), c->ba->set_force_sharded(o.debug_force_sharded != 0);
+    if (c->ba) c->ba->set_fault_injection(o.debug_fail_factorizations, o.debug_invalid_steps), c->ba->set_linearize_mode(o.linearize_mode), c->ba->set_force_sharded(o.debug_force_sharded != 0), c->ba->set_reuse_candidates(o.reuse_identical_candidates != 0);
     c->klt = new (std::nothrow) pvklt::Klt(o.device);
     if (!c->ba || !c->klt) {
         pvio_hip_destroy(c);
@@ -75,6 +75,7 @@ int32_t pvio_hip_ba_profile_resident(pvio_hip_ctx *ctx, pvio_ba_summary *summary
     if (!ctx || !times) return PVIO_ERR_INVALID_ARGUMENT;
     return ctx->ba->solve(summary, times);
 }
+int32_t pvio_hip_ba_last_candidate_repeats(const pvio_hip_ctx *ctx) { return ctx && ctx->ba ? ctx->ba->last_candidate_repeats() : 0; }
 int32_t pvio_hip_ba_download(pvio_hip_ctx *ctx, pvio_ba_state *state) {
     if (!ctx) return PVIO_ERR_INVALID_ARGUMENT;
     return ctx->ba->download(state);

@@ -43,6 +43,10 @@ pvio_hip_ctx *process_ctx() {
         pvio_hip_opts o;
         std::memset(&o, 0, sizeof o);
         o.world_size = 1, o.use_graph = 1;
+        // A candidate that is bit-identical to the one just rejected is not evaluated again (include/pvio_hip.h): same iterations, records and
+        // results as the reference, which does re-evaluate it; PVIO_HIP_REUSE_CANDIDATES=0 turns it off.
+        const char *reuse = std::getenv("PVIO_HIP_REUSE_CANDIDATES");
+        o.reuse_identical_candidates = (reuse && std::atoi(reuse) == 0) ? 0 : 1;
         if (const char *dev = std::getenv("PVIO_HIP_DEVICE")) o.device = std::atoi(dev); // one ctx per process and GPU
         if (pvio_hip_create(&o, &ctx) != PVIO_OK) {
             std::fprintf(stderr, "[pvio-hip] no usable GPU context: BundleAdjustor::solve will report failure\n");

@@ -16,13 +16,14 @@ class HipError(RuntimeError):
 
 class HipContext:
     def __init__(self, device=0, rank=0, world_size=1, use_graph=True, lib=None, debug_fail_factorizations=0, debug_invalid_steps=0,
-                 linearize_mode=0, force_sharded=False):
+                 linearize_mode=0, force_sharded=False, reuse_identical_candidates=False):
         self.lib = lib or capi.load()
         opts = capi.HipOpts()
         opts.device, opts.rank, opts.world_size, opts.use_graph = device, rank, world_size, int(use_graph)
         opts.debug_fail_factorizations, opts.debug_invalid_steps = debug_fail_factorizations, debug_invalid_steps  # tests only
         opts.linearize_mode = linearize_mode
         opts.debug_force_sharded = int(force_sharded)
+        opts.reuse_identical_candidates = int(reuse_identical_candidates)  # pvio_hip_opts: skip re-evaluating a bit-identical rejected candidate
         self.ctx = C.c_void_p()
         rc = self.lib.pvio_hip_create(C.byref(opts), C.byref(self.ctx))
         if rc != 0:
@@ -60,6 +61,11 @@ class HipContext:
         self._keep = (problem, state)
         self._check(self.lib.pvio_hip_ba_upload(self.ctx, C.byref(pb), C.byref(st)), "pvio_hip_ba_upload")
         return state
+
+    def last_candidate_repeats(self):
+        """candidate evaluations the last solve short-circuited (reuse_identical_candidates)"""
+        self.lib.pvio_hip_ba_last_candidate_repeats.argtypes = [C.c_void_p]
+        return int(self.lib.pvio_hip_ba_last_candidate_repeats(self.ctx))
 
     def solve_resident(self, summary):
         self._check(self.lib.pvio_hip_ba_solve_resident(self.ctx, C.byref(summary.c)), "pvio_hip_ba_solve_resident")

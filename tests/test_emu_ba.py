@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import ba_compare
-from pvio_amd import capi
+from pvio_amd import BASummary, capi
 from pvio_amd.solver import HipContext
 
 EMU_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hipemu")
@@ -211,3 +211,39 @@ def test_emulated_one_rank_sharded_path(oracle):
     finally:
         ctx.close()
         lib.hipemu_set_allreduce(C.cast(None, C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_long, C.c_int)))
+
+
+# ---- pvio_hip_opts::reuse_identical_candidates: a candidate that is bit-identical to the one just rejected is not evaluated again ---------
+REUSE_CASES = {  # (window, candidate evaluations the short-circuit must save: the runs of consecutive rejections with |gn| <= radius in its trace)
+    "vio_partial": 2, "vio_zero_bias_quirk": 4, "vio_plane": 1, "vision_partial": 0, "vio_rot_prior": None, "vio_duplicate_blocks": None,
+}
+
+
+@pytest.fixture(scope="module")
+def emu_ctx_reuse(emu_ctx):
+    ctx = HipContext(lib=emu_ctx.lib, use_graph=True, reuse_identical_candidates=True)
+    yield ctx
+    ctx.close()
+
+
+@pytest.mark.parametrize("name", sorted(REUSE_CASES))
+def test_emulated_identical_candidates_are_not_evaluated_twice(emu_ctx_reuse, oracle, name):
+    """same iterations, same records, same states after every iteration as the oracle (which, like Ceres, evaluates every candidate), with the
+    repeated evaluations skipped"""
+    pb = ba_compare.make(oracle, **ba_compare.CASES[name])
+    ba_compare.check_against_oracle(emu_ctx_reuse, oracle, pb)
+    if REUSE_CASES[name] is not None:
+        assert emu_ctx_reuse.last_candidate_repeats() == REUSE_CASES[name]
+
+
+def test_emulated_identical_candidates_metric_window(emu_ctx_reuse, oracle):
+    """the window the metric is quoted on ends in four rejections of ONE candidate (|gn| = 0.053 << radius): three evaluations saved, nothing else changes;
+    and a resident re-solve starts from a clean record"""
+    pb = ba_compare.make(oracle, **ba_compare.BIG_CASES["metric_10x1000_vio"])
+    ba_compare.check_against_oracle(emu_ctx_reuse, oracle, pb)
+    assert emu_ctx_reuse.last_candidate_repeats() == 3
+    emu_ctx_reuse.upload(pb)
+    for _ in range(2):
+        sm = BASummary(pb, trace=False)
+        emu_ctx_reuse.solve_resident(sm)
+        assert sm.num_iterations == 10 and emu_ctx_reuse.last_candidate_repeats() == 3

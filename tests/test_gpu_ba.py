@@ -347,3 +347,42 @@ def test_gpu_solver_reads_no_stale_lds_or_registers(gpu_ctx, oracle, name):
         assert L.lds_poison(pat) == 0 and R.reg_poison(pat) == 0
         st1, _ = gpu_ctx.solve(pb)
         assert (st1.frame_state == st0.frame_state).all() and (st1.lm_inv_depth == st0.lm_inv_depth).all(), (name, val, base)
+
+
+# ---- pvio_hip_opts::reuse_identical_candidates -----------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def gpu_ctx_reuse():
+    from pvio_amd.solver import HipContext
+    ctx = HipContext(device=0, use_graph=True, reuse_identical_candidates=True)
+    yield ctx
+    ctx.close()
+
+
+@pytest.mark.parametrize("name,saved", [("vio_partial", 2), ("vio_zero_bias_quirk", 4), ("vio_plane", 1), ("vision_partial", 0), ("vio_rot_prior", None),
+                                        ("vio_duplicate_blocks", None), ("vio_13_frames_global_matrix", None)])
+def test_gpu_identical_candidates_are_not_evaluated_twice(gpu_ctx_reuse, oracle, name, saved):
+    """a candidate that is bit-identical to the one just rejected is not evaluated again: same iterations, records and per-iteration states as the
+    oracle, which -- like Ceres -- evaluates every candidate"""
+    pb = ba_compare.make(oracle, **ba_compare.CASES[name])
+    print(name, ba_compare.check_against_oracle(gpu_ctx_reuse, oracle, pb), "evaluations saved:", gpu_ctx_reuse.last_candidate_repeats())
+    if saved is not None:
+        assert gpu_ctx_reuse.last_candidate_repeats() == saved
+
+
+def test_gpu_identical_candidates_metric_window_and_resident_repeats(gpu_ctx_reuse, gpu_ctx, oracle):
+    """the metric window: three of its ten candidate evaluations are repeats; resident re-solves are bit-identical to each other and to the solves of
+    a context that evaluates everything"""
+    pb = ba_compare.make(oracle, **ba_compare.BIG_CASES["metric_10x1000_vio"])
+    ba_compare.check_against_oracle(gpu_ctx_reuse, oracle, pb)
+    assert gpu_ctx_reuse.last_candidate_repeats() == 3
+    outs = []
+    for ctx in (gpu_ctx, gpu_ctx_reuse):
+        ctx.upload(pb)
+        for _ in range(5):
+            sm = BASummary(pb, trace=False)
+            ctx.solve_resident(sm)
+            st = BAState(pb)
+            ctx.download(st)
+            outs.append((st.frame_state.copy(), st.lm_inv_depth.copy(), sm.final_cost, sm.num_iterations))
+    for o in outs[1:]:
+        assert (o[0] == outs[0][0]).all() and (o[1] == outs[0][1]).all() and o[2] == outs[0][2] and o[3] == outs[0][3]

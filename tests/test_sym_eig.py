@@ -71,3 +71,15 @@ def test_dispatcher_reports_its_build():
     fn = getattr(lib, "_ZN4pvba11sym_eig_isaEv")
     fn.restype = C.c_char_p
     assert fn().decode() == ("avx2" if _has_avx2() else "generic")
+
+
+@pytest.mark.parametrize("name", sorted(_matrices()))
+def test_both_builds_are_bit_identical(name):
+    """both builds are compiled -ffp-contract=off, so the instruction set the dispatcher picks changes the speed and nothing else -- the
+    prior of a marginalization (and which of its eigenvalues fall under the reference's 1e-8 cut, bundle_adjustor.cpp:586-587) does not depend on the host"""
+    if not _has_avx2():
+        pytest.skip("host without AVX2+FMA")
+    A = _matrices()[name]
+    wa, Va = _eig("generic", A)
+    wb, Vb = _eig("avx2", A)
+    assert (wa == wb).all() and (Va == Vb).all()
