@@ -500,7 +500,7 @@ def main():
     # the dense kernel against the only roofline it has, FP64 arithmetic: P^3 / 3 + 2 P^2 flops (Cholesky of the reduced system with the
     # right-hand side carried along + back substitution) per FACTORING launch.  Its average duration over all launches of a solve
     # (rejected steps do not factor) is a lower bound of a factoring launch's: the fraction quoted is an upper bound -- and still
-    # ~1e-4: one workgroup on one CU, a chain of P dependent pivots.
+    # ~1e-4: one workgroup on one CU, a chain of P dependent pivots (profiles/NOTES_r1_r3.md section 4).
     Pd = (15 if vio else 6) * n_frames
     dense_flops = Pd ** 3 / 3.0 + 2.0 * Pd ** 2
     dense_s = roofline["kernel_us"]["k_dense"] * 1e-6
@@ -510,7 +510,7 @@ def main():
                       "note": "dtype f64 on the FP64 matrix cores (v_mfma_f64_16x16x4_f64) + FP64 VALU; one workgroup: a serial dependency chain, not a throughput kernel"}
     if n_lm >= 10000:
         roofline["note"] = ("large window: k_linearize is FP64-issue bound (factor evaluation on the VALU + Schur complement on the f64 matrix "
-                            "cores), not HBM bound; see DESIGN.md section 5")
+                            "cores), not HBM bound; see profiles/NOTES_r1_r3.md section 5")
 
     # ---- scaling window: the window north_star's multi-GPU sentence names (10 KF x 50 000 landmarks, full factor set),
     # sharded exactly like the headline window, same context and communicator; a few solves, barrier-bracketed ----

@@ -184,7 +184,7 @@ __device__ __forceinline__ void lin_prologue(const View &v, double *lds, Pro *&p
     // load costs a trip through the fabric: ALL of them are requested up front, whatever the mode turns out to be (control
     // block, back-substitution partials, both state buffers of this lane's frame, both step vectors, the static frame
     // data), then used -- one trip instead of the three dependent ones of "read the mode, then the partials, then the
-    // states" (10.3k -> see DESIGN section 5).  The dogleg scalars stay in lane 0; ca / cb / valid reach the frame lanes by
+    // states" (10.3k -> see profiles/NOTES_r1_r3.md section 5).  The dogleg scalars stay in lane 0; ca / cb / valid reach the frame lanes by
     // lane reads, so the only barrier is the one that publishes the records to the other waves.
     if (tid < 64) {
         const Ctrl *c = v.ctrl;
@@ -2539,7 +2539,7 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
                 }
                 // Every column's operand is requested UNCONDITIONALLY (dead columns read row block b0 like dead rows do).  Round 2 had
                 // eleven uniform `if (g < R)` branches around these loads; with them, the DEscending request order compiled to a
-                // k_dense whose results were wrong on the GPU (emulator fine).  Round 3 characterized it (DESIGN.md section 4,
+                // k_dense whose results were wrong on the GPU (emulator fine).  Round 3 characterized it (profiles/NOTES_r1_r3.md section 4,
                 // tests/micro/order_probe.py, profiles/r3_kdense_order_probe_*.txt): deterministic, independent of LDS / register
                 // contents, gone when SGPRs spill to scratch instead of VGPR lanes and gone -- in BOTH orders -- without the
                 // branches.  The branch-free form is what ships; it also drops eleven scalar branches per panel.

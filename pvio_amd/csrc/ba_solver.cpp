@@ -990,7 +990,7 @@ int BASolver::marginalize(const pvio_ba_problem *pb, const pvio_ba_state *st, in
     // Coordinates without any information -- an exactly zero row and column: velocity / biases of a frame no IMU factor or prior reaches --
     // are eigenvectors of eigenvalue 0 by themselves and stay out of the eigen-problem: a backward-stable solver would hand them back with
     // an eigenvalue of a few eps |C| and a few eps of every other coordinate mixed in, which the 1e-8 cut then keeps or drops as the rounding
-    // falls.  Their rows of S are zero (they come first, like the zero eigenvalues of the full problem).
+    // falls (profiles/NOTES_r1_r3.md section 2a).  Their rows of S are zero (they come first, like the zero eigenvalues of the full problem).
     std::vector<int> keep;
     keep.reserve(R);
     for (int i = 0; i < R; ++i) {

@@ -7,7 +7,7 @@
 // and of the accumulation of the reflectors runs over contiguous memory too (the EISPACK column-major organisation with
 // the roles of the indices exchanged).  Reductions use four partial sums so that they vectorize without -ffast-math.
 // Measured on the GPU box's host, 135 x 135 marginalization matrix: 1000 us with the strided round-2 layout -> see
-// DESIGN.md section 5.
+// profiles/NOTES_r1_r3.md section 5.
 #pragma once
 
 namespace pvba {

@@ -1,6 +1,6 @@
 """Third-party pins for the CPU oracle (scipy is in the image; Ceres / OpenCV / Eigen are not).
 
-The oracle restates the reference's arithmetic and cannot be checked against the reference itself (DESIGN.md section 2:
+The oracle restates the reference's arithmetic and cannot be checked against the reference itself (profiles/NOTES_r1_r3.md section 2:
 parity unpinned).  Where an INDEPENDENT third-party implementation of the same mathematical object exists in this image it
 is used here as a pin -- not a pin to Ceres or OpenCV, but to code nobody in this repository wrote:
 
