@@ -238,3 +238,26 @@ def test_gpu_dropin_marginalize_on_reference_map(ref, gpu, oracle, victim):  # n
 def test_gpu_dropin_keyframe_cycle_on_reference_map(ref, gpu, oracle):  # noqa: F811
     print(diff_cycle(ref, gpu, oracle, n_frames=7, n_landmarks=120, use_inertial=True, visibility=5))
     print(diff_cycle(ref, gpu, oracle, n_frames=10, n_landmarks=300, use_inertial=True, visibility=6))
+
+
+def _random_window(oracle, seed):
+    """the shapes of tests/sweep_random_dropin.py"""
+    rng = np.random.default_rng(8000 + seed)
+    n = int(rng.integers(3, 13))
+    kw = dict(n_frames=n, n_landmarks=int(rng.integers(20, 400)), use_inertial=bool(rng.integers(0, 2)), visibility=int(rng.integers(2, n + 1)),
+              plane_fraction=float(rng.choice([0.0, 0.0, 0.3, 0.5])), seed=int(rng.integers(1, 10000)))
+    if rng.random() < 0.25:
+        kw["duplicate_fraction"] = 0.3
+        kw["plane_fraction"] = 0.0
+    return ba_compare.make(oracle, **kw)
+
+
+@pytest.mark.parametrize("seed", [5, 9, 18])
+def test_emulated_dropin_random_windows_on_reference_map(ref, emu, oracle, seed):  # noqa: F811
+    print(seed, diff_solve(ref, emu, _random_window(oracle, seed)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [0, 3, 5, 7, 9, 11, 14, 16, 18, 22])
+def test_gpu_dropin_random_windows_on_reference_map(ref, gpu, oracle, seed):  # noqa: F811
+    print(seed, diff_solve(ref, gpu, _random_window(oracle, seed)))
