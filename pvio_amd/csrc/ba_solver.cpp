@@ -34,15 +34,19 @@ void *DevicePool::get(const char *name, size_t bytes, bool *grew) {
             (void)hipFree(s.ptr);
             total_ -= s.bytes;
             s.ptr = nullptr;
-            const size_t nb = bytes + bytes / 4;
+            const size_t nb = bytes + bytes / 2;
             if (hipMalloc(&s.ptr, nb) != hipSuccess) return nullptr;
             s.bytes = nb;
             total_ += nb;
             if (grew) *grew = true;
             return s.ptr;
         }
+    // Headroom from the first allocation on: the windows of a sequence change shape with every keyframe (landmarks +-30 %), and a slot that is
+    // sized exactly is freed and allocated again -- ~40 slots x (hipFree + hipMalloc) showed up as 0.3-0.4 ms on individual keyframe solves of the
+    // rendered sequence (profiles/r4_prof_sequence_solves.txt).  288 GB of HBM: 50 % slack on the largest window (30 x 50 000: 0.4 GB) is nothing.
     Slot s;
     s.name = name;
+    bytes = bytes + bytes / 2 < 4096 ? 4096 : bytes + bytes / 2;
     if (hipMalloc(&s.ptr, bytes) != hipSuccess) return nullptr;
     s.bytes = bytes;
     total_ += bytes;
@@ -435,7 +439,7 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st, bool ma
         if (staged > h_stage_cap_) {
             if (h_stage_) (void)hipHostFree(h_stage_);
             h_stage_ = nullptr, h_stage_cap_ = 0;
-            const size_t cap = staged + staged / 4;
+            const size_t cap = staged + staged / 2; // (pinned host memory is the expensive allocation: headroom for the next windows of the sequence)
             if (hipHostMalloc(&h_stage_, cap) != hipSuccess) return fail(PVIO_ERR_OUT_OF_MEMORY, "hipHostMalloc failed");
             h_stage_cap_ = cap;
         }
@@ -578,7 +582,7 @@ int BASolver::solve(pvio_ba_summary *sum, pvio_ba_kernel_times *prof, pvio_ba_st
         if (n_pack > h_pack_cap_) {
             if (h_pack_) (void)hipHostFree(h_pack_);
             h_pack_ = nullptr, h_pack_cap_ = 0;
-            const size_t cap = n_pack + n_pack / 4;
+            const size_t cap = n_pack + n_pack / 2;
             if (hipHostMalloc(reinterpret_cast<void **>(&h_pack_), cap * sizeof(double)) != hipSuccess) return fail(PVIO_ERR_OUT_OF_MEMORY, "hipHostMalloc failed");
             h_pack_cap_ = cap;
         }
@@ -880,7 +884,7 @@ int BASolver::marginalize(const pvio_ba_problem *pb, const pvio_ba_state *st, in
     if (off_back[8] > h_back_cap_) {
         if (h_back_) (void)hipHostFree(h_back_);
         h_back_ = nullptr, h_back_cap_ = 0;
-        const size_t cap = off_back[8] + off_back[8] / 4;
+        const size_t cap = off_back[8] + off_back[8] / 2;
         if (hipHostMalloc(reinterpret_cast<void **>(&h_back_), cap * sizeof(double)) != hipSuccess) return fail(PVIO_ERR_OUT_OF_MEMORY, "hipHostMalloc failed");
         h_back_cap_ = cap;
     }
