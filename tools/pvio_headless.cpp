@@ -1,6 +1,7 @@
 // pvio_headless -- the sequence loop of pvio-pc (pvio-pc/src/main.cpp:207-258) without GUI, OpenCV, Ceres or yaml-cpp:
 //   DatasetReader::next() -> read_gyroscope / read_accelerometer / read_image -> HeadlessVio::track_* -> trajectory.tum
-// Usage: pvio_headless <euroc://DIR | tum://DIR> <ground_truth.tum> [trajectory.tum] [max_frames]
+// Usage: pvio_headless <euroc://DIR | tum://DIR> <ground_truth.tum> [trajectory.tum] [max_frames] [window] [keyframe_gap]
+//   window / keyframe_gap: sliding_window_size and initializer_keyframe_gap (config yaml: 8 and 5); short test sequences pass smaller ones
 //   ground_truth.tum  "t px py pz qx qy qz qw" lines (body poses): used ONLY to bootstrap the first window, in place of the
 //                     reference's SfM initializer (see tests/host/standin/headless.h)
 // Camera / IMU constants are those of config/euroc.yaml and config/tum-vi.yaml, chosen by the URI scheme.
@@ -18,7 +19,7 @@ using namespace pvio;
 
 int main(int argc, char **argv) {
     if (argc < 3) {
-        std::fprintf(stderr, "usage: %s <euroc://DIR|tum://DIR> <ground_truth.tum> [trajectory.tum] [max_frames]\n", argv[0]);
+        std::fprintf(stderr, "usage: %s <euroc://DIR|tum://DIR> <ground_truth.tum> [trajectory.tum] [max_frames] [window] [keyframe_gap]\n", argv[0]);
         return 2;
     }
     const std::string uri = argv[1], out_path = argc > 3 ? argv[3] : "trajectory.tum";
@@ -36,6 +37,8 @@ int main(int argc, char **argv) {
         auto reader = DatasetReader::create_reader(uri, ctx);
         if (!reader) throw std::runtime_error("unknown dataset scheme: " + uri);
         auto config = uri.rfind("euroc://", 0) == 0 ? HeadlessConfig::euroc() : HeadlessConfig::tum_vi();
+        if (argc > 5 && std::atol(argv[5]) >= 2) config->window = (size_t)std::atol(argv[5]);
+        if (argc > 6 && std::atol(argv[6]) >= 1) config->keyframe_gap = (size_t)std::atol(argv[6]);
         HeadlessVio vio(config);
         {
             std::ifstream gt(argv[2]);
