@@ -45,11 +45,24 @@ def _relief(u, v):
     return 0.25 * np.sin(4.1 * u + 0.3) * np.cos(3.3 * v - 0.8) + 0.2 * np.sin(2.2 * u - 1.9 * v + 1.1)
 
 
-def _undistorted_rays(us, vs, K4, dist):
+def _undistorted_rays(us, vs, K4, dist, model="radtan"):
     """normalized pinhole coordinates (x, y) of the scene point seen at DISTORTED pixel (u, v) under OpenCV's radial-tangential model
-    (k1, k2, p1, p2): the inverse of x_d = x (1 + k1 r2 + k2 r4) + 2 p1 x y + p2 (r2 + 2 x^2), ... by fixed-point iteration (cv::undistortPoints)"""
-    k1, k2, p1, p2 = dist
+    (k1, k2, p1, p2): the inverse of x_d = x (1 + k1 r2 + k2 r4) + 2 p1 x y + p2 (r2 + 2 x^2), ... by fixed-point iteration (cv::undistortPoints);
+    model "equidistant" (Kannala-Brandt, image_undistorter.h:78-93): theta_d = theta (1 + k1 theta^2 + ... + k4 theta^8) inverted by Newton steps"""
     xd, yd = (us - K4[2]) / K4[0], (vs - K4[3]) / K4[1]
+    if model == "equidistant":
+        k1, k2, k3, k4 = dist
+        rd = np.sqrt(xd * xd + yd * yd)
+        th = rd.copy()
+        for _ in range(10):
+            t2 = th * th
+            f = th * (1 + t2 * (k1 + t2 * (k2 + t2 * (k3 + t2 * k4)))) - rd
+            df = 1 + t2 * (3 * k1 + t2 * (5 * k2 + t2 * (7 * k3 + t2 * 9 * k4)))
+            th = th - f / df
+        th = np.minimum(th, 1.45)  # rays beyond ~83 degrees see nothing sensible of the wall
+        sc = np.where(rd > 1e-12, np.tan(th) / np.maximum(rd, 1e-12), 1.0)
+        return xd * sc, yd * sc
+    k1, k2, p1, p2 = dist
     x, y = xd.copy(), yd.copy()
     for _ in range(12):
         r2 = x * x + y * y
@@ -60,7 +73,7 @@ def _undistorted_rays(us, vs, K4, dist):
     return x, y
 
 
-def render_sequence(n_frames, fps=20.0, imu_rate=200.0, t_start=0.0, size=None, relief=False, distortion=None):
+def render_sequence(n_frames, fps=20.0, imu_rate=200.0, t_start=0.0, size=None, relief=False, distortion=None, model="radtan", extrinsics=None):
     """images (n, H, W) u8, image times, IMU (t, w, a), body poses at the image times (t p q).  relief: the textured surface is the wall plus _relief()
     (ray / surface intersection by fixed-point iteration) instead of the wall itself: a scene without planes."""
     W, H, K4 = size if size is not None else (globals()["W"], globals()["H"], globals()["K4"])
@@ -72,17 +85,24 @@ def render_sequence(n_frames, fps=20.0, imu_rate=200.0, t_start=0.0, size=None, 
     fwd = R_mid[:, 2]
     tilt = np.deg2rad(20.0)
     nrm = np.cos(tilt) * fwd + np.sin(tilt) * R_mid[:, 1]
+    d = 0.0  # n . X = 0: the plane passes through the orbit centre (the origin)
+    if extrinsics is not None:  # another rig (q_bc xyzw, p_bc): the wall is set up against THAT camera's axes, 3 m in front of it at mid-sequence
+        q_bc = np.asarray(extrinsics[0], float) / np.linalg.norm(extrinsics[0])
+        R_bc, p_bc = synth.qmat(q_bc), np.asarray(extrinsics[1], float)
+        Rc = R_mid @ R_bc
+        fwd = Rc[:, 2]
+        nrm = np.cos(tilt) * fwd + np.sin(tilt) * Rc[:, 0]
+        d = float(nrm @ (p_mid + R_mid @ p_bc + 3.0 * fwd)) / np.linalg.norm(nrm)
     nrm /= np.linalg.norm(nrm)
     e1 = np.cross(nrm, np.array([0.0, 0.0, 1.0]))
     e1 /= np.linalg.norm(e1)
     e2 = np.cross(nrm, e1)
-    d = 0.0  # n . X = 0: the plane passes through the orbit centre (the origin)
     tex = _texture()
     us, vs = np.meshgrid(np.arange(W, dtype=float), np.arange(H, dtype=float))
     if distortion is None:
         rays_c = np.stack([(us - K4[2]) / K4[0], (vs - K4[3]) / K4[1], np.ones_like(us)], -1)
     else:  # the images a camera with this lens records: a reader that undistorts them (cv::undistort with the same K) recovers the pinhole image
-        xn, yn = _undistorted_rays(us, vs, K4, distortion)
+        xn, yn = _undistorted_rays(us, vs, K4, distortion, model)
         rays_c = np.stack([xn, yn, np.ones_like(us)], -1)
     rng = np.random.default_rng(5)
     images, times, poses = [], [], []
@@ -156,29 +176,35 @@ def test_headless_pipeline_follows_the_rendered_trajectory():
 
 
 @pytest.mark.gpu
-def test_headless_binary_on_a_euroc_layout_sequence(tmp_path):
+@pytest.mark.parametrize("kind", ["euroc", "tum"])
+def test_headless_binary_on_a_dataset_layout_sequence(tmp_path, kind):
     """BASELINE configs[0]'s plumbing with the actual binary (tools/pvio_headless.cpp, the sequence loop of pvio-pc/src/main.cpp:207-258): a sequence ON DISK in
     EuRoC's layout -- cam0/data.csv + cam0/data/<ns>.png recorded through EuRoC's lens (752 x 480, the intrinsics and radial-tangential coefficients of
     euroc_dataset_reader.cpp:73-74), imu0/data.csv at 200 Hz, CRLF line ends -- goes through the readers (CSV, PNG decode), the device undistortion, the front
-    end, PnP and the sliding-window BA, and comes out as trajectory.tum (output_writer.h:41-50 format), which follows the ground truth."""
+    end, PnP and the sliding-window BA, and comes out as trajectory.tum (output_writer.h:41-50 format), which follows the ground truth.
+    kind "tum": TUM-VI's layout and camera (512 x 512 equidistant fisheye, tum_dataset_reader.cpp:73-81, LF line ends)."""
     import os
     import subprocess
     import test_host_ingest as ing
     host_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host")
     subprocess.check_call(["make", "-s", "-C", host_dir, "pvio_headless"])
-    n_frames, W_, H_ = 36, 752, 480
-    K4e = np.array([458.654, 457.296, 367.215, 248.375])
-    images, times, imu_t, imu_w, imu_a, gt, q_bc, p_bc = render_sequence(n_frames, size=(W_, H_, K4e), relief=True, distortion=ing.EUROC_D)
+    n_frames = 36
+    if kind == "euroc":
+        W_, H_, K4e, dist, model, ext = 752, 480, np.array([458.654, 457.296, 367.215, 248.375]), ing.EUROC_D, "radtan", None
+    else:  # config/tum-vi.yaml:13-22
+        W_, H_, K4e, dist, model = 512, 512, np.array([ing.TUM_K[0], ing.TUM_K[4], ing.TUM_K[2], ing.TUM_K[5]]), ing.TUM_D, "equidistant"
+        ext = ([-0.013272, -0.694726, 0.719112, 0.007648], [0.04536566, -0.071996, -0.04478181])
+    images, times, imu_t, imu_w, imu_a, gt, q_bc, p_bc = render_sequence(n_frames, size=(W_, H_, K4e), relief=True, distortion=dist, model=model, extrinsics=ext)
     t0 = 20_000_000_000  # ns
     cam_ns = [t0 + int(round(t * 1e9)) for t in times]
     imu_rows = [(t0 + int(round(t * 1e9)), *w, *a) for t, w, a in zip(imu_t, imu_w, imu_a)]
     root = tmp_path / "mav0"
-    ing._write_sequence(root, True, list(images), cam_ns, imu_rows)
+    ing._write_sequence(root, kind == "euroc", list(images), cam_ns, imu_rows)
     gt_path, out_path = tmp_path / "gt.tum", tmp_path / "trajectory.tum"
     with open(gt_path, "w") as f:
         for g in gt:
             f.write(" ".join(repr(float(v)) for v in ([g[0] + t0 * 1e-9] + list(g[1:]))) + "\n")
-    r = subprocess.run([os.path.join(host_dir, "pvio_headless"), "euroc://" + str(root), str(gt_path), str(out_path), "-1", "6", "3"], capture_output=True, text=True,
+    r = subprocess.run([os.path.join(host_dir, "pvio_headless"), kind + "://" + str(root), str(gt_path), str(out_path), "-1", "6", "3"], capture_output=True, text=True,
                        timeout=600)  # window of 6 keyframes 3 frames apart: the first window exists at frame 15 of the 36
     assert r.returncode == 0, r.stderr[-2000:]
     print(r.stderr.strip().splitlines()[-1])
@@ -189,6 +215,6 @@ def test_headless_binary_on_a_euroc_layout_sequence(tmp_path):
     idx = [int(np.argmin(np.abs(gt[:, 0] + t0 * 1e-9 - t))) for t in tum[:, 0]]
     assert np.abs(gt[idx, 0] + t0 * 1e-9 - tum[:, 0]).max() < 1e-6
     err = np.linalg.norm(tum[:, 1:4] - gt[idx, 1:4], axis=1)
-    print("pvio_headless on the EuRoC-layout sequence: %d poses, position error cm: median %.2f max %.2f; %s" % (
+    print("pvio_headless on the " + kind + "-layout sequence: %d poses, position error cm: median %.2f max %.2f; %s" % (
         len(tum), 100 * np.median(err), 100 * err.max(), r.stderr.strip().splitlines()[-1]))
     assert np.median(err) < 0.05 and err.max() < 0.12
