@@ -193,7 +193,10 @@ __device__ __forceinline__ void lin_prologue(const View &v, double *lds, Pro *&p
         const int done = c->done; // (tested after everything has been requested: a test up front is a fabric trip of its own)
         const int mode = c->mode, cur = c->cur, lin = c->lin, dbg_invalid_left = c->dbg_invalid_left, iter = c->iter;
         const double c_mu = c->mu, radius = c->radius;
-        const double recv = v.cand_rec[lane & 15]; // the candidate records of both iteration parities (Dims::reuse_cand), one double per lane
+        // the candidate records of both iteration parities (Dims::reuse_cand), one double per lane.  Workgroup 0 of THIS launch rewrites the record of
+        // this iteration's parity while other workgroups may still be loading it: only the OTHER parity's values are used below (a read of a word that
+        // is being overwritten by a value nobody looks at)
+        const double recv = v.cand_rec[lane & 15];
         const double c_g2 = c->pose_g2, c_lm_g2 = c->lm_g2, c_gn2 = c->pose_gn2, c_gdot = c->pose_gdot, c_qvv = c->pose_qvv, c_qvy = c->pose_qvy,
                      c_qyy = c->pose_qyy, c_gy = c->pose_gy;
         // (2) partial sums of the landmark back-substitution (<= 64 rows unless the window is large)
