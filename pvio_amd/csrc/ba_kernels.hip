@@ -149,6 +149,21 @@ __device__ __forceinline__ void block_sum(double *vals, double *scratch) {
 }
 
 constexpr int kPanel = 8; // Cholesky panel width (= K of two f64 MFMAs)
+// The factor wave of the look-ahead form is bound by the NUMBER of instructions it issues per panel (one wave on its SIMD, ~4.6 cycles per FP64
+// instruction, tools/ubench/wave_costs.hip; neither the reciprocal chain nor LDS bank conflicts: profiles/r4_ab_split_rows_rcp_chain.txt,
+// r4_ab_panel_loop_diet.txt), and it is the critical path of the panel loop.  Round 4 therefore takes instructions OUT of its loop:
+// kDenseMaskUpper: the panel's own eight rows carry entries ABOVE the diagonal through the forward substitution (a row is eight numbers whichever row
+// it is).  Rounds 1-3 stored zeros there (a compare and two selects per entry and row pass: 72 instructions per panel).  Nothing reads them: the back
+// substitution and the block inverses take the strictly lower entries (lf_at(i, k), k < i), and as operands of the rank-8 update they only reach
+// accumulator entries above the diagonal of a diagonal tile, which are never published for a row that is not finished.  They stay what they are.
+constexpr bool kDenseMaskUpper = false;
+// the per-panel profiling stamps of the look-ahead loop (sites 8-17) cost ~45 scalar instructions and ten branches per panel even when profiling is
+// off: compiled in only with -DPVIO_DENSE_LOOP_STAMPS (tests/micro/build_variant.py loop_stamps)
+#ifdef PVIO_DENSE_LOOP_STAMPS
+#define PV_LOOP_STAMP2(idx) PV_STAMP2(idx)
+#else
+#define PV_LOOP_STAMP2(idx) ((void)0)
+#endif
 typedef double mfma_d4 __attribute__((vector_size(32))); // the accumulator of one v_mfma_f64_16x16x4_f64
 typedef double lds_d2 __attribute__((vector_size(16)));  // one 16-byte LDS access
 
@@ -2298,9 +2313,18 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
             const bool late_patch = img_scaled; // (uniform)
             if (wv == 0) {
                 int pidx = 0;
+                // this lane's row of each pass, fixed for the whole factorization (rows counted from the END: row LDV - 1 - lane - 64 t).  A row above the
+                // panel (finished, or not a row at all) is read where it lies -- stale columns, valid memory -- and its result is never stored.
+                constexpr int kPass = 3;
+                const double *xrow[kPass];
+#pragma unroll
+                for (int t = 0; t < kPass; ++t) {
+                    const int irow = LDV - 1 - lane - 64 * t;
+                    xrow[t] = Xs + 8 * (irow > 0 ? irow : 0);
+                }
                 for (int j0 = 0; j0 < Pp; j0 += kPanel, ++pidx) {
-                    if (j0 == 0) PV_STAMP2(8);
-                    if (j0 == 80) PV_STAMP2(13);
+                    if (j0 == 0) PV_LOOP_STAMP2(8);
+                    if (j0 == 80) PV_LOOP_STAMP2(13);
                     // late_patch: this panel's diagonal patch and its piece of the rhs row are requested from LDS BEFORE the wait for the
                     // update waves (they do not depend on them): the latency disappears in the wait
                     lds_d2 dg2[4], rh2[4];
@@ -2323,16 +2347,13 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
                     // (always three passes, rows past the end re-read the last one: skipping the empty passes was tried twice -- a uniform
                     // branch per pass inside the pivot loop, and one straight-line copy of the body per pass count -- and both were
                     // slower than carrying the dead rows: 12.0k / 12.1k against 12.6k iterations/s, profiles/r3_ab_lookahead.txt)
-                    constexpr int kPass = 3;
                     double x[kPass][kPanel];
 #pragma unroll
                     for (int t = 0; t < kPass; ++t) {
-                        // rows counted from the END (row LDV - 1 - lane - 64 t): the rhs row Pp (LDV - 16 or LDV - 8) sits in the same lane of
-                        // pass 0 in EVERY panel
-                        const int irow = LDV - 1 - lane - 64 * t, ir = irow >= j0 ? irow : j0;
+                        // (rows from the end: the rhs row Pp (LDV - 16 or LDV - 8) sits in the same lane of pass 0 in EVERY panel)
 #pragma unroll
                         for (int h = 0; h < 4; ++h) {
-                            const lds_d2 g2 = *reinterpret_cast<const lds_d2 *>(Xs + ir * 8 + 2 * h);
+                            const lds_d2 g2 = *reinterpret_cast<const lds_d2 *>(xrow[t] + 2 * h);
                             x[t][2 * h] = -g2[0], x[t][2 * h + 1] = -g2[1];
                         }
                     }
@@ -2364,25 +2385,27 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
 #pragma unroll
                             for (int c2 = cc + 1; c2 < kPanel; ++c2) x[t][c2] -= x[t][cc] * Ls[c2][cc];
                     }
-                    if (j0 == 0) PV_STAMP2(9);
-                    if (j0 == 80) PV_STAMP2(14);
+                    if (j0 == 0) PV_LOOP_STAMP2(9);
+                    if (j0 == 80) PV_LOOP_STAMP2(14);
                     if (fail) { // uniform
                         if (lane == 0) sh_fail = 1;
                         dense_signal_set(flag_L, -1);
                         break;
                     }
-                    if (lane < kPanel) {
-                        double iv = inv[0];
+                    if (lane == 0) { // 1 / L_jj for the back substitution: every lane holds all eight, one writes them (four 16-byte writes instead of a select chain)
 #pragma unroll
-                        for (int cc = 1; cc < kPanel; ++cc) iv = (lane == cc) ? inv[cc] : iv;
-                        tmp[j0 + lane] = iv; // 1 / L_jj for the back substitution
+                        for (int h = 0; h < 4; ++h) {
+                            lds_d2 pr;
+                            pr[0] = inv[2 * h], pr[1] = inv[2 * h + 1];
+                            *reinterpret_cast<lds_d2 *>(tmp + j0 + 2 * h) = pr;
+                        }
                     }
 #pragma unroll
                     for (int t = 0; t < kPass; ++t) {
                         const int irow = LDV - 1 - lane - 64 * t;
                         if (irow >= j0) {
 #pragma unroll
-                            for (int cc = 0; cc < kPanel; ++cc) x[t][cc] = (j0 + cc <= irow) ? x[t][cc] * inv[cc] : 0.0;
+                            for (int cc = 0; cc < kPanel; ++cc) x[t][cc] = kDenseMaskUpper ? ((j0 + cc <= irow) ? x[t][cc] * inv[cc] : 0.0) : x[t][cc] * inv[cc];
                             lds_d2 *Lrow = reinterpret_cast<lds_d2 *>(Lf + lfo + 8 * (irow - j0));
 #pragma unroll
                             for (int h = 0; h < 4; ++h) {
@@ -2392,11 +2415,11 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
                             }
                         }
                     }
-                    if (j0 == 0) PV_STAMP2(10);
-                    if (j0 == 80) PV_STAMP2(15);
+                    if (j0 == 0) PV_LOOP_STAMP2(10);
+                    if (j0 == 80) PV_LOOP_STAMP2(15);
                     dense_signal_set(flag_L, pidx + 1); // (release: the rows above are in LDS before the counter moves)
-                    if (j0 == 0) { PV_STAMP2(11); PV_STAMP2(12); }
-                    if (j0 == 80) { PV_STAMP2(16); PV_STAMP2(17); }
+                    if (j0 == 0) { PV_LOOP_STAMP2(11); PV_LOOP_STAMP2(12); }
+                    if (j0 == 80) { PV_LOOP_STAMP2(16); PV_LOOP_STAMP2(17); }
                     lfo += 8 * (LDV - j0);
                 }
             } else {

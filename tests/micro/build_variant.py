@@ -65,6 +65,9 @@ RECIPES = {
     "desc_wc0": dict(subs=[(OPB_SHIPPED, OPB_R2_DESC)], flags=["-mllvm", "-amdgpu-waitcnt-forcezero=1"]),           # fails, same numbers
     "desc_mfmapad": dict(subs=[(OPB_SHIPPED, OPB_R2_DESC)], flags=["-mllvm", "-amdgpu-mfma-padding-ratio=100"]),    # fails, same numbers
     "desc_uncond": dict(subs=[(OPB_SHIPPED, OPB_DESC_UNCOND)]),            # passes
+    # round 4, the factor wave's instruction diet (profiles/r4_ab_panel_loop_diet.txt): the loop of round 3 piece by piece
+    "mask_upper": dict(subs=[("constexpr bool kDenseMaskUpper = false;", "constexpr bool kDenseMaskUpper = true;")]),
+    "loop_stamps": dict(defines=["PVIO_DENSE_LOOP_STAMPS"]),  # the per-panel stamp sites 8-17 (tests/prof_phases.py reads them)
 }
 
 if __name__ == "__main__":
