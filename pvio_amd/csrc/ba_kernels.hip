@@ -157,6 +157,8 @@ constexpr int kPanel = 8; // Cholesky panel width (= K of two f64 MFMAs)
 // substitution and the block inverses take the strictly lower entries (lf_at(i, k), k < i), and as operands of the rank-8 update they only reach
 // accumulator entries above the diagonal of a diagonal tile, which are never published for a row that is not finished.  They stay what they are.
 constexpr bool kDenseMaskUpper = false;
+// update waves of the look-ahead form: operands of the tile columns requested in groups of four, dead groups skipped
+constexpr bool kDenseOperandGroups = true;
 // the per-panel profiling stamps of the look-ahead loop (sites 8-17) cost ~45 scalar instructions and ten branches per panel even when profiling is
 // off: compiled in only with -DPVIO_DENSE_LOOP_STAMPS (tests/micro/build_variant.py loop_stamps)
 #ifdef PVIO_DENSE_LOOP_STAMPS
@@ -2436,9 +2438,18 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
                         hq[q] = dt_row_of<LA>(wv, q);
                         opA[q] = *reinterpret_cast<const lds_d2 *>(Lpan + 128 * (hq[q] < R ? nbk - 1 - hq[q] : b0));
                     }
+                    // (columns in groups of four: a group without a live column is not requested at all -- two uniform branches; inside a group the
+                    // requests stay unconditional, see the note on the eleven branches of round 2 in the other form below)
 #pragma unroll
-                    for (int g = 0; g < kDenseCols; ++g)
-                        opB[g] = *reinterpret_cast<const lds_d2 *>(Lpan + 128 * (g < R ? nbk - 1 - g : b0));
+                    for (int g = 0; g < 4; ++g) opB[g] = *reinterpret_cast<const lds_d2 *>(Lpan + 128 * (g < R ? nbk - 1 - g : b0));
+                    if (!kDenseOperandGroups || R > 4) {
+#pragma unroll
+                        for (int g = 4; g < 8; ++g) opB[g] = *reinterpret_cast<const lds_d2 *>(Lpan + 128 * (g < R ? nbk - 1 - g : b0));
+                    }
+                    if (!kDenseOperandGroups || R > 8) {
+#pragma unroll
+                        for (int g = 8; g < kDenseCols; ++g) opB[g] = *reinterpret_cast<const lds_d2 *>(Lpan + 128 * (g < R ? nbk - 1 - g : b0));
+                    }
 #define PV_LA_COLUMN(g)                                                                                                \
     do {                                                                                                               \
         _Pragma("unroll") for (int q = 0; q < dt_col_slot<LA>((g) + 1) - dt_col_slot<LA>(g); ++q)                      \

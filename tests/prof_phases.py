@@ -1,7 +1,9 @@
 """Phase profile of the four kernels of a bundle-adjustment iteration (10 x 1000, VIO and vision-only).
 Per-kernel times: hipEvents around every launch of the profiling entry point, WITHOUT stamps (PVIO_HIP_STAMP_SEL=-2).
 Phases: one run per stamp site (PVIO_HIP_STAMP_SEL=k: only site k stores, ticks since the start of its own launch), so that
-the stamps' own waits and stores do not add up; `all` = every site active in one run, for comparison (that kernel is slower)."""
+the stamps' own waits and stores do not add up; `all` = every site active in one run, for comparison (that kernel is slower).
+Since round 4 the per-panel sites of k_dense's look-ahead loop (8-17) are compiled in only with -DPVIO_DENSE_LOOP_STAMPS: for those rows run
+`python tests/micro/build_variant.py loop_stamps` first and `PVIO_HIP_LIB=tests/micro/variants/loop_stamps.so python tests/prof_phases.py` (zeros otherwise)."""
 import os, sys
 sys.path.insert(0, '.')
 from pvio_amd import synth, BASummary
