@@ -1,6 +1,6 @@
 """Soak run on the GPU: thousands of complete keyframe solves over alternating window shapes with image pairs (undistortion,
 pyramid, LK, detection) in between; device memory must not grow after the warm-up and nothing may hang.
-Last run (round 3, profiles/r3_soak.txt): 3000 solves (30 000 iterations) + 300 image pairs in 3.6 s, 197.1 MB before and after."""
+Last run (round 4, profiles/r4_soak.txt): 3000 solves (30 000 iterations) + 300 image pairs in 3.2 s, 197.1 MB before and after."""
 import sys, time; sys.path.insert(0, '.')
 import torch
 from pvio_amd import synth
