@@ -98,10 +98,17 @@ __device__ __forceinline__ double wave_sum(double v) {
     v += dpp_f64(v, 3);
     return ((readlane_f64(v, 0) + readlane_f64(v, 16)) + readlane_f64(v, 32)) + readlane_f64(v, 48);
 }
+constexpr bool kRsqrtCubic = true;
 // 1/sqrt(x) for the pivot chain of the block factorization: v_rsq_f64 (~2^-23 relative) + two Newton steps
 // (-> ~1 ulp).  ocml's correctly rounded sqrt + divide is ~40 dependent FP64 instructions per pivot.
 __device__ __forceinline__ double fast_rsqrt(double x) {
     double y = __builtin_amdgcn_rsq(x);
+    if (kRsqrtCubic) {
+        // one third-order step instead of two Newton steps: e = 1 - x y^2 (|e| <~ 2^-22), 1/sqrt(1 - e) = 1 + e/2 + 3 e^2/8 + O(e^3): five instructions
+        // instead of seven, and the pivot loop of k_dense's factor wave is bound by the instructions it issues
+        const double e = fma(-x, y * y, 1.0);
+        return fma(y, e * fma(e, 0.375, 0.5), y);
+    }
     y = y * fma(-0.5 * x, y * y, 1.5);
     y = y * fma(-0.5 * x, y * y, 1.5);
     return y;

@@ -68,6 +68,7 @@ RECIPES = {
     # round 4, the factor wave's instruction diet (profiles/r4_ab_panel_loop_diet.txt): the loop of round 3 piece by piece
     "mask_upper": dict(subs=[("constexpr bool kDenseMaskUpper = false;", "constexpr bool kDenseMaskUpper = true;")]),
     "operands_all": dict(subs=[("constexpr bool kDenseOperandGroups = true;", "constexpr bool kDenseOperandGroups = false;")]),
+    "rsqrt_newton": dict(subs=[("constexpr bool kRsqrtCubic = true;", "constexpr bool kRsqrtCubic = false;")]),
     "loop_stamps": dict(defines=["PVIO_DENSE_LOOP_STAMPS"]),  # the per-panel stamp sites 8-17 (tests/prof_phases.py reads them)
 }
 
