@@ -164,6 +164,10 @@ constexpr int kPanel = 8; // Cholesky panel width (= K of two f64 MFMAs)
 // substitution and the block inverses take the strictly lower entries (lf_at(i, k), k < i), and as operands of the rank-8 update they only reach
 // accumulator entries above the diagonal of a diagonal tile, which are never published for a row that is not finished.  They stay what they are.
 constexpr bool kDenseMaskUpper = false;
+// pvio_hip_opts::debug_fail_factorizations = kDbgNegativePivot + n: the next n factorizations of the look-ahead form meet a negative pivot (instead of
+// having their result discarded): the detection itself is exercised (tests/test_emu_ba.py, tests/test_gpu_ba.py)
+constexpr int kDbgNegativePivot = 1000;
+constexpr bool kDenseFailAtEnd = true; // look-ahead form: a bad pivot is detected once per panel (see the factor wave's loop)
 // update waves of the look-ahead form: operands of the tile columns requested in groups of four, dead groups skipped
 constexpr bool kDenseOperandGroups = true;
 // the per-panel profiling stamps of the look-ahead loop (sites 8-17) cost ~45 scalar instructions and ten branches per panel even when profiling is
@@ -2059,6 +2063,7 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
                 diagH[a] = yv[a];               // keep the scaled rhs (yv is reused by the back substitution)
                 // diagonal patch of the assembled system: 1 on inactive coordinates and on the panel padding, mu D^2 elsewhere
                 yv[a] = a < P ? (cpl[a] == 0.0 ? 1.0 : mu * tmp[a] * tmp[a]) : (a < Pp ? 1.0 : 0.0);
+                if (a == 3 && c->dbg_fail_left > kDbgNegativePivot) yv[a] = -1e300; // fault injection (tests only): the fourth pivot of panel 0 turns hugely negative
             }
         }
     };
@@ -2307,6 +2312,8 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
             if (sbk[i] == 0) PV_PUBLISH(i, 0);
         int *const flag_L = reinterpret_cast<int *>(lds + 216), *const flag_pub = flag_L + 1; // look-ahead form: see below
         if (LA && tid == 0) *flag_L = 0, *flag_pub = 3, sh_fail = 0; // (panel 0 has just been published by the three update waves)
+        if (LA && tid == 0 && c->dbg_fail_left > kDbgNegativePivot) // fault injection (tests only): this factorization has been given a bad pivot (dense_scale_vectors)
+            c->dbg_fail_left = c->dbg_fail_left - 1 == kDbgNegativePivot ? 0 : c->dbg_fail_left - 1;
         __syncthreads(); // every wave holds its tiles: the tile image may be overwritten from here on
         int lfo = 0;     // offset of the current panel in Lf (panel p keeps rows j0 .. LDV - 1, 8 doubles each)
         if constexpr (LA) {
@@ -2380,7 +2387,7 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
 #pragma unroll
                     for (int cc = 0; cc < kPanel; ++cc) {
                         const double dd = Ld[cc][cc];
-                        fail |= (!(dd > 0.0) || !isfinite(dd)) ? 1 : 0;
+                        if (!kDenseFailAtEnd) fail |= (!(dd > 0.0) || !isfinite(dd)) ? 1 : 0;
                         inv[cc] = fast_rsqrt(dd);
                         const double inv2 = inv[cc] * inv[cc];
 #pragma unroll
@@ -2394,6 +2401,10 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
 #pragma unroll
                             for (int c2 = cc + 1; c2 < kPanel; ++c2) x[t][c2] -= x[t][cc] * Ls[c2][cc];
                     }
+                    // A pivot that is not a positive finite number makes fast_rsqrt return NaN (negative / NaN: v_rsq_f64 does; zero / infinite: the
+                    // correction step forms 0 x inf), and a NaN multiplier reaches every entry of the block that is still to be eliminated: the LAST
+                    // reciprocal pivot is NaN exactly when some pivot of the panel was bad -- one test per panel instead of a class test per pivot.
+                    if (kDenseFailAtEnd) fail |= (inv[kPanel - 1] == inv[kPanel - 1]) ? 0 : 1;
                     if (j0 == 0) PV_LOOP_STAMP2(9);
                     if (j0 == 80) PV_LOOP_STAMP2(14);
                     if (fail) { // uniform
@@ -2953,7 +2964,7 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
         block_sum<6>(sc, red_scratch);
         nbad = sc[5];
         if (tid == 0) {
-            const int injected = c->dbg_fail_left > 0; // fault injection (tests only)
+            const int injected = c->dbg_fail_left > 0 && c->dbg_fail_left < kDbgNegativePivot; // fault injection (tests only)
             if (injected) c->dbg_fail_left--;
             sh.do_solve = !sh_fail && nbad == 0.0 && !injected;
             if (sh.do_solve) {

@@ -69,6 +69,7 @@ RECIPES = {
     "mask_upper": dict(subs=[("constexpr bool kDenseMaskUpper = false;", "constexpr bool kDenseMaskUpper = true;")]),
     "operands_all": dict(subs=[("constexpr bool kDenseOperandGroups = true;", "constexpr bool kDenseOperandGroups = false;")]),
     "rsqrt_newton": dict(subs=[("constexpr bool kRsqrtCubic = true;", "constexpr bool kRsqrtCubic = false;")]),
+    "fail_per_pivot": dict(subs=[("constexpr bool kDenseFailAtEnd = true;", "constexpr bool kDenseFailAtEnd = false;")]),
     "loop_stamps": dict(defines=["PVIO_DENSE_LOOP_STAMPS"]),  # the per-panel stamp sites 8-17 (tests/prof_phases.py reads them)
 }
 

@@ -158,6 +158,16 @@ def test_emulated_fault_paths_match_oracle(oracle, fault, inertial):
     _fault_case(mk, oracle, fault["fail"], fault["invalid"], n_frames=4, n_landmarks=30, use_inertial=inertial)
 
 
+@pytest.mark.parametrize("fail", [1, 3, 8])
+def test_emulated_negative_pivot_is_detected_like_an_injected_failure(oracle, fail):
+    """debug_fail_factorizations = 1000 + n makes the next n factorizations MEET a negative pivot (the fourth of panel 0) instead of discarding their
+    result: the factor wave's own detection -- one NaN test of the panel's last reciprocal pivot -- takes the solver down the same path the oracle's
+    injected failures do.  (A window with more than 256 landmarks: the form of k_dense that patches the diagonal late is the one that has the hook.)"""
+    lib = capi.load(os.path.join(EMU_DIR, "libpvio_hipemu.so"))
+    mk = lambda f, i: HipContext(lib=lib, debug_fail_factorizations=1000 + f, debug_invalid_steps=i)  # noqa: E731
+    _fault_case(mk, oracle, fail, 0, n_frames=4, n_landmarks=300, use_inertial=True)
+
+
 # ---- large-window accumulation (linearize_mode = 2): Schur complement on 16x16 f64 MFMA tiles, per-frame direct rows,
 # contiguous chunk ranges with anchor flushes; forced here on windows small enough for the emulator ----
 MM_CASES = {

@@ -94,6 +94,25 @@ def test_gpu_marginalize_folds_the_victims_rotation_prior(gpu_ctx, oracle, victi
     marg_compare.check_marginalize(gpu_ctx, oracle, victim, n_frames=10, n_landmarks=300, use_inertial=True, visibility=6, rot_prior_frames=(2, 5, 9))
 
 
+@pytest.mark.parametrize("fail", [1, 3, 8])
+def test_gpu_negative_pivot_is_detected_like_an_injected_failure(oracle, fail):
+    """the metric window with 1000 + n: the next n factorizations meet a genuinely negative pivot (see tests/test_emu_ba.py)"""
+    import ctypes as C
+
+    from oracle import oracle_py
+    from pvio_amd.solver import HipContext
+
+    pb = ba_compare.make(oracle, **ba_compare.BIG_CASES["metric_10x1000_vio"])
+    L = oracle_py.lib()
+    L.oracle_debug_fault_injection(C.c_int32(fail), C.c_int32(0))
+    ctx = HipContext(device=0, debug_fail_factorizations=1000 + fail)
+    try:
+        print(fail, ba_compare.check_against_oracle(ctx, oracle, pb))
+    finally:
+        L.oracle_debug_fault_injection(C.c_int32(0), C.c_int32(0))
+        ctx.close()
+
+
 @pytest.mark.parametrize("fail,invalid", [(1, 0), (3, 0), (0, 1), (0, 2), (0, 5), (8, 0)])
 @pytest.mark.parametrize("case", ["vio_small", "metric_10x1000_vio"])
 def test_gpu_fault_paths_match_oracle(oracle, fail, invalid, case):
