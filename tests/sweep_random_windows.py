@@ -1,8 +1,9 @@
 """Ad-hoc parity sweep on the GPU: 60 windows of random shape (2-32 frames, 10-1500 landmarks, visibility, plane share, inertial
-or not, a fixed frame) against the oracle with the test tolerances.  Last run (round 3, profiles/r3_sweep_random_windows.txt): 58 pass at 1e-8 .. 1e-15; the two that do not (round 2: three) are
+or not, a fixed frame) against the oracle with the test tolerances.  Last run (round 4, profiles/r4_sweep_random_windows.txt): 57 pass at 1e-8 .. 1e-15 (round 3: 58); the three that do not (round 2: the same three) are
 vision-only windows whose landmarks are all seen by exactly two frames (no gauge, barely observable depths): <= 1.5e-5 in the
 inverse depths -- and the kernel emulator (CPU double arithmetic, the kernels' summation order) is off by the same amount on
-them, i.e. conditioning, not device arithmetic."""
+them, i.e. conditioning, not device arithmetic.  (The third, 16 x 1391, is over the 1e-5 bound by 1.4e-6 on ONE inverse depth of ONE intermediate iterate
+-- a landmark 5 mm in front of its anchor; its final states agree to 9.4e-8, whatever was solved on the context before: tests/micro/seq_windows.py.)"""
 import sys; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import numpy as np
 import ba_compare
