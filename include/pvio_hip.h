@@ -56,6 +56,12 @@ typedef struct pvio_hip_ctx pvio_hip_ctx;
 typedef struct pvio_hip_image pvio_hip_image;
 typedef struct pvio_hip_undistort pvio_hip_undistort;
 
+/* Layout version of the structs below.  pvio_hip_opts is copied BY VALUE by pvio_hip_create and has grown a trailing field since 0.1
+ * (reuse_identical_candidates): a caller built against an older header would have 4 bytes past its struct read as that field.  A caller
+ * therefore checks pvio_hip_abi_version() == PVIO_HIP_ABI_VERSION once before the first pvio_hip_create (pvio_amd/host/bundle_adjustor.cpp
+ * does).  Bumped whenever a struct of this header changes size or field order. */
+#define PVIO_HIP_ABI_VERSION 2
+
 typedef struct pvio_hip_opts {
     int32_t device;          /* HIP device ordinal */
     int32_t rank;            /* landmark-shard index of this process (0 when single GPU) */
@@ -209,6 +215,8 @@ int32_t pvio_hip_create(const pvio_hip_opts *opts, pvio_hip_ctx **out);
 void pvio_hip_destroy(pvio_hip_ctx *ctx);
 const char *pvio_hip_last_error(const pvio_hip_ctx *ctx);
 const char *pvio_hip_version(void);
+/* PVIO_HIP_ABI_VERSION of the header the LIBRARY was built against */
+int32_t pvio_hip_abi_version(void);
 
 /* replaces BundleAdjustor::solve (bundle_adjustor.cpp:63-299) */
 int32_t pvio_hip_ba_solve(pvio_hip_ctx *ctx, const pvio_ba_problem *problem, pvio_ba_state *state,

@@ -104,6 +104,19 @@ struct Lin { // normal-equation pieces of one linearization (unscaled, robustifi
     std::vector<double> Wa;      // M x 6  (rho row x anchor pose cols)
 };
 
+// Second summation order (tests only): every sum over landmarks -- the pose blocks of J^T J and J^T r, the Schur
+// complement, the dogleg scalars -- runs over the landmarks last to first (and over a landmark's observations last to first) instead of in
+// the reference's order (bundle_adjustor.cpp:142-161: tracks in map order, observations in frame order).  Same algorithm, same factors,
+// a different rounding of every sum: what two runs of it differ by is what ANY reordering of the sums (the kernels' included) is entitled to.
+// Orders 2 and 3 are two more samples of the same thing: even landmarks first, then the odd ones; and that walk backwards.
+static int g_sum_order = 0;
+static inline int lm_at(int k, int M) {
+    if (g_sum_order == 0) return k;
+    if (g_sum_order == 1) return M - 1 - k;
+    const int h = (M + 1) / 2, kk = g_sum_order == 3 ? M - 1 - k : k; // 2, 3: evens, then odds
+    return kk < h ? 2 * kk : 2 * (kk - h) + 1;
+}
+
 struct Evaluator {
     const pvio_ba_problem &pb;
     const Layout &L;
@@ -187,9 +200,11 @@ struct Evaluator {
             }
         }
         // reprojection factors: bundle_adjustor.cpp:142-161, CauchyLoss(1.0)
-        for (int l = 0; l < L.M; ++l) {
+        for (int lk = 0; lk < L.M; ++lk) {
+            const int l = lm_at(lk, L.M);
             int a = pb.lm_anchor_frame[l];
-            for (int o = pb.lm_obs_ptr[l]; o < pb.lm_obs_ptr[l + 1]; ++o) {
+            for (int ok_ = pb.lm_obs_ptr[l]; ok_ < pb.lm_obs_ptr[l + 1]; ++ok_) {
+                const int o = (g_sum_order & 1) ? pb.lm_obs_ptr[l] + pb.lm_obs_ptr[l + 1] - 1 - ok_ : ok_;
                 int t = pb.obs_frame[o];
                 double r[2], J[26];
                 eval_reprojection(fs + 16 * t, fs + 16 * a, rho[l], pb.lm_anchor_z + 2 * l, pb.obs_z + 2 * o, cam[a], cam[t],
@@ -393,7 +408,8 @@ struct Solver {
             for (int b = 0; b < P; ++b) row += lin.Hpp[(size_t)a * P + b] * cp[b] * wp[b];
             s += up[a] * cp[a] * row;
         }
-        for (int l = 0; l < M; ++l) {
+        for (int lk = 0; lk < M; ++lk) {
+            const int l = lm_at(lk, M);
             if (!L.lm_used[l]) continue;
             double Wu = 0, Ww = 0;
             wdot(l, up, wp, &Wu, &Ww);
@@ -462,8 +478,10 @@ struct Solver {
             std::vector<double> vp(P), vl(M, 0.0);
             double g2 = 0;
             for (int a = 0; a < P; ++a) vp[a] = ghp[a] / Dp[a], g2 += ghp[a] * ghp[a];
-            for (int l = 0; l < M; ++l)
+            for (int lk = 0; lk < M; ++lk) {
+                const int l = lm_at(lk, M);
                 if (L.lm_used[l]) vl[l] = ghl[l] / Dl[l], g2 += ghl[l] * ghl[l];
+            }
             alpha = g2 / quad(vp.data(), vl.data(), vp.data(), vl.data());
             // Gauss-Newton step with mu escalation
             bool solved = false;
@@ -482,8 +500,10 @@ struct Solver {
         // ComputeTraditionalDoglegStep
         double gnorm2 = 0, gnn2 = 0, gdot = 0;
         for (int a = 0; a < P; ++a) gnorm2 += ghp[a] * ghp[a], gnn2 += gnp[a] * gnp[a], gdot += ghp[a] * gnp[a];
-        for (int l = 0; l < M; ++l)
+        for (int lk = 0; lk < M; ++lk) {
+            const int l = lm_at(lk, M);
             if (L.lm_used[l]) gnorm2 += ghl[l] * ghl[l], gnn2 += gnl[l] * gnl[l], gdot += ghl[l] * gnl[l];
+        }
         double gradient_norm = std::sqrt(gnorm2), gauss_newton_norm = std::sqrt(gnn2);
         double ca, cb; // step = ca * g^ + cb * gn
         if (gauss_newton_norm <= radius) {
@@ -505,11 +525,13 @@ struct Solver {
                 double v = ca * ghp[a] + cb * gnp[a];
                 n2 += v * v;
             }
-            for (int l = 0; l < M; ++l)
+            for (int lk = 0; lk < M; ++lk) {
+                const int l = lm_at(lk, M);
                 if (L.lm_used[l]) {
                     double v = ca * ghl[l] + cb * gnl[l];
                     n2 += v * v;
                 }
+            }
             dogleg_step_norm = std::sqrt(n2);
         }
         stp.resize(P), stl.assign(M, 0.0);
@@ -529,7 +551,8 @@ struct Solver {
         }
         std::vector<int> offs;
         std::vector<const double *> ws;
-        for (int l = 0; l < M; ++l) {
+        for (int lk = 0; lk < M; ++lk) {
+            const int l = lm_at(lk, M);
             if (!L.lm_used[l]) continue;
             A[l] = cl[l] * cl[l] * lin.Hll[l] + mu * Dl[l] * Dl[l];
             double wgt = cl[l] * cl[l] / A[l];
@@ -630,6 +653,7 @@ void quality_pass(const pvio_ba_problem &pb, const double *fs, const double *rho
 extern "C" {
 
 // ceres::Solve(...) as configured at bundle_adjustor.cpp:244-249 + post passes :277-296
+void oracle_debug_sum_order(int32_t order) { g_sum_order = order >= 0 && order <= 3 ? order : 0; }
 void oracle_debug_fault_injection(int32_t fail_factorizations, int32_t invalid_steps) { g_dbg_fail_factorizations = fail_factorizations, g_dbg_invalid_steps = invalid_steps; }
 
 int32_t oracle_ba_solve(const pvio_ba_problem *pbp, pvio_ba_state *state, pvio_ba_summary *sum) {

@@ -46,7 +46,7 @@ inline uint8_t sat_u8(int v) { return (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v); 
 constexpr int kWin = 21;        // Size(21, 21)
 constexpr int kMaxLevel = 3;    // level_num()
 constexpr int kMaxCount = 30;
-constexpr float kEps2 = 0.01f * 0.01f; // criteria.epsilon is squared by calcOpticalFlowPyrLK
+constexpr double kEps2 = 0.01 * 0.01; // criteria.epsilon (a double, 0.01: opencv_image.cpp:103) is squared by calcOpticalFlowPyrLK: 1.0000000000000002e-4
 constexpr float kMinEig = 1e-4f;
 
 // the defined fold of 64 run sums (see the header): returns what every lane of the wave holds after klt.hip's wave_sum_f
@@ -283,8 +283,10 @@ static void klt_track_impl(bool by_runs, int n_levels, const int *ws, const int 
                 float dx = (float)((A12 * b2 - A22 * b1) * D), dy = (float)((A12 * b1 - A11 * b2) * D);
                 nx += dx, ny += dy;
                 next_xy[2 * p] = nx + half, next_xy[2 * p + 1] = ny + half;
-                if (dx * dx + dy * dy <= kEps2) break;
-                if (j > 0 && std::fabs(dx + pdx) < 0.01f && std::fabs(dy + pdy) < 0.01f) {
+                // both tests in double, as OpenCV makes them: delta.ddot(delta) <= criteria.epsilon; std::abs(delta.x + prevDelta.x) < 0.01
+                // (the sum is a float sum, the comparison is against the double literal)
+                if ((double)dx * (double)dx + (double)dy * (double)dy <= kEps2) break;
+                if (j > 0 && (double)std::fabs(dx + pdx) < 0.01 && (double)std::fabs(dy + pdy) < 0.01) {
                     next_xy[2 * p] -= dx * 0.5f, next_xy[2 * p + 1] -= dy * 0.5f;
                     break;
                 }

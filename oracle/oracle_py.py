@@ -104,6 +104,12 @@ def solve(problem, state, summary):
     return summary
 
 
+def set_sum_order(order):
+    """0: the reference's order of every sum over landmarks; 1: last landmark first; 2: even landmarks, then odd;
+    3: order 2 backwards (tests: what a reordering of the sums is entitled to)"""
+    lib().oracle_debug_sum_order(C.c_int32(int(order)))
+
+
 def linearize(problem, frame_state, rho):
     pb = problem.as_c()
     N, M = problem.n_frames, problem.n_landmarks

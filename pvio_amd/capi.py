@@ -80,9 +80,11 @@ class ImuNoiseC(C.Structure):
                 ("cov_ba", C.c_double * 9)]
 
 
+ABI_VERSION = 2  # PVIO_HIP_ABI_VERSION of include/pvio_hip.h these ctypes structs mirror
+
 # every symbol include/pvio_hip.h declares (tests check the .so exports all of them)
 EXPORTS = [
-    "pvio_hip_create", "pvio_hip_destroy", "pvio_hip_last_error", "pvio_hip_version",
+    "pvio_hip_create", "pvio_hip_destroy", "pvio_hip_last_error", "pvio_hip_version", "pvio_hip_abi_version",
     "pvio_hip_ba_solve", "pvio_hip_ba_marginalize", "pvio_hip_ba_reprojection_error",
     "pvio_hip_ba_upload", "pvio_hip_ba_solve_resident", "pvio_hip_ba_download", "pvio_hip_ba_profile_resident", "pvio_hip_ba_last_candidate_repeats",
     "pvio_hip_comm_unique_id", "pvio_hip_comm_init", "pvio_preintegrate",
@@ -114,6 +116,10 @@ def load(path=None):
     lib.pvio_hip_last_error.restype = C.c_char_p
     lib.pvio_hip_version.argtypes = []
     lib.pvio_hip_version.restype = C.c_char_p
+    lib.pvio_hip_abi_version.argtypes = []
+    lib.pvio_hip_abi_version.restype = C.c_int32
+    if lib.pvio_hip_abi_version() != ABI_VERSION:  # the ctypes mirrors below are a layout of their own: same check as a C caller makes
+        raise RuntimeError("%s has ABI version %d, pvio_amd/capi.py mirrors version %d of include/pvio_hip.h" % (p, lib.pvio_hip_abi_version(), ABI_VERSION))
     lib.pvio_hip_ba_solve.argtypes = [vp, C.POINTER(BAProblemC), C.POINTER(BAStateC), C.POINTER(BASummaryC)]
     lib.pvio_hip_ba_solve.restype = C.c_int32
     lib.pvio_hip_ba_marginalize.argtypes = [vp, C.POINTER(BAProblemC), C.POINTER(BAStateC), C.c_int32, C.POINTER(BAPriorC)]

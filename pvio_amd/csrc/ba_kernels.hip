@@ -163,13 +163,22 @@ constexpr int kPanel = 8; // Cholesky panel width (= K of two f64 MFMAs)
 // it is).  Rounds 1-3 stored zeros there (a compare and two selects per entry and row pass: 72 instructions per panel).  Nothing reads them: the back
 // substitution and the block inverses take the strictly lower entries (lf_at(i, k), k < i), and as operands of the rank-8 update they only reach
 // accumulator entries above the diagonal of a diagonal tile, which are never published for a row that is not finished.  They stay what they are.
-constexpr bool kDenseMaskUpper = false;
+// -DPVIO_DENSE_CONSERVATIVE: the three round-4 source forms of the look-ahead loop whose correctness on the GPU rests on the code the
+// compiler happened to generate for them (uniform branches around operand loads have miscompiled before, see the note at the update waves' operand
+// requests) fall back to the forms rounds 1-3 shipped.  __graft_entry__.build() passes it whenever hipcc is not the version the kernels were
+// last verified with on a GPU (csrc/KNOWN_GOOD_TOOLCHAIN): ~5 % slower, nothing to trust.
+#ifdef PVIO_DENSE_CONSERVATIVE
+constexpr bool kDenseConservative = true;
+#else
+constexpr bool kDenseConservative = false;
+#endif
+constexpr bool kDenseMaskUpper = kDenseConservative;
 // pvio_hip_opts::debug_fail_factorizations = kDbgNegativePivot + n: the next n factorizations of the look-ahead form meet a negative pivot (instead of
 // having their result discarded): the detection itself is exercised (tests/test_emu_ba.py, tests/test_gpu_ba.py)
 constexpr int kDbgNegativePivot = 1000;
-constexpr bool kDenseFailAtEnd = true; // look-ahead form: a bad pivot is detected once per panel (see the factor wave's loop)
+constexpr bool kDenseFailAtEnd = !kDenseConservative; // look-ahead form: a bad pivot is detected once per panel (see the factor wave's loop)
 // update waves of the look-ahead form: operands of the tile columns requested in groups of four, dead groups skipped
-constexpr bool kDenseOperandGroups = true;
+constexpr bool kDenseOperandGroups = !kDenseConservative;
 // the per-panel profiling stamps of the look-ahead loop (sites 8-17) cost ~45 scalar instructions and ten branches per panel even when profiling is
 // off: compiled in only with -DPVIO_DENSE_LOOP_STAMPS (tests/micro/build_variant.py loop_stamps)
 #ifdef PVIO_DENSE_LOOP_STAMPS
@@ -2063,7 +2072,7 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
                 diagH[a] = yv[a];               // keep the scaled rhs (yv is reused by the back substitution)
                 // diagonal patch of the assembled system: 1 on inactive coordinates and on the panel padding, mu D^2 elsewhere
                 yv[a] = a < P ? (cpl[a] == 0.0 ? 1.0 : mu * tmp[a] * tmp[a]) : (a < Pp ? 1.0 : 0.0);
-                if (a == 3 && c->dbg_fail_left > kDbgNegativePivot) yv[a] = -1e300; // fault injection (tests only): the fourth pivot of panel 0 turns hugely negative
+                if (LA && a == 3 && c->dbg_fail_left > kDbgNegativePivot) yv[a] = -1e300; // fault injection (tests only): the fourth pivot of panel 0 turns hugely negative
             }
         }
     };
@@ -2401,10 +2410,12 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
 #pragma unroll
                             for (int c2 = cc + 1; c2 < kPanel; ++c2) x[t][c2] -= x[t][cc] * Ls[c2][cc];
                     }
-                    // A pivot that is not a positive finite number makes fast_rsqrt return NaN (negative / NaN: v_rsq_f64 does; zero / infinite: the
-                    // correction step forms 0 x inf), and a NaN multiplier reaches every entry of the block that is still to be eliminated: the LAST
-                    // reciprocal pivot is NaN exactly when some pivot of the panel was bad -- one test per panel instead of a class test per pivot.
-                    if (kDenseFailAtEnd) fail |= (inv[kPanel - 1] == inv[kPanel - 1]) ? 0 : 1;
+                    // A pivot that is negative, zero, infinite or NaN makes fast_rsqrt return NaN (negative / NaN: v_rsq_f64 does; zero / infinite: the
+                    // correction step forms 0 x inf), and a NaN multiplier reaches every entry of the block that is still to be eliminated, the last
+                    // reciprocal pivot included.  A tiny positive (denormal-range) pivot does not: its reciprocal square root overflows to +inf
+                    //  -- as an earlier pivot it turns the rest of the block into inf - inf = NaN, as the panel's LAST pivot it is only
+                    // visible as an infinite inv[7].  One test per panel catches both: inv[7] * 0 is 0 exactly when inv[7] is finite.
+                    if (kDenseFailAtEnd) fail |= (inv[kPanel - 1] * 0.0 == 0.0) ? 0 : 1;
                     if (j0 == 0) PV_LOOP_STAMP2(9);
                     if (j0 == 80) PV_LOOP_STAMP2(14);
                     if (fail) { // uniform

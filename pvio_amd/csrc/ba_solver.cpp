@@ -224,7 +224,11 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st, bool ma
     dm.G_prior = dm.prior_n; // one workgroup per prior frame
     // One workgroup fits on a CU (registers, LDS) and the IMU / prior workgroups are the longest: the landmark chunks get
     // the CUs that are left, so that the whole grid is resident at once instead of queueing a second round behind it.
-    const int lm_cus = std::max(1, cus - dm.G_plane - dm.G_pre - dm.G_prior);
+    // (PVIO_HIP_LM_WGS=n: experiments -- at most n landmark workgroups, i.e. n partial rows for k_reduce to sum instead of one per free CU:
+    // profiles/r5_ab_partials.txt)
+    static const int lm_wgs_cap = std::getenv("PVIO_HIP_LM_WGS") ? std::atoi(std::getenv("PVIO_HIP_LM_WGS")) : 0;
+    int lm_cus = std::max(1, cus - dm.G_plane - dm.G_pre - dm.G_prior);
+    if (lm_wgs_cap > 0) lm_cus = std::min(lm_cus, lm_wgs_cap);
     const int slots_lds = (int)std::max<size_t>(1, std::min<size_t>(lds_budget / 8 / (40 * N + 46), (size_t)kLinThreads));
     const int slots_spread = std::max(1, (M + lm_cus - 1) / lm_cus);
     dm.lm_slots = std::min(slots_lds, slots_spread);

@@ -157,6 +157,12 @@ struct View { // passed by value to every kernel
     double *cp, *Dp, *gtot, *ghp, *vstep, *ystep; // [P] each
     // Dims::reuse_cand: [2][8] the candidate of the last two trust-region iterations by iteration parity -- ca, cb, mu, lin, cur, iteration, evaluated,
     // unused -- written by workgroup 0 of k_linearize, read by every workgroup of the NEXT launch; [16] = this slot repeats the last candidate
+    // INVARIANT the short-circuit rests on: between the k_linearize launch that evaluated a candidate and the launch that finds it again,
+    // nothing writes what the skipped evaluation would have produced and the rest of the slot still reads -- the partial rows part_*, `red`, the tile
+    // image `img`, the candidate buffers fs[1 - cur] / rho[1 - cur] and the cost buffers pre_cost / prior_cost / rot_cost of the speculative
+    // linearization set.  Holds because a rejected step makes k_dense return before it builds anything (need_build false: it only READS red / img) and
+    // k_backsub only writes step vectors and back_part.  Does NOT hold on landmark shards, whose all-reduce sums `red` in place -- upload() turns the
+    // mode off there.  Held by tests: the whole case matrix runs with the mode on against the oracle per iteration (test_emu_ba.py, test_gpu_ba.py).
     double *cand_rec;
     double *cpl, *vraw; // [P] each: Jacobi scale with 0 on inactive coordinates (img_scaled: read by k_reduce); v = g^ / D before C is applied
     // trace

@@ -20,7 +20,8 @@ struct pvio_hip_ctx {
 
 extern "C" {
 
-const char *pvio_hip_version(void) { return "pvio-mi355x 0.1 (gfx950)"; }
+const char *pvio_hip_version(void) { return "pvio-mi355x 0.2 (gfx950; ABI 2)"; }
+int32_t pvio_hip_abi_version(void) { return PVIO_HIP_ABI_VERSION; }
 
 int32_t pvio_hip_create(const pvio_hip_opts *opts, pvio_hip_ctx **out) {
     if (!out) return PVIO_ERR_INVALID_ARGUMENT;

@@ -402,8 +402,11 @@ __global__ void __launch_bounds__(256) k_lk_track(TrackArgs a) {
             const float dx = (a12 * b2 - a22 * b1) * D, dy = (a12 * b1 - a11 * b2) * D;
             nx += dx, ny += dy;
             outx = nx + half, outy = ny + half;
-            if (dx * dx + dy * dy <= 0.01f * 0.01f) break;
-            if (j > 0 && fabsf(dx + pdx) < 0.01f && fabsf(dy + pdy) < 0.01f) {
+            // OpenCV's two termination tests are DOUBLE comparisons (lkpyramid.cpp: `delta.ddot(delta) <= criteria.epsilon` with the double
+            // epsilon 0.01 squared by calcOpticalFlowPyrLK = 1.0000000000000002e-4; `std::abs(delta.x + prevDelta.x) < 0.01`: a float sum
+            // against the double literal): a float comparison decides differently within an ulp of either threshold.  Wave-uniform, twice per iteration.
+            if ((double)dx * (double)dx + (double)dy * (double)dy <= 0.01 * 0.01) break;
+            if (j > 0 && (double)fabsf(dx + pdx) < 0.01 && (double)fabsf(dy + pdy) < 0.01) {
                 outx -= dx * 0.5f, outy -= dy * 0.5f;
                 break;
             }

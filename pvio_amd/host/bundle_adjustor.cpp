@@ -48,6 +48,11 @@ pvio_hip_ctx *process_ctx() {
         const char *reuse = std::getenv("PVIO_HIP_REUSE_CANDIDATES");
         o.reuse_identical_candidates = (reuse && std::atoi(reuse) == 0) ? 0 : 1;
         if (const char *dev = std::getenv("PVIO_HIP_DEVICE")) o.device = std::atoi(dev); // one ctx per process and GPU
+        if (pvio_hip_abi_version() != PVIO_HIP_ABI_VERSION) { // pvio_hip_opts is copied by value: a library built against another header reads another layout
+            std::fprintf(stderr, "[pvio-hip] libpvio_hip.so has ABI version %d, this adapter was built against %d\n", (int)pvio_hip_abi_version(), PVIO_HIP_ABI_VERSION);
+            ctx = nullptr;
+            return;
+        }
         if (pvio_hip_create(&o, &ctx) != PVIO_OK) {
             std::fprintf(stderr, "[pvio-hip] no usable GPU context: BundleAdjustor::solve will report failure\n");
             ctx = nullptr;

@@ -61,6 +61,7 @@ struct pvio_hip_ctx {
     std::string err;
 };
 extern "C" {
+int32_t pvio_hip_abi_version(void) { return PVIO_HIP_ABI_VERSION; }
 int32_t pvio_hip_create(const pvio_hip_opts *, pvio_hip_ctx **out) {
     *out = new pvio_hip_ctx();
     return PVIO_OK;

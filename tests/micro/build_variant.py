@@ -66,10 +66,11 @@ RECIPES = {
     "desc_mfmapad": dict(subs=[(OPB_SHIPPED, OPB_R2_DESC)], flags=["-mllvm", "-amdgpu-mfma-padding-ratio=100"]),    # fails, same numbers
     "desc_uncond": dict(subs=[(OPB_SHIPPED, OPB_DESC_UNCOND)]),            # passes
     # round 4, the factor wave's instruction diet (profiles/r4_ab_panel_loop_diet.txt): the loop of round 3 piece by piece
-    "mask_upper": dict(subs=[("constexpr bool kDenseMaskUpper = false;", "constexpr bool kDenseMaskUpper = true;")]),
-    "operands_all": dict(subs=[("constexpr bool kDenseOperandGroups = true;", "constexpr bool kDenseOperandGroups = false;")]),
+    "mask_upper": dict(subs=[("constexpr bool kDenseMaskUpper = kDenseConservative;", "constexpr bool kDenseMaskUpper = true;")]),
+    "operands_all": dict(subs=[("constexpr bool kDenseOperandGroups = !kDenseConservative;", "constexpr bool kDenseOperandGroups = false;")]),
     "rsqrt_newton": dict(subs=[("constexpr bool kRsqrtCubic = true;", "constexpr bool kRsqrtCubic = false;")]),
-    "fail_per_pivot": dict(subs=[("constexpr bool kDenseFailAtEnd = true;", "constexpr bool kDenseFailAtEnd = false;")]),
+    "fail_per_pivot": dict(subs=[("constexpr bool kDenseFailAtEnd = !kDenseConservative;", "constexpr bool kDenseFailAtEnd = false;")]),
+    "conservative": dict(defines=["PVIO_DENSE_CONSERVATIVE"]),  # what build() ships when hipcc is not csrc/KNOWN_GOOD_TOOLCHAIN
     "loop_stamps": dict(defines=["PVIO_DENSE_LOOP_STAMPS"]),  # the per-panel stamp sites 8-17 (tests/prof_phases.py reads them)
 }
 

@@ -22,13 +22,7 @@ else:
     ctx = HipContext(device=0)
 bad = 0
 for seed in range(60):
-    rng = np.random.default_rng(5000 + seed)
-    n = int(rng.integers(2, 33))
-    kw = dict(n_frames=n, n_landmarks=int(rng.integers(10, 1500)), use_inertial=bool(rng.integers(0, 2)), visibility=int(rng.integers(2, n + 1)),
-              plane_fraction=float(rng.choice([0.0, 0.0, 0.3, 0.6])), seed=int(rng.integers(1, 10000)))
-    pb = ba_compare.make(O, **kw)
-    if rng.random() < 0.4:
-        pb.frame_fixed[int(rng.integers(0, n))] = 1
+    kw, pb = ba_compare.sweep_window(O, seed)  # (the bounded pytest of the same windows: tests/test_gpu_ba.py::test_gpu_window_sweep_within_oracle_spread)
     try:
         r = ba_compare.check_against_oracle(ctx, O, pb)
         print(seed, kw['n_frames'], kw['n_landmarks'], kw['use_inertial'], 'ok', '%.1e' % r['worst_state_diff'], r['iterations'], flush=True)

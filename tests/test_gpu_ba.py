@@ -297,6 +297,25 @@ def test_gpu_random_windows_match_oracle(gpu_ctx, oracle, seed):
     print(kw, ba_compare.check_against_oracle(gpu_ctx, oracle, pb))
 
 
+@pytest.mark.parametrize("seed", list(range(60)))
+def test_gpu_window_sweep_within_oracle_spread(gpu_ctx, oracle, seed):
+    """The 60-window sweep of profiles/r*_sweep_random_windows.txt as a bounded test: 2-32 frames, 10-1500 landmarks,
+    incl. the many-frame two-view windows.  Tolerance per window: north_star's 1e-6, or -- where the ORACLE'S OWN reorderings of the sums over
+    landmarks differ by more (computed in the test: ba_compare.oracle_spread; windows 15, 20, 37: 2.6e-4, 6.9e-6, 6.4e-7 in the states,
+    8.5e-5 px in the quality of #37) -- four times that spread."""
+    kw, pb = ba_compare.sweep_window(oracle, seed)
+    r = ba_compare.check_against_oracle_within_spread(gpu_ctx, oracle, pb)
+    print(seed, kw, r)
+    assert "skipped" not in r or seed not in (15, 20, 37)  # (the three ill-conditioned windows are not decision-boundary cases)
+
+
+@pytest.mark.parametrize("case", range(len(ba_compare.TWO_VIEW_CASES)))
+def test_gpu_many_frame_two_view_windows(gpu_ctx, oracle, case):
+    """15-31 frames, every landmark seen by exactly two of them, vision only (no gauge): the class the sweep's three outliers belong to"""
+    pb = ba_compare.make(oracle, **ba_compare.TWO_VIEW_CASES[case])
+    print(ba_compare.TWO_VIEW_CASES[case], ba_compare.check_against_oracle_within_spread(gpu_ctx, oracle, pb))
+
+
 @pytest.mark.parametrize("poison", [float("nan"), 1e300], ids=["nan", "1e300"])
 def test_gpu_solver_reads_nothing_it_did_not_write(oracle, poison):
     """A fresh context on device memory that a previous owner left full of NaN (or 1e300): 4 GB are filled and handed back to the
@@ -377,12 +396,13 @@ def gpu_ctx_reuse():
     ctx.close()
 
 
-@pytest.mark.parametrize("name,saved", [("vio_partial", 2), ("vio_zero_bias_quirk", 4), ("vio_plane", 1), ("vision_partial", 0), ("vio_rot_prior", None),
-                                        ("vio_duplicate_blocks", None), ("vio_13_frames_global_matrix", None)])
+# (the adapter's default is ON, so the whole case matrix runs with it, not a selection)
+@pytest.mark.parametrize("name,saved", [(n, {"vio_partial": 2, "vio_zero_bias_quirk": 4, "vio_plane": 1, "vision_partial": 0}.get(n)) for n in sorted(ba_compare.CASES)] +
+                         [(n, None) for n in sorted(ba_compare.BIG_CASES)])
 def test_gpu_identical_candidates_are_not_evaluated_twice(gpu_ctx_reuse, oracle, name, saved):
     """a candidate that is bit-identical to the one just rejected is not evaluated again: same iterations, records and per-iteration states as the
     oracle, which -- like Ceres -- evaluates every candidate"""
-    pb = ba_compare.make(oracle, **ba_compare.CASES[name])
+    pb = ba_compare.make(oracle, **(ba_compare.CASES.get(name) or ba_compare.BIG_CASES[name]))
     print(name, ba_compare.check_against_oracle(gpu_ctx_reuse, oracle, pb), "evaluations saved:", gpu_ctx_reuse.last_candidate_repeats())
     if saved is not None:
         assert gpu_ctx_reuse.last_candidate_repeats() == saved
