@@ -251,6 +251,9 @@ typedef struct pvio_ba_kernel_times {
 int32_t pvio_hip_ba_profile_resident(pvio_hip_ctx *ctx, pvio_ba_summary *summary, pvio_ba_kernel_times *times);
 /* candidate evaluations the last solve short-circuited (pvio_hip_opts::reuse_identical_candidates; 0 when the option is off) */
 int32_t pvio_hip_ba_last_candidate_repeats(const pvio_hip_ctx *ctx);
+/* diagnostics: how many solves of this context ran as a replay of the captured slot graph (the others launched eagerly: the first solve of
+ * an upload, contexts created with use_graph = 0, a landmark shard whose capture failed) */
+int32_t pvio_hip_ba_graph_replays(const pvio_hip_ctx *ctx);
 
 /* multi-GPU (landmark shards, one process per GPU): RCCL communicator bootstrap.
  * rank 0 creates the 128-byte unique id, the launcher broadcasts it (torch.distributed), every rank inits. */

@@ -86,7 +86,7 @@ ABI_VERSION = 2  # PVIO_HIP_ABI_VERSION of include/pvio_hip.h these ctypes struc
 EXPORTS = [
     "pvio_hip_create", "pvio_hip_destroy", "pvio_hip_last_error", "pvio_hip_version", "pvio_hip_abi_version",
     "pvio_hip_ba_solve", "pvio_hip_ba_marginalize", "pvio_hip_ba_reprojection_error",
-    "pvio_hip_ba_upload", "pvio_hip_ba_solve_resident", "pvio_hip_ba_download", "pvio_hip_ba_profile_resident", "pvio_hip_ba_last_candidate_repeats",
+    "pvio_hip_ba_upload", "pvio_hip_ba_solve_resident", "pvio_hip_ba_download", "pvio_hip_ba_profile_resident", "pvio_hip_ba_last_candidate_repeats", "pvio_hip_ba_graph_replays",
     "pvio_hip_comm_unique_id", "pvio_hip_comm_init", "pvio_preintegrate",
     "pvio_hip_image_create", "pvio_hip_image_release", "pvio_hip_image_download_level", "pvio_hip_klt_track", "pvio_hip_image_detect", "pvio_hip_image_download_response",
     "pvio_hip_klt_last_device_ms", "pvio_hip_fundamental_ransac", "pvio_hip_ransac_last_hypotheses",

@@ -1680,9 +1680,15 @@ __device__ __forceinline__ void dense_signal_add(int *flag) {
 // compile-time storage choice: a runtime LDS-or-global pointer select degrades every access to FLAT.  The register-resident
 // form runs one wave per SIMD (its tiles live in the accumulators of exactly four waves); the HBM form runs two: its sweeps
 // and passes over the matrix wait on L2 round trips that a second wave fills.
-template <bool LDSMAT, bool LA>
+// LS: row stride, in doubles, of the two row-major LDS arrays of the register-resident factorization -- Xs (the 8 columns that are factored next) and
+// Lf (the finished panels of L).  A row is 8 doubles; at LS = 8 the factor wave's lane-per-row accesses (12 ds_read_b128 + 12 ds_write_b128 per panel at
+// 64-byte stride) run into 4-way bank conflicts: 75 cycles per instruction against 32 at an 80-byte stride (tools/ubench/wave_costs.hip).  LS = 10 pads
+// every row to 80 bytes -- no address arithmetic, only other constants.  Round 5 built it and measured NO gain (dense_row_stride() below): LS = 8 ships,
+// the padded instantiation stays reachable for the A/B.
+template <bool LDSMAT, bool LA, int LS = 8>
 __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_dense(View v) {
     static_assert(LDSMAT || !LA, "the look-ahead form is a form of the register-resident factorization");
+    static_assert(LS == 8 || (LDSMAT && LS == 10), "row stride of Xs / Lf: 8 doubles, or padded to 10 (80 bytes: 16-byte aligned, conflict-free)");
     // 256 threads = one wave per SIMD: the redundant 8 x 8 block factorization then costs each SIMD exactly once
     HIP_DYNAMIC_SHARED(double, lds)
     Ctrl *const cg = v.ctrl;
@@ -1709,7 +1715,7 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
     double *aux_costs = lds + 280; // [N + prior_n <= 64] IMU factor costs (0 where absent) and prior costs
     double *vec = lds + 352;
     double *Lp = vec + 8 * (size_t)LDV;
-    double *A = LDSMAT ? Lp + 8 * (size_t)LDV : v.Smat;
+    double *A = LDSMAT ? Lp + LS * (size_t)LDV : v.Smat;
     double *diagH = vec, *gtot = vec + LDV, *rhs = vec + 2 * LDV, *yv = vec + 3 * LDV, *vv = vec + 4 * LDV, *act = vec + 5 * LDV,
            *tmp = vec + 6 * LDV, *cpl = vec + 7 * LDV;
     double *ysol = rhs; // solution of the reduced system (rhs is dead once the augmented row has been written)
@@ -2149,7 +2155,7 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
         if (!early) __syncthreads(); // (early: the barriers behind Finalize already separate the scaling from its readers)
         PV_STAMP2(21);
     } else {
-        for (int e = tid; e < 8 * LDV; e += nthr) Lp[e] = 0.0;
+        for (int e = tid; e < LS * LDV; e += nthr) Lp[e] = 0.0;
         __syncthreads();
         PV_STAMP2(21);
         const bool fused_qvv = !LDSMAT && v.dm.use_img; // (uniform) the build from the image forms v^T S v on the way
@@ -2312,7 +2318,7 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
     do {                                                                                                \
         const int cX = lr - (o2);                                                                       \
         if (cX >= 0 && cX < kPanel) {                                                                   \
-            _Pragma("unroll") for (int r = 0; r < 4; ++r) Xs[(16 * (brow) + lk + 4 * r) * 8 + cX] = acc[i][r]; \
+            _Pragma("unroll") for (int r = 0; r < 4; ++r) Xs[(16 * (brow) + lk + 4 * r) * LS + cX] = acc[i][r]; \
         }                                                                                               \
     } while (0)
 #define PV_PUBLISH(i, o2) PV_PUBLISH_ROW(i, sbi[i], o2)
@@ -2345,7 +2351,7 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
 #pragma unroll
                 for (int t = 0; t < kPass; ++t) {
                     const int irow = LDV - 1 - lane - 64 * t;
-                    xrow[t] = Xs + 8 * (irow > 0 ? irow : 0);
+                    xrow[t] = Xs + LS * (irow > 0 ? irow : 0);
                 }
                 for (int j0 = 0; j0 < Pp; j0 += kPanel, ++pidx) {
                     if (j0 == 0) PV_LOOP_STAMP2(8);
@@ -2364,7 +2370,7 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
                     for (int r = 0; r < kPanel; ++r)
 #pragma unroll
                         for (int h = 0; h <= (r >> 1); ++h) {
-                            const lds_d2 g2 = *reinterpret_cast<const lds_d2 *>(Xs + (j0 + r) * 8 + 2 * h);
+                            const lds_d2 g2 = *reinterpret_cast<const lds_d2 *>(Xs + (j0 + r) * LS + 2 * h);
                             Ld[r][2 * h] = -g2[0];
                             if (2 * h + 1 <= r) Ld[r][2 * h + 1] = -g2[1];
                         }
@@ -2437,7 +2443,7 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
                         if (irow >= j0) {
 #pragma unroll
                             for (int cc = 0; cc < kPanel; ++cc) x[t][cc] = kDenseMaskUpper ? ((j0 + cc <= irow) ? x[t][cc] * inv[cc] : 0.0) : x[t][cc] * inv[cc];
-                            lds_d2 *Lrow = reinterpret_cast<lds_d2 *>(Lf + lfo + 8 * (irow - j0));
+                            lds_d2 *Lrow = reinterpret_cast<lds_d2 *>(Lf + lfo + LS * (irow - j0));
 #pragma unroll
                             for (int h = 0; h < 4; ++h) {
                                 lds_d2 pr;
@@ -2451,7 +2457,7 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
                     dense_signal_set(flag_L, pidx + 1); // (release: the rows above are in LDS before the counter moves)
                     if (j0 == 0) { PV_LOOP_STAMP2(11); PV_LOOP_STAMP2(12); }
                     if (j0 == 80) { PV_LOOP_STAMP2(16); PV_LOOP_STAMP2(17); }
-                    lfo += 8 * (LDV - j0);
+                    lfo += LS * (LDV - j0);
                 }
             } else {
                 int pidx = 0;
@@ -2459,25 +2465,25 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
                     const int k0 = j0 + kPanel, b0 = k0 >> 4, o2 = k0 & 15;
                     if (dense_wait(flag_L, pidx + 1) < 0) break;
                     const int R = nbk - b0; // live tile columns g = 0 .. R - 1 (from the end); the one that is factored next is g = R - 1
-                    const double *Lpan = Lf + lfo - 8 * j0 + 2 * lk + 8 * lr; // + 128 * tile row -> this lane's operand pair
+                    const double *Lpan = Lf + lfo - LS * j0 + 2 * lk + LS * lr; // + 16 LS * tile row -> this lane's operand pair
                     lds_d2 opA[kNQ], opB[kDenseCols];
                     int hq[kNQ]; // this wave's tile rows (uniform)
 #pragma unroll
                     for (int q = 0; q < kNQ; ++q) {
                         hq[q] = dt_row_of<LA>(wv, q);
-                        opA[q] = *reinterpret_cast<const lds_d2 *>(Lpan + 128 * (hq[q] < R ? nbk - 1 - hq[q] : b0));
+                        opA[q] = *reinterpret_cast<const lds_d2 *>(Lpan + 16 * LS * (hq[q] < R ? nbk - 1 - hq[q] : b0));
                     }
                     // (columns in groups of four: a group without a live column is not requested at all -- two uniform branches; inside a group the
                     // requests stay unconditional, see the note on the eleven branches of round 2 in the other form below)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) opB[g] = *reinterpret_cast<const lds_d2 *>(Lpan + 128 * (g < R ? nbk - 1 - g : b0));
+                    for (int g = 0; g < 4; ++g) opB[g] = *reinterpret_cast<const lds_d2 *>(Lpan + 16 * LS * (g < R ? nbk - 1 - g : b0));
                     if (!kDenseOperandGroups || R > 4) {
 #pragma unroll
-                        for (int g = 4; g < 8; ++g) opB[g] = *reinterpret_cast<const lds_d2 *>(Lpan + 128 * (g < R ? nbk - 1 - g : b0));
+                        for (int g = 4; g < 8; ++g) opB[g] = *reinterpret_cast<const lds_d2 *>(Lpan + 16 * LS * (g < R ? nbk - 1 - g : b0));
                     }
                     if (!kDenseOperandGroups || R > 8) {
 #pragma unroll
-                        for (int g = 8; g < kDenseCols; ++g) opB[g] = *reinterpret_cast<const lds_d2 *>(Lpan + 128 * (g < R ? nbk - 1 - g : b0));
+                        for (int g = 8; g < kDenseCols; ++g) opB[g] = *reinterpret_cast<const lds_d2 *>(Lpan + 16 * LS * (g < R ? nbk - 1 - g : b0));
                     }
 #define PV_LA_COLUMN(g)                                                                                                \
     do {                                                                                                               \
@@ -2501,14 +2507,14 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
                             }
                         }
 #undef PV_LA_COLUMN
-                    lfo += 8 * (LDV - j0);
+                    lfo += LS * (LDV - j0);
                 }
             }
             __syncthreads();
             fail = sh_fail;
             {
                 int lfo_end = 0; // every wave leaves with the offset behind the last panel (a failed pivot: unused)
-                for (int j0 = 0; j0 < Pp; j0 += kPanel) lfo_end += 8 * (LDV - j0);
+                for (int j0 = 0; j0 < Pp; j0 += kPanel) lfo_end += LS * (LDV - j0);
                 lfo = lfo_end;
             }
         } else
@@ -2521,7 +2527,7 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
             for (int r = 0; r < kPanel; ++r)
 #pragma unroll
                 for (int h = 0; h <= (r >> 1); ++h) {
-                    const lds_d2 g2 = *reinterpret_cast<const lds_d2 *>(Xs + (j0 + r) * 8 + 2 * h);
+                    const lds_d2 g2 = *reinterpret_cast<const lds_d2 *>(Xs + (j0 + r) * LS + 2 * h);
                     Ld[r][2 * h] = -g2[0];
                     if (2 * h + 1 <= r) Ld[r][2 * h + 1] = -g2[1];
                 }
@@ -2534,7 +2540,7 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
                 const int ir = irow < LDV ? irow : LDV - 1;
 #pragma unroll
                 for (int h = 0; h < 4; ++h) {
-                    const lds_d2 g2 = *reinterpret_cast<const lds_d2 *>(Xs + ir * 8 + 2 * h);
+                    const lds_d2 g2 = *reinterpret_cast<const lds_d2 *>(Xs + ir * LS + 2 * h);
                     x[2 * h] = -g2[0], x[2 * h + 1] = -g2[1];
                 }
             }
@@ -2575,7 +2581,7 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
 #pragma unroll
                 for (int cc = 0; cc < kPanel; ++cc) x[cc] = (j0 + cc <= irow) ? x[cc] * inv[cc] : 0.0;
                 if (j0 == 80) PV_STAMPV2(20, x[7]);
-                lds_d2 *Lrow = reinterpret_cast<lds_d2 *>(Lf + lfo + 8 * tid);
+                lds_d2 *Lrow = reinterpret_cast<lds_d2 *>(Lf + lfo + LS * tid);
 #pragma unroll
                 for (int h = 0; h < 4; ++h) {
                     lds_d2 pr;
@@ -2593,7 +2599,7 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
             // published while the remaining groups still compute).
             {
                 const int R = nbk - b0; // live tile columns g = 0 .. R - 1 (from the end); the one that is factored next is g = R - 1
-                const double *Lpan = Lf + lfo - 8 * j0 + 2 * lk + 8 * lr; // + 128 * tile row -> this lane's operand pair
+                const double *Lpan = Lf + lfo - LS * j0 + 2 * lk + LS * lr; // + 16 LS * tile row -> this lane's operand pair
                 // operands: A(q) = rows wv + 4 q (from the end), B(g) = column g; rows / columns outside the live range read the
                 // row block b0 (a valid address; they only ever meet slots that hold no live tile)
                 lds_d2 opA[3], opB[kDenseCols];
@@ -2601,7 +2607,7 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
                     hq[q] = dense_row_of(wv, q);
-                    opA[q] = *reinterpret_cast<const lds_d2 *>(Lpan + 128 * (hq[q] < R ? nbk - 1 - hq[q] : b0));
+                    opA[q] = *reinterpret_cast<const lds_d2 *>(Lpan + 16 * LS * (hq[q] < R ? nbk - 1 - hq[q] : b0));
                 }
                 // Every column's operand is requested UNCONDITIONALLY (dead columns read row block b0 like dead rows do).  Round 2 had
                 // eleven uniform `if (g < R)` branches around these loads; with them, the DEscending request order compiled to a
@@ -2611,7 +2617,7 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
                 // branches.  The branch-free form is what ships; it also drops eleven scalar branches per panel.
 #pragma unroll
                 for (int g = 0; g < kDenseCols; ++g)
-                    opB[g] = *reinterpret_cast<const lds_d2 *>(Lpan + 128 * (g < R ? nbk - 1 - g : b0));
+                    opB[g] = *reinterpret_cast<const lds_d2 *>(Lpan + 16 * LS * (g < R ? nbk - 1 - g : b0));
                 // a column's slots, unconditionally: a slot that holds no tile of this wave (its q-th row lies outside the column)
                 // costs two MFMAs on registers nobody reads -- cheaper than a uniform branch per slot, which splits the MFMA
                 // sequence into basic blocks (measured: 54.4 against 49.7 us)
@@ -2643,19 +2649,19 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
             __syncthreads();
             if (j0 == 0) PV_STAMP2(12);
             if (j0 == 80) PV_STAMP2(17);
-            lfo += 8 * (LDV - j0);
+            lfo += LS * (LDV - j0);
         }
 #undef PV_PUBLISH
 #undef PV_PUBLISH_ROW
         PV_STAMP2(5);
         // ---------------- back substitution L^T y = z, 8 columns per step ----------------
-        // L(i, k) = Lf[off(k >> 3) + (i - 8 (k >> 3)) * 8 + perm(k & 7)], off(p) = 8 p LDV - 32 p (p - 1), perm(c) = 2 (c & 3) + (c >> 2)
+        // L(i, k) = Lf[off(k >> 3) + (i - 8 (k >> 3)) * LS + perm(k & 7)], off(p) = LS (p LDV - 4 p (p - 1)), perm(c) = 2 (c & 3) + (c >> 2)
         if (tid == 0) sh_fail = fail;
         __syncthreads();
         if (!fail) {
             auto lf_at = [&](int i, int k) -> int {
                 const int p = k >> 3, cI = k & 7;
-                return 8 * p * LDV - 32 * p * (p - 1) + (i - 8 * p) * 8 + 2 * (cI & 3) + (cI >> 2);
+                return LS * (p * LDV - 4 * p * (p - 1)) + (i - 8 * p) * LS + 2 * (cI & 3) + (cI >> 2);
             };
             // inverses of the 8 x 8 diagonal blocks, all at once (thread = one column of one block: L X = e_c), so that a
             // block step below is a short dot product instead of a dependent triangular solve.  Li overlays Xs.
@@ -2699,7 +2705,7 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
                 if (a < jb0) {
                     const double *T = Lf + lf_at(jb0, a);
 #pragma unroll
-                    for (int cc = 0; cc < kPanel; ++cc) lrow[cc] = T[8 * cc];
+                    for (int cc = 0; cc < kPanel; ++cc) lrow[cc] = T[LS * cc];
                     ya = yv[a];
                 }
                 double part = li * zr;
@@ -3455,14 +3461,25 @@ size_t dense_tile_doubles(const Dims &dm) {
     const size_t nbk = ((((size_t)dm.P + 7) & ~(size_t)7) + 16) >> 4;
     return nbk * (nbk + 1) / 2 * 256; // 16 x 16 tiles of the lower block triangle incl. the rhs row
 }
+// bytes of dynamic LDS of the register-resident form at row stride `ls` of Xs / Lf (k_dense's template parameter LS)
+static size_t dense_lds_bytes_at(const Dims &dm, int ls) {
+    const size_t nbk = ((((size_t)dm.P + 7) & ~(size_t)7) + 16) >> 4, LDV = nbk << 4;
+    const size_t vec = (352 + 8 * LDV + (size_t)ls * LDV) * sizeof(double); // header, 8 vectors, Xs
+    const size_t npan = (((size_t)dm.P + 7) & ~(size_t)7) / 8;
+    const size_t lfull = (size_t)ls * (npan * LDV - 4 * npan * (npan - 1)); // finished panels of L (overlays the tile image)
+    return std::max(dense_tile_doubles(dm), lfull) * sizeof(double) + vec;
+}
+// 8, or -- PVIO_HIP_DENSE_ROW_STRIDE=10, experiments only -- rows padded to 80 bytes where the LDS holds them.  Measured on the metric window
+// (profiles/r5_ab_row_stride.txt): 13 964 iterations/s padded against 14 056 unpadded, i.e. the bank conflicts of the factor wave's row accesses
+// that tools/ubench/wave_costs.hip shows in isolation (899 against 391 cycles per 12 ds_write_b128) are NOT on the panel loop's critical path.
+int dense_row_stride(const Dims &dm) {
+    static const int forced = std::getenv("PVIO_HIP_DENSE_ROW_STRIDE") ? std::atoi(std::getenv("PVIO_HIP_DENSE_ROW_STRIDE")) : 0;
+    return (forced == 10 && dm.dense_la && dense_lds_bytes_at(dm, 10) <= 160 * 1024) ? 10 : 8;
+}
 size_t dense_lds_bytes(const Dims &dm, int *lds_matrix) {
     const size_t nbk = ((((size_t)dm.P + 7) & ~(size_t)7) + 16) >> 4, LDV = nbk << 4;
-    const size_t vec = (352 + 16 * LDV) * sizeof(double); // header, 8 vectors, panel buffer
-    const size_t npan = (((size_t)dm.P + 7) & ~(size_t)7) / 8;
-    const size_t lfull = 8 * (npan * LDV - 4 * npan * (npan - 1)); // finished panels of L (overlays the tile image)
-    const size_t mat = std::max(dense_tile_doubles(dm), lfull) * sizeof(double);
-    *lds_matrix = (mat + vec <= 160 * 1024 && LDV <= 176) ? 1 : 0;
-    if (*lds_matrix) return mat + vec;
+    *lds_matrix = (dense_lds_bytes_at(dm, 8) <= 160 * 1024 && LDV <= 176) ? 1 : 0;
+    if (*lds_matrix) return dense_lds_bytes_at(dm, dense_row_stride(dm));
     return (352 + 8 * LDV + LDV * (size_t)(dense_panel_width((int)LDV) + 2)) * sizeof(double); // header, 8 vectors, LDS panel
 }
 
@@ -3475,6 +3492,8 @@ hipError_t launch_dense(const View &v, hipStream_t st) {
         if (e != hipSuccess) return e;
         e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dense<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_dense<true, true, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
         configured = lds;
     }
     if (!lm && lds > configured_g) {
@@ -3482,10 +3501,13 @@ hipError_t launch_dense(const View &v, hipStream_t st) {
         if (e != hipSuccess) return e;
         configured_g = lds;
     }
+    const bool la = lm && v.dm.dense_la && v.dm.split_fin && v.dm.use_img;
+    const int ls = la ? dense_row_stride(v.dm) : 8;
     static const bool say = std::getenv("PVIO_HIP_DEBUG_LAUNCH") != nullptr;
     static bool said = false;
-    if (say && !said) said = true, std::fprintf(stderr, "launch_dense: lds matrix %d, look-ahead %d, split finalize %d, qvv in backsub %d\n", lm, v.dm.dense_la, v.dm.split_fin, v.dm.qvv_back);
-    if (lm && v.dm.dense_la && v.dm.split_fin && v.dm.use_img) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_dense<true, true>), dim3(1), dim3(kDenseThreads), lds, st, v);
+    if (say && !said) said = true, std::fprintf(stderr, "launch_dense: lds matrix %d, look-ahead %d, split finalize %d, qvv in backsub %d, row stride %d, lds %zu\n", lm, v.dm.dense_la, v.dm.split_fin, v.dm.qvv_back, ls, lds);
+    if (la && ls == 10) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_dense<true, true, 10>), dim3(1), dim3(kDenseThreads), lds, st, v);
+    else if (la) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_dense<true, true>), dim3(1), dim3(kDenseThreads), lds, st, v);
     else if (lm) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_dense<true, false>), dim3(1), dim3(kDenseThreads), lds, st, v);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_dense<false, false>), dim3(1), dim3(2 * kDenseThreads), lds, st, v);
     return hipGetLastError();

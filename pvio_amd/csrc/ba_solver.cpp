@@ -562,7 +562,10 @@ int BASolver::run_slots(int n_slots) {
                 sharded_graph_failed_ = true;
             }
         }
-        if (ok) return check(hipGraphLaunch(graph_exec_, stream_), "graph launch");
+        if (ok) {
+            ++graph_replays_;
+            return check(hipGraphLaunch(graph_exec_, stream_), "graph launch");
+        }
     }
     for (int s = 0; s < n_slots; ++s) {
         int rc = enqueue_slot();

@@ -41,6 +41,7 @@ class BASolver {
     void set_linearize_mode(int m) { lin_mode_ = m; }
     void set_reuse_candidates(bool on) { reuse_cand_ = on; }
     int last_candidate_repeats() const { return last_repeats_; }
+    int graph_replays() const { return graph_replays_; }
     ~BASolver();
     int upload(const pvio_ba_problem *pb, const pvio_ba_state *st, bool may_return_early = false);   // H2D of the flat problem + initial state
     // runs from the uploaded initial state; `read_back`: the accepted iterate + quality pass land in the caller's arrays as part of the same
@@ -66,6 +67,7 @@ class BASolver {
     int lin_mode_ = 0; // pvio_hip_opts::linearize_mode
     bool reuse_cand_ = false; // pvio_hip_opts::reuse_identical_candidates
     int last_repeats_ = 0;    // Ctrl::cand_repeats of the last solve
+    int graph_replays_ = 0;   // hipGraphLaunch calls so far (diagnostics: pvio_hip_ba_graph_replays)
     int dbg_fail_ = 0, dbg_invalid_ = 0; // tests only: forced factorization failures / invalid steps per solve
     hipStream_t stream_ = nullptr;
     hipEvent_t ev0_ = nullptr, ev1_ = nullptr;

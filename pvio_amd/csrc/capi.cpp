@@ -76,6 +76,7 @@ int32_t pvio_hip_ba_profile_resident(pvio_hip_ctx *ctx, pvio_ba_summary *summary
     if (!ctx || !times) return PVIO_ERR_INVALID_ARGUMENT;
     return ctx->ba->solve(summary, times);
 }
+int32_t pvio_hip_ba_graph_replays(const pvio_hip_ctx *ctx) { return ctx && ctx->ba ? ctx->ba->graph_replays() : 0; }
 int32_t pvio_hip_ba_last_candidate_repeats(const pvio_hip_ctx *ctx) { return ctx && ctx->ba ? ctx->ba->last_candidate_repeats() : 0; }
 int32_t pvio_hip_ba_download(pvio_hip_ctx *ctx, pvio_ba_state *state) {
     if (!ctx) return PVIO_ERR_INVALID_ARGUMENT;

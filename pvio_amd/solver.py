@@ -62,6 +62,11 @@ class HipContext:
         self._check(self.lib.pvio_hip_ba_upload(self.ctx, C.byref(pb), C.byref(st)), "pvio_hip_ba_upload")
         return state
 
+    def graph_replays(self):
+        """solves of this context that ran as a replay of the captured slot graph"""
+        self.lib.pvio_hip_ba_graph_replays.argtypes = [C.c_void_p]
+        return int(self.lib.pvio_hip_ba_graph_replays(self.ctx))
+
     def last_candidate_repeats(self):
         """candidate evaluations the last solve short-circuited (reuse_identical_candidates)"""
         self.lib.pvio_hip_ba_last_candidate_repeats.argtypes = [C.c_void_p]

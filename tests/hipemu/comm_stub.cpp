@@ -21,8 +21,16 @@ int comm_init(Comm **out, const uint8_t *, int rank, int world, int) {
     *out = new Comm{rank, world};
     return 0;
 }
-int comm_allreduce(Comm *c, double *buf, size_t n, int op_max, hipStream_t) {
+// Inside a stream capture the collective becomes a NODE of the graph, like ncclAllReduce does under hipStreamBeginCapture (RCCL supports
+// capture): it runs at every replay, between the kernels recorded around it -- so that graph-captured collectives execute with more than one
+// rank somewhere (tests/test_multi_rank_cpu.py::test_sharded_graph_replay_with_captured_collectives).
+int comm_allreduce(Comm *c, double *buf, size_t n, int op_max, hipStream_t st) {
     if (!c || !g_allreduce) return 1;
+    if (st && st->capturing) {
+        hipemu_allreduce_fn fn = g_allreduce;
+        st->graph->push_back([fn, buf, n, op_max] { (void)fn(buf, (long)n, op_max); });
+        return 0;
+    }
     return g_allreduce(buf, (long)n, op_max);
 }
 void comm_destroy(Comm *c) { delete c; }
