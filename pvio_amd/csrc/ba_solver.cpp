@@ -224,15 +224,13 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st, bool ma
     dm.G_prior = dm.prior_n; // one workgroup per prior frame
     // One workgroup fits on a CU (registers, LDS) and the IMU / prior workgroups are the longest: the landmark chunks get
     // the CUs that are left, so that the whole grid is resident at once instead of queueing a second round behind it.
-    // Round 5: no more landmark workgroups than it takes to give every factor a thread (256 factors per chunk), and at least 48.  A small window used to
-    // spread its landmarks over every free CU (230 workgroups of ~40 factors at 10 x 1000), i.e. 230 partial rows of 17 KB for k_reduce to sum: 6 MB of
-    // counter traffic per launch against 0.6 MB algorithmic.  The A/B (profiles/r5_ab_partials.txt: 230 / 128 / 64 / 48 / 32 rows, same box) shows the
-    // iteration rate does not depend on the count at all -- every workgroup runs the same latency chain whether it holds 40 factors or 250 -- so the count
-    // is chosen for the traffic.  PVIO_HIP_LM_WGS=n caps it at n instead, -1 restores one chunk per free CU.
+    // One landmark chunk per free CU.  Round 5 measured the alternative the 22x traffic of the partial rows suggests -- fewer, fatter workgroups, i.e.
+    // fewer rows for k_reduce to sum (PVIO_HIP_LM_WGS=n caps the count; profiles/r5_ab_partials.txt): the traffic falls with the count and the
+    // iteration rate with it, because a workgroup's chain grows with the landmarks it holds (the per-landmark sums and the tile accumulation walk
+    // them one after another): 48 rows = 12 161 against 14 112 iterations/s, k_linearize 18.4 -> 29.2 us for 0.4 us less in k_reduce.
     static const int lm_wgs_cap = std::getenv("PVIO_HIP_LM_WGS") ? std::atoi(std::getenv("PVIO_HIP_LM_WGS")) : 0;
     int lm_cus = std::max(1, cus - dm.G_plane - dm.G_pre - dm.G_prior);
     if (lm_wgs_cap > 0) lm_cus = std::min(lm_cus, lm_wgs_cap);
-    else if (lm_wgs_cap == 0) lm_cus = std::min(lm_cus, std::max(48, (F + kLinThreads - 1) / kLinThreads));
     const int slots_lds = (int)std::max<size_t>(1, std::min<size_t>(lds_budget / 8 / (40 * N + 46), (size_t)kLinThreads));
     const int slots_spread = std::max(1, (M + lm_cus - 1) / lm_cus);
     dm.lm_slots = std::min(slots_lds, slots_spread);
