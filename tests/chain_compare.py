@@ -274,3 +274,18 @@ def compare_seq(log_ref, log_dropin, fx, kp_px=2.0e-3):
     assert info["max_kp_px"] <= kp_px, "tracked keypoints differ by %.3g px" % info["max_kp_px"]
     assert info["first_divergence"] is None, info["first_divergence"]
     return info
+
+
+def ate_rmse(tum_path, gt):
+    """Absolute trajectory error the way the TUM / EuRoC benchmarks define it: positions of trajectory.tum (t px py pz q) matched to the ground truth
+    [t p q] by time, aligned by the best rigid transform (Horn / Umeyama without scale), RMSE of what is left.  Returns (rmse [m], poses used)."""
+    T = np.loadtxt(tum_path, ndmin=2)
+    idx = [int(np.argmin(np.abs(gt[:, 0] - t))) for t in T[:, 0]]
+    assert np.abs(gt[idx, 0] - T[:, 0]).max() < 1e-6
+    A, B = T[:, 1:4], gt[idx, 1:4]
+    ca, cb = A.mean(0), B.mean(0)
+    U, _, Vt = np.linalg.svd((B - cb).T @ (A - ca))
+    S = np.diag([1.0, 1.0, np.sign(np.linalg.det(U @ Vt))])
+    R = U @ S @ Vt
+    res = (A - ca) @ R.T + cb - B
+    return float(np.sqrt((res ** 2).sum(1).mean())), int(len(T))

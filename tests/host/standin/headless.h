@@ -25,39 +25,14 @@
 #include <memory>
 #include <vector>
 
+#include "dataset_config.h"
 #include "feature_tracker.h"
 #include "host_seam.h"
 
 namespace pvio {
 
-// Config with the constants of config/euroc.yaml / config/tum-vi.yaml (the reference parses them with yaml-cpp)
-class HeadlessConfig : public Config {
-  public:
-    static std::shared_ptr<HeadlessConfig> euroc();
-    static std::shared_ptr<HeadlessConfig> tum_vi();
-    matrix<3> camera_intrinsic() const override { return K; }
-    quaternion camera_to_body_rotation() const override { return q_bc; }
-    vector<3> camera_to_body_translation() const override { return p_bc; }
-    quaternion imu_to_body_rotation() const override { return q_bi; }
-    vector<3> imu_to_body_translation() const override { return p_bi; }
-    matrix<2> keypoint_noise_cov() const override { return cov_kp; }
-    matrix<3> gyroscope_noise_cov() const override { return cov_g; }
-    matrix<3> accelerometer_noise_cov() const override { return cov_a; }
-    matrix<3> gyroscope_bias_noise_cov() const override { return cov_bg; }
-    matrix<3> accelerometer_bias_noise_cov() const override { return cov_ba; }
-    size_t sliding_window_size() const override { return window; }
-    double feature_tracker_min_keypoint_distance() const override { return min_keypoint_distance; }
-    size_t solver_iteration_limit() const override { return iteration_limit; }
-    size_t initializer_keyframe_gap_() const { return keyframe_gap; }
-
-    matrix<3> K;
-    quaternion q_bc, q_bi;
-    vector<3> p_bc, p_bi;
-    matrix<2> cov_kp;
-    matrix<3> cov_g, cov_a, cov_bg, cov_ba;
-    size_t window = 8, keyframe_gap = 5, iteration_limit = 10;
-    double min_keypoint_distance = 25.0;
-};
+// the dataset constants are product code now (pvio_amd/host/dataset_config.h, round 5): the headless driver needs them whatever control plane it drives
+using HeadlessConfig = DatasetConfig;
 
 struct TimedPose { // body pose in the world frame at time t
     double t;

@@ -148,3 +148,48 @@ def test_reference_pvio_with_the_whole_product_gpu(tmp_path):
     if path:
         import json
         json.dump(out, open(path, "w"), indent=1)
+
+
+def _long_sequence(tmp_path, scene, n_frames=360, window=8, gap=3):
+    """reference's pvio::PVIO + reference back-end + oracle front end against the same pvio::PVIO with the WHOLE product below its seams, over a long sequence
+    on the sweep trajectory; both trajectories against the ground truth (ATE)."""
+    _libs()
+    a, b = str(tmp_path / ("ref_" + scene)), str(tmp_path / ("product_" + scene))
+    line_ref = _run(os.path.join(REFDIR, "libpvio_ref.so"), a, n_frames, window, gap, 25.0, scene, 2400)
+    line_prod = _run(os.path.join(REFDIR, "libpvio_dropin.so"), b, n_frames, window, gap, 25.0, scene, 1200, image="hip")
+    info = chain_compare.compare_seq(a + ".log", b + ".log", hh.K4[0])
+    gt = np.load(a + ".gt.npy")
+    ate_ref, n_ref = chain_compare.ate_rmse(a + ".tum", gt)
+    ate_prod, n_prod = chain_compare.ate_rmse(b + ".tum", gt)
+    ta, tb = np.loadtxt(a + ".tum", ndmin=2), np.loadtxt(b + ".tum", ndmin=2)
+    info.update(scene=scene, n_frames=n_frames, window=window, reference_run=line_ref, product_run=line_prod, ate_rmse_reference_m=ate_ref, ate_rmse_product_m=ate_prod,
+                ate_poses=n_ref, ate_difference_m=abs(ate_ref - ate_prod), trajectory_max_difference_m=float(np.abs(ta[:, 1:4] - tb[:, 1:4]).max()) if ta.shape == tb.shape else None)
+    assert n_ref == n_prod
+    return info
+
+
+@pytest.mark.gpu
+def test_long_sequence_ate_reference_vs_whole_product_gpu(tmp_path):
+    """VERDICT r4 item 8 ("final ATE equal" on more than a handful of keyframe solves): 360 frames at 512 x 384 (18 s, ~31 keyframe solves with a marginalization
+    each, window of 8 like config/euroc.yaml:50), relief scene -- no planes, so the two runs make the same discrete choices throughout: identical track ids,
+    flags and keypoints in all 360 frames, every window state within 1e-6, and the same ATE to well below a micrometre.
+    PVIO_LONG_SEQUENCE_WALL=1 adds the wall scene (planes extracted, cast and constrained): strict until the reference's own best-plane coin flip
+    (chain_compare.compare_seq), reported poses within 5 cm after it, both ATEs reported."""
+    import json
+    out = {}
+    info = _long_sequence(tmp_path, "full_relief_sweep")
+    print("long sequence, relief scene:", info)
+    assert info["frames"] == 360 and info["strict_frames"] == 360 and info["keyframes"] >= 30 and info["max_state"] <= 1e-6 and info["max_kp_px"] <= 1e-3
+    assert info["ate_difference_m"] <= 1e-6 and info["ate_rmse_product_m"] < 0.08
+    out["relief"] = info
+    if os.environ.get("PVIO_LONG_SEQUENCE_WALL"):
+        info = _long_sequence(tmp_path, "full_sweep")
+        print("long sequence, wall scene (planes on):", info)
+        assert info["frames"] == 360 and info["keyframes"] >= 1 and info["planes_seen"] >= 1
+        # (the REFERENCE's own run of this scene has an ATE of 13 cm: its plane factors pull the window, see SURVEY App. D quirk 3; what is held is that the product's run
+        # stays with the reference's, not that either is good)
+        assert info["ate_difference_m"] < 0.03
+        out["wall"] = info
+    path = os.environ.get("PVIO_SEQ_REPORT_LONG")
+    if path:
+        json.dump(out, open(path, "w"), indent=1)

@@ -7,6 +7,8 @@ This is an end-to-end plumbing test of the rows SURVEY.md section 8 marks K6 / F
 trajectory to compare with (the reference cannot run here), so the bar is the known ground truth of the rendered scene."""
 import ctypes as C
 
+import os
+
 import numpy as np
 import pytest
 
@@ -73,15 +75,35 @@ def _undistorted_rays(us, vs, K4, dist, model="radtan"):
     return x, y
 
 
-def render_sequence(n_frames, fps=20.0, imu_rate=200.0, t_start=0.0, size=None, relief=False, distortion=None, model="radtan", extrinsics=None):
+# A trajectory for LONG sequences: synth._pose orbits the centre at a constant rate and leaves the +-40 degrees in front of the wall after
+# ~4 s; this one sweeps back and forth on the same circle -- theta(t) = TH0 + A sin(w t), peak rate A w = OMEGA as before -- so that any number of frames
+# keeps the wall (or the relief) in view.  Same frame conventions, analytic velocity / acceleration / yaw rate for the IMU.
+SWEEP_A, SWEEP_W = 0.6, 0.5
+
+
+def _pose_sweep(t):
+    R0, H_AMP, H_FREQ = synth.RADIUS, synth.H_AMP, synth.H_FREQ
+    th, dth, ddth = SWEEP_A * np.sin(SWEEP_W * t), SWEEP_A * SWEEP_W * np.cos(SWEEP_W * t), -SWEEP_A * SWEEP_W ** 2 * np.sin(SWEEP_W * t)
+    c, s = np.cos(th), np.sin(th)
+    p = np.array([R0 * c, R0 * s, H_AMP * np.sin(H_FREQ * t)])
+    v = np.array([-R0 * s * dth, R0 * c * dth, H_AMP * H_FREQ * np.cos(H_FREQ * t)])
+    acc = np.array([-R0 * (c * dth ** 2 + s * ddth), R0 * (-s * dth ** 2 + c * ddth), -H_AMP * H_FREQ ** 2 * np.sin(H_FREQ * t)])
+    up, fwd = np.array([0.0, 0.0, 1.0]), np.array([-c, -s, 0.0])
+    R = np.stack([up, np.cross(fwd, up), fwd], 1)
+    return R, p, v, acc, dth
+
+
+def render_sequence(n_frames, fps=20.0, imu_rate=200.0, t_start=0.0, size=None, relief=False, distortion=None, model="radtan", extrinsics=None, sweep=False):
     """images (n, H, W) u8, image times, IMU (t, w, a), body poses at the image times (t p q).  relief: the textured surface is the wall plus _relief()
     (ray / surface intersection by fixed-point iteration) instead of the wall itself: a scene without planes."""
     W, H, K4 = size if size is not None else (globals()["W"], globals()["H"], globals()["K4"])
     q_bc = synth.Q_BC / np.linalg.norm(synth.Q_BC)
     R_bc, p_bc = synth.qmat(q_bc), synth.P_BC
     # the wall: through the orbit centre, facing the camera at mid-sequence, tilted by 20 degrees so that depth varies
-    t_mid = t_start + 0.5 * n_frames / fps
-    R_mid, p_mid, _, _ = synth._pose(t_mid)
+    pose = (lambda t: _pose_sweep(t)[:4]) if sweep else synth._pose
+    yaw_rate = (lambda t: _pose_sweep(t)[4]) if sweep else (lambda t: synth.OMEGA)
+    t_mid = 0.0 if sweep else t_start + 0.5 * n_frames / fps  # (sweep: the wall faces the centre of the sweep)
+    R_mid, p_mid, _, _ = pose(t_mid)
     fwd = R_mid[:, 2]
     tilt = np.deg2rad(20.0)
     nrm = np.cos(tilt) * fwd + np.sin(tilt) * R_mid[:, 1]
@@ -108,7 +130,7 @@ def render_sequence(n_frames, fps=20.0, imu_rate=200.0, t_start=0.0, size=None, 
     images, times, poses = [], [], []
     for k in range(n_frames):
         t = t_start + k / fps
-        R, p, _, _ = synth._pose(t)
+        R, p, _, _ = pose(t)
         R_wc, p_wc = R @ R_bc, p + R @ p_bc
         rays = rays_c @ R_wc.T
         s = (d - nrm @ p_wc) / (rays @ nrm)
@@ -128,8 +150,8 @@ def render_sequence(n_frames, fps=20.0, imu_rate=200.0, t_start=0.0, size=None, 
     nw = rng.normal(0, np.sqrt(synth.COV_G * imu_rate), (n_imu, 3))
     na = rng.normal(0, np.sqrt(synth.COV_A * imu_rate), (n_imu, 3))
     for k in range(n_imu):
-        R, _, _, acc = synth._pose(imu_t[k])
-        imu_w[k] = np.array([synth.OMEGA, 0.0, 0.0]) + bg + nw[k]  # body x = world z (synth._pose)
+        R, _, _, acc = pose(imu_t[k])
+        imu_w[k] = np.array([yaw_rate(imu_t[k]), 0.0, 0.0]) + bg + nw[k]  # body x = world z (synth._pose)
         imu_a[k] = R.T @ (acc + np.array([0, 0, synth.GRAVITY])) + ba + na[k]
     return (np.ascontiguousarray(np.stack(images)), np.array(times), imu_t, np.ascontiguousarray(imu_w), np.ascontiguousarray(imu_a),
             np.ascontiguousarray(np.stack(poses)), q_bc, p_bc)
@@ -175,20 +197,10 @@ def test_headless_pipeline_follows_the_rendered_trajectory():
 # kernel emulator, compared record by record with the oracle chain and with the ground truth
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("kind", ["euroc", "tum"])
-def test_headless_binary_on_a_dataset_layout_sequence(tmp_path, kind):
-    """BASELINE configs[0]'s plumbing with the actual binary (tools/pvio_headless.cpp, the sequence loop of pvio-pc/src/main.cpp:207-258): a sequence ON DISK in
-    EuRoC's layout -- cam0/data.csv + cam0/data/<ns>.png recorded through EuRoC's lens (752 x 480, the intrinsics and radial-tangential coefficients of
-    euroc_dataset_reader.cpp:73-74), imu0/data.csv at 200 Hz, CRLF line ends -- goes through the readers (CSV, PNG decode), the device undistortion, the front
-    end, PnP and the sliding-window BA, and comes out as trajectory.tum (output_writer.h:41-50 format), which follows the ground truth.
-    kind "tum": TUM-VI's layout and camera (512 x 512 equidistant fisheye, tum_dataset_reader.cpp:73-81, LF line ends)."""
-    import os
+def _binary_on_dataset_layout(tmp_path, kind, binary, n_frames=36, window="6", gap="3", timeout=600, bounds=(0.05, 0.12), min_poses=12):
+    """writes a rendered sequence to disk in the dataset's layout, runs `binary` (a build of tools/pvio_headless.cpp) on it, checks trajectory.tum"""
     import subprocess
     import test_host_ingest as ing
-    host_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host")
-    subprocess.check_call(["make", "-s", "-C", host_dir, "pvio_headless"])
-    n_frames = 36
     if kind == "euroc":
         W_, H_, K4e, dist, model, ext = 752, 480, np.array([458.654, 457.296, 367.215, 248.375]), ing.EUROC_D, "radtan", None
     else:  # config/tum-vi.yaml:13-22
@@ -204,17 +216,57 @@ def test_headless_binary_on_a_dataset_layout_sequence(tmp_path, kind):
     with open(gt_path, "w") as f:
         for g in gt:
             f.write(" ".join(repr(float(v)) for v in ([g[0] + t0 * 1e-9] + list(g[1:]))) + "\n")
-    r = subprocess.run([os.path.join(host_dir, "pvio_headless"), kind + "://" + str(root), str(gt_path), str(out_path), "-1", "6", "3"], capture_output=True, text=True,
-                       timeout=600)  # window of 6 keyframes 3 frames apart: the first window exists at frame 15 of the 36
+    r = subprocess.run([binary, kind + "://" + str(root), str(gt_path), str(out_path), "-1", window, gap], capture_output=True, text=True,
+                       timeout=timeout)  # window of 6 keyframes 3 frames apart: the first window exists at frame 15 of the 36
     assert r.returncode == 0, r.stderr[-2000:]
-    print(r.stderr.strip().splitlines()[-1])
     lines = [l.split() for l in open(out_path).read().strip().splitlines()]
-    assert len(lines) >= 12 and all(len(l) == 8 for l in lines), (len(lines), r.stderr[-500:])
+    assert len(lines) >= min_poses and all(len(l) == 8 for l in lines), (len(lines), r.stderr[-500:])
     assert all("." in l[1] and len(l[1].split(".")[1]) >= 9 for l in lines)  # full precision, not %g
     tum = np.array(lines, float)
     idx = [int(np.argmin(np.abs(gt[:, 0] + t0 * 1e-9 - t))) for t in tum[:, 0]]
     assert np.abs(gt[idx, 0] + t0 * 1e-9 - tum[:, 0]).max() < 1e-6
     err = np.linalg.norm(tum[:, 1:4] - gt[idx, 1:4], axis=1)
-    print("pvio_headless on the " + kind + "-layout sequence: %d poses, position error cm: median %.2f max %.2f; %s" % (
+    print(os.path.basename(binary) + " on the " + kind + "-layout sequence: %d poses, position error cm: median %.2f max %.2f; %s" % (
         len(tum), 100 * np.median(err), 100 * err.max(), r.stderr.strip().splitlines()[-1]))
-    assert np.median(err) < 0.05 and err.max() < 0.12
+    assert np.median(err) < bounds[0] and err.max() < bounds[1]
+    return tum
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["euroc", "tum"])
+def test_headless_binary_on_a_dataset_layout_sequence(tmp_path, kind):
+    """BASELINE configs[0]'s plumbing with the actual binary (tools/pvio_headless.cpp, the sequence loop of pvio-pc/src/main.cpp:207-258): a sequence ON DISK in
+    EuRoC's layout -- cam0/data.csv + cam0/data/<ns>.png recorded through EuRoC's lens (752 x 480, the intrinsics and radial-tangential coefficients of
+    euroc_dataset_reader.cpp:73-74), imu0/data.csv at 200 Hz, CRLF line ends -- goes through the readers (CSV, PNG decode), the device undistortion, the front
+    end, PnP and the sliding-window BA, and comes out as trajectory.tum (output_writer.h:41-50 format), which follows the ground truth.
+    kind "tum": TUM-VI's layout and camera (512 x 512 equidistant fisheye, tum_dataset_reader.cpp:73-81, LF line ends).
+    This is the build above the STAND-IN control plane (tests/host/standin); the one above the reference's own pvio::PVIO is the next test."""
+    import subprocess
+    host_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host")
+    subprocess.check_call(["make", "-s", "-C", host_dir, "pvio_headless"])
+    _binary_on_dataset_layout(tmp_path, kind, os.path.join(host_dir, "pvio_headless"))
+
+
+def _reference_pvio_binary(name):
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "oracle", "ref"), "headless"])
+    path = os.path.join(root, "oracle", "_ref", name)
+    if not os.path.exists(path):
+        pytest.skip("oracle/_ref/%s not built and /root/reference absent" % name)
+    return path
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["euroc", "tum"])
+def test_headless_binary_above_the_reference_pvio(tmp_path, kind):
+    """the SAME tools/pvio_headless.cpp built against the reference's own pvio::PVIO (oracle/ref/Makefile `headless`: the reference's
+    pvio.cpp, core/*.cpp, map/*.cpp compiled from /root/reference, the product's BundleAdjustor / visual_inertial_pnp / HipImage / readers linked in,
+    nothing from tests/) on the same on-disk sequences: PNG + CSV readers -> device undistortion -> PVIO::track_* -> trajectory.tum."""
+    _binary_on_dataset_layout(tmp_path, kind, _reference_pvio_binary("pvio_headless"))
+
+
+def test_headless_binary_above_the_reference_pvio_emulated(tmp_path):
+    """the same binary above the kernel emulator (CPU suite): 14 frames of the TUM-VI-layout sequence through PNG / CSV readers, emulated undistortion, front end,
+    the reference's pvio::PVIO, PnP and the window solves; a window of 3 keyframes 2 frames apart exists from frame 6 on"""
+    _binary_on_dataset_layout(tmp_path, "tum", _reference_pvio_binary("pvio_headless_emu"), n_frames=14, window="3", gap="2", timeout=1200, bounds=(0.06, 0.12), min_poses=6)
