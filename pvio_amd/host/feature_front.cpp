@@ -1,6 +1,9 @@
 // feature_front.cpp -- see feature_front.h.  Host C++ above the C ABI; no OpenCV, no Eigen.
 #include "feature_front.h"
 
+#include <cstdio>
+#include <cstdlib>
+
 #include "fundamental_ransac.h"
 
 #include <algorithm>
@@ -241,8 +244,16 @@ void HipImage::track_keypoints(const Image *next_image, const std::vector<vector
     if (next && n > 0) {
         if (!img_ || !next->img_) throw std::runtime_error("HipImage::track_keypoints: preprocess() was not called");
         std::vector<uint8_t> st(n, 0);
+        const std::vector<float> init_xy = next_xy;
         const int32_t rc = pvio_hip_klt_track(ctx_, img_, next->img_, (int32_t)n, prev_xy.data(), next_xy.data(), st.data()); // LK + 20 px border gate
         if (rc != 0) throw std::runtime_error(std::string("pvio_hip_klt_track: ") + pvio_hip_last_error(ctx_));
+        if (const char *dump = std::getenv("PVIO_KLT_DUMP")) { // diagnostics: every LK call's inputs and outputs, appended to <dump>_hip.bin (tests/probe_klt_dump.py replays them)
+            if (FILE *f = std::fopen((std::string(dump) + "_hip.bin").c_str(), "ab")) {
+                const int32_t nn = (int32_t)n;
+                std::fwrite(&nn, 4, 1, f), std::fwrite(prev_xy.data(), 4, 2 * n, f), std::fwrite(init_xy.data(), 4, 2 * n, f), std::fwrite(next_xy.data(), 4, 2 * n, f), std::fwrite(st.data(), 1, n, f);
+                std::fclose(f);
+            }
+        }
         for (size_t i = 0; i < n; ++i) result_status[i] = (char)st[i];
     }
     if (filter_) {

@@ -6,6 +6,9 @@
 #pragma once
 #include <algorithm>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
 #include <stdexcept>
 #include <vector>
 
@@ -93,7 +96,15 @@ class OracleImage : public Image {
             std::vector<const int16_t *> pd(L);
             for (size_t l = 0; l < L; ++l) pi[l] = img_[l].data(), pd[l] = drv_[l].data(), ni[l] = nx->img_[l].data();
             std::vector<uint8_t> st(n, 0);
+            const std::vector<float> q_init = q;
             oracle_klt_track((int)L, ws_.data(), hs_.data(), pi.data(), pd.data(), ni.data(), (int)n, p.data(), q.data(), st.data());
+            if (const char *dump = std::getenv("PVIO_KLT_DUMP")) { // diagnostics (see HipImage::track_keypoints): <dump>_oracle.bin
+                if (FILE *f = std::fopen((std::string(dump) + "_oracle.bin").c_str(), "ab")) {
+                    const int32_t nn = (int32_t)n;
+                    std::fwrite(&nn, 4, 1, f), std::fwrite(p.data(), 4, 2 * n, f), std::fwrite(q_init.data(), 4, 2 * n, f), std::fwrite(q.data(), 4, 2 * n, f), std::fwrite(st.data(), 1, n, f);
+                    std::fclose(f);
+                }
+            }
             for (size_t i = 0; i < n; ++i) status[i] = (char)st[i];
         }
         std::vector<size_t> l;

@@ -136,13 +136,11 @@ def test_gpu_corner_detection_random_images_exact(oracle):
 
 
 def test_gpu_lk_border_corner_starts_are_bit_identical(gpu_ctx, oracle):
-    """Round 5: the long-sequence run (test_dropin_sequence.py::test_long_sequence_*, 360 frames on the sweep trajectory) stays strictly identical between
-    the reference's pipeline above the CPU oracle's front end and above the product for 63 frames; then ONE track -- a corner detected exactly on the
-    20-pixel border, (20, 294) in frame 62 -- comes back from LK 54 px apart in the two runs (its start is a gyro prediction that carries the two
-    back-ends' 1e-10 into a float32, its gradient matrix is next to singular at the coarse levels), and a new corner is blocked in one run only.
-    This test holds the two LK implementations together on exactly that input class: frames 62 -> 63 of that sequence, every keypoint position of the
-    image grid border plus a dense grid of 243 starts around the border corner: status bytes identical, positions bit-identical -- i.e. the two
-    implementations are ONE function of their inputs, and what separated the runs is the input, not the kernel."""
+    """Round 5, from the diagnosis of the long-sequence run (test_dropin_sequence.py::test_long_sequence_*): corners detected exactly ON the 20-pixel
+    border -- (20, 294) in frame 62 of that sequence -- are legal keypoints whose windows reach into the padding at every coarse level, and whose LK result
+    is killed by the output gate as soon as it moves outward.  Frames 62 -> 63 of that sequence: a dense grid of 243 starts around that corner and 207
+    points along the whole border ring, no initial flow: status bytes identical, positions bit-identical between the oracle and the kernel.  (What did
+    separate the two runs of that sequence was a tie in the F-matrix RANSAC, not LK: every LK call's inputs and outputs were bit-identical.)"""
     import test_host_headless as hh
     from pvio_amd.solver import HipImage, klt_track
     images, *_ = hh.render_sequence(64, relief=True, sweep=True)
