@@ -223,14 +223,158 @@ int update_num_iters(double p, double ep, int model_points, int max_iters) {
     return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)std::lround(num / denom);
 }
 
+
+// ---- the DEFINED arithmetic of the seven-point step (round 5) -------------------------------------------------------------------------------------
+// RANSAC keeps the first hypothesis that reaches the best inlier count, a correspondence whose error sits on the threshold moves a count by one, and two
+// hypotheses tie often enough that a long sequence meets it (tests/golden/ransac_ties.npz): the independent restatement above and the product then keep
+// DIFFERENT hypotheses -- both legitimate, nothing in the reference says which one OpenCV's own rounding would keep -- and a sequence-level comparison
+// ends there.  As for the LK sums (oracle_klt.cpp), the order of operations is therefore DEFINED, here, and the kernel is held to it bit for bit
+// (pvio_amd/csrc/pv_fundamental.h implements the same sequence; tests/test_host_ransac.py):
+//   null space   Householder QR of A^T (9 x 7), reflector c: v = column below the diagonal, v_c -= alpha with alpha = -sign(M_cc) |column|, beta = 2 / v.v,
+//                applied to columns c..6; the basis is Q e_7, Q e_8 (reflectors applied in reverse order to the unit vectors)
+//   cubic        det(f2 + l (f1 - f2)): c3 = det f2, c0 = det D, c2 / c1 = sums over the rows of the determinants with one row exchanged
+//   roots        Q, R of the normalized cubic as in cv::solveCubic; three real roots: c = cos(theta / 3) by 64 bisection steps on 4 c^3 - 3 c = R / sqrt(Q^3) in
+//                [1/2, 1], the other two from the angle-sum identities (order k = 0, 1, 2 of the closed form); one real root: cube root by 12 Newton steps from a
+//                power of two; only +, -, *, /, sqrt (correctly rounded everywhere), no FMA contraction (-ffp-contract=off here, a pragma there)
+//   scaling      F = f2 + l D, times 1 / F[8] when |F[8]| > DBL_EPSILON, else 1 / |F|
+// The entry points above stay what the ALGORITHM is checked against (another null-space method, libm's closed form), at a tolerance.
+namespace defined {
+
+double det3(const double *m) { return m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]); }
+
+double cube_root(double x) {
+    if (!(x > 0)) return 0.0;
+    int e;
+    (void)std::frexp(x, &e);
+    const int k = e >= 0 ? e / 3 : -((-e + 2) / 3);
+    double y = std::ldexp(1.0, k);
+    for (int it = 0; it < 12; ++it) y = (2.0 * y + x / (y * y)) * (1.0 / 3.0);
+    return y;
+}
+
+int cubic_roots(const double c[4], double x[3]) {
+    const double a0 = c[0];
+    if (a0 == 0) {
+        if (c[1] == 0) {
+            if (c[2] == 0) return 0;
+            x[0] = -c[3] / c[2];
+            return 1;
+        }
+        double d = c[2] * c[2] - 4 * c[1] * c[3];
+        if (d < 0) return 0;
+        d = std::sqrt(d);
+        const double q1 = (-c[2] + d) * 0.5, q2 = (c[2] + d) * -0.5;
+        if (std::fabs(q1) > std::fabs(q2)) x[0] = q1 / c[1], x[1] = c[3] / q1;
+        else x[0] = q2 / c[1], x[1] = c[3] / q2;
+        return d > 0 ? 2 : 1;
+    }
+    const double a1 = c[1] / a0, a2 = c[2] / a0, a3 = c[3] / a0;
+    const double Q = (a1 * a1 - 3 * a2) * (1. / 9), R = (2 * a1 * a1 * a1 - 9 * a1 * a2 + 27 * a3) * (1. / 54), Qc = Q * Q * Q;
+    double d = Qc - R * R;
+    if (d > 0) {
+        const double r = R / std::sqrt(Qc), t0 = -2 * std::sqrt(Q), t2 = a1 * (1. / 3);
+        double lo = 0.5, hi = 1.0;
+        for (int it = 0; it < 64; ++it) {
+            const double mid = 0.5 * (lo + hi);
+            if ((4.0 * mid * mid - 3.0) * mid < r) lo = mid;
+            else hi = mid;
+        }
+        const double cs = 0.5 * (lo + hi), sn = std::sqrt((1.0 - cs) * (1.0 + cs)), half_sqrt3 = 0.86602540378443864676;
+        x[0] = t0 * cs - t2, x[1] = t0 * (-0.5 * cs - sn * half_sqrt3) - t2, x[2] = t0 * (-0.5 * cs + sn * half_sqrt3) - t2;
+        return 3;
+    }
+    if (d == 0) {
+        if (R >= 0) x[0] = -2 * cube_root(R) - a1 / 3, x[1] = cube_root(R) - a1 / 3;
+        else x[0] = 2 * cube_root(-R) - a1 / 3, x[1] = -cube_root(-R) - a1 / 3;
+        return 2;
+    }
+    d = std::sqrt(-d);
+    double e = cube_root(d + std::fabs(R));
+    if (R > 0) e = -e;
+    x[0] = (e + Q / e) - a1 * (1. / 3);
+    return 1;
+}
+
+int seven_point(const float *p, const float *q, double *F) {
+    double M[9][7];
+    for (int i = 0; i < 7; ++i) {
+        const double x1 = p[2 * i], y1 = p[2 * i + 1], x2 = q[2 * i], y2 = q[2 * i + 1];
+        const double row[9] = {x2 * x1, x2 * y1, x2, y2 * x1, y2 * y1, y2, x1, y1, 1.0};
+        for (int k = 0; k < 9; ++k) M[k][i] = row[k];
+    }
+    double v[7][9], beta[7];
+    for (int c = 0; c < 7; ++c) {
+        double nrm = 0;
+        for (int k = c; k < 9; ++k) nrm += M[k][c] * M[k][c];
+        nrm = std::sqrt(nrm);
+        for (int k = 0; k < 9; ++k) v[c][k] = 0;
+        if (nrm == 0) {
+            beta[c] = 0;
+            continue;
+        }
+        const double alpha = M[c][c] > 0 ? -nrm : nrm;
+        for (int k = c; k < 9; ++k) v[c][k] = M[k][c];
+        v[c][c] -= alpha;
+        double vv = 0;
+        for (int k = c; k < 9; ++k) vv += v[c][k] * v[c][k];
+        beta[c] = vv > 0 ? 2.0 / vv : 0.0;
+        for (int j = c; j < 7; ++j) {
+            double d = 0;
+            for (int k = c; k < 9; ++k) d += v[c][k] * M[k][j];
+            d *= beta[c];
+            for (int k = c; k < 9; ++k) M[k][j] -= d * v[c][k];
+        }
+    }
+    double f1[9], f2[9];
+    for (int which = 0; which < 2; ++which) {
+        double e[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        e[7 + which] = 1.0;
+        for (int c = 6; c >= 0; --c) {
+            double d = 0;
+            for (int k = c; k < 9; ++k) d += v[c][k] * e[k];
+            d *= beta[c];
+            for (int k = c; k < 9; ++k) e[k] -= d * v[c][k];
+        }
+        for (int k = 0; k < 9; ++k) (which == 0 ? f1 : f2)[k] = e[k];
+    }
+    double D[9], tmp[9], c[4];
+    for (int k = 0; k < 9; ++k) D[k] = f1[k] - f2[k];
+    c[3] = det3(f2), c[0] = det3(D), c[2] = 0, c[1] = 0;
+    for (int row = 0; row < 3; ++row) {
+        for (int k = 0; k < 9; ++k) tmp[k] = f2[k];
+        for (int k = 0; k < 3; ++k) tmp[3 * row + k] = D[3 * row + k];
+        c[2] += det3(tmp);
+        for (int k = 0; k < 9; ++k) tmp[k] = D[k];
+        for (int k = 0; k < 3; ++k) tmp[3 * row + k] = f2[3 * row + k];
+        c[1] += det3(tmp);
+    }
+    double roots[3];
+    const int n = cubic_roots(c, roots);
+    int m = 0;
+    for (int k = 0; k < n; ++k) {
+        const double l = roots[k];
+        double *Fk = F + 9 * m, nrm = 0;
+        for (int e = 0; e < 9; ++e) Fk[e] = f2[e] + l * D[e], nrm += Fk[e] * Fk[e];
+        if (!(nrm > 0) || !std::isfinite(nrm)) continue;
+        const double s = std::fabs(Fk[8]) > DBL_EPSILON ? 1.0 / Fk[8] : 1.0 / std::sqrt(nrm);
+        for (int e = 0; e < 9; ++e) Fk[e] *= s;
+        ++m;
+    }
+    return m;
+}
+
+} // namespace defined
+
 } // namespace
 
 extern "C" {
 
 int32_t oracle_seven_point(const float *p, const float *q, double *F27) { return seven_point(p, q, F27); }
+int32_t oracle_seven_point_defined(const float *p, const float *q, double *F27) { return defined::seven_point(p, q, F27); }
 
 // -> number of inliers of the best model (0: no model); mask[n] and F[9] filled when > 0
-int32_t oracle_find_fundamental_ransac(int32_t n, const float *p, const float *q, double threshold, double confidence, int32_t max_iters, uint8_t *mask, double *F_out) {
+static int32_t find_fundamental_ransac_with(int (*seven)(const float *, const float *, double *), int32_t n, const float *p, const float *q, double threshold,
+                                            double confidence, int32_t max_iters, uint8_t *mask, double *F_out) {
     constexpr int kModel = 7;
     for (int i = 0; i < n; ++i) mask[i] = 0;
     if (n < kModel) return 0;
@@ -268,7 +412,7 @@ int32_t oracle_find_fundamental_ransac(int32_t n, const float *p, const float *q
             std::copy(p, p + 2 * kModel, ms1.begin()), std::copy(q, q + 2 * kModel, ms2.begin());
         }
         double models[27];
-        const int nmodels = seven_point(ms1.data(), ms2.data(), models);
+        const int nmodels = seven(ms1.data(), ms2.data(), models);
         if (nmodels <= 0) continue;
         for (int m = 0; m < nmodels; ++m) {
             const int good = find_inliers(n, p, q, models + 9 * m, thresh2, cur.data());
@@ -285,6 +429,15 @@ int32_t oracle_find_fundamental_ransac(int32_t n, const float *p, const float *q
         if (F_out) std::copy(best_model, best_model + 9, F_out);
     }
     return max_good;
+}
+// the independent restatement (Jacobi null space, closed-form roots through libm): the check of the algorithm
+int32_t oracle_find_fundamental_ransac(int32_t n, const float *p, const float *q, double threshold, double confidence, int32_t max_iters, uint8_t *mask, double *F_out) {
+    return find_fundamental_ransac_with(seven_point, n, p, q, threshold, confidence, max_iters, mask, F_out);
+}
+// the same loop over the seven-point step in its DEFINED arithmetic: what the kernel is held to bit for bit, and what the sequence-level chains use
+int32_t oracle_find_fundamental_ransac_defined(int32_t n, const float *p, const float *q, double threshold, double confidence, int32_t max_iters, uint8_t *mask,
+                                               double *F_out) {
+    return find_fundamental_ransac_with(defined::seven_point, n, p, q, threshold, confidence, max_iters, mask, F_out);
 }
 
 } // extern "C"

@@ -12,6 +12,15 @@
 //                            det(l F1 + (1 - l) F2) = 0 in the order of the closed form, F scaled to F[8] = 1   [host + device]
 //   fm_error                 max of the two squared point-to-epipolar-line distances, as a float              [host + device]
 //   fm_update_iterations     log(1 - confidence) / log(1 - (1 - eps)^7), capped                               [host only]
+//
+// DEFINED ARITHMETIC (round 5).  A hypothesis' inlier count decides which hypothesis wins, a correspondence whose error sits on the threshold moves a
+// count by one, and two hypotheses tie often enough that a long sequence meets such a case (tests/golden/ransac_ties.npz: frames 34 and 63 of two rendered
+// sequences).  So the matrices are computed by ONE sequence of IEEE operations wherever this header is compiled: no FMA contraction (the pragma below; hipcc
+// contracts by default, g++ -ffp-contract=off does not), and no libm call whose last bit differs between glibc and the device library -- the closed
+// form's acos / cos are replaced by a bisection on the trisection polynomial (4 c^3 - 3 c = cos theta, c = cos(theta / 3) in [1/2, 1]) and the angle-sum
+// identities, pow(x, 1/3) by a fixed number of Newton steps; +, -, *, /, sqrt are correctly rounded on both sides.  The device form, the sequential host
+// form and the oracle's `defined` entry point (oracle/oracle_ransac.cpp, restated there) are bit-identical; the oracle's independent entry point (Jacobi
+// null space, libm closed form) and tests/np_ransac.py (LAPACK) stay the checks of the ALGORITHM, at a tolerance.
 #pragma once
 #include <float.h>
 #include <math.h>
@@ -19,7 +28,22 @@
 
 #include "pv_math.h" // PV_HD
 
+#if defined(__clang__)
+#pragma clang fp contract(off) // (file scope: holds for everything below in the translation unit; klt.hip's own float kernels say the same per function)
+#endif
+
 namespace pvfm {
+
+// x^(1/3), x > 0: Newton on y^3 = x from a power of two within a factor of two of the root, a fixed number of steps (each: y <- (2 y + x / y^2) / 3)
+PV_HD double fm_cbrt(double x) {
+    if (!(x > 0)) return 0.0;
+    int e;
+    (void)frexp(x, &e); // x = m 2^e, m in [1/2, 1): exact
+    const int k = e >= 0 ? e / 3 : -((-e + 2) / 3);
+    double y = ldexp(1.0, k);
+    for (int it = 0; it < 12; ++it) y = (2.0 * y + x / (y * y)) * (1.0 / 3.0);
+    return y;
+}
 
 PV_HD double fm_det3(const double *m) {
     return m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
@@ -27,7 +51,7 @@ PV_HD double fm_det3(const double *m) {
 
 // real roots of c[0] x^3 + c[1] x^2 + c[2] x + c[3] = 0 in the order of the closed form (three cosines, or the single real root)
 PV_HD int fm_solve_cubic(const double c[4], double x[3]) {
-    const double a0 = c[0], pi = 3.14159265358979323846;
+    const double a0 = c[0];
     if (a0 == 0) {
         if (c[1] == 0) {
             if (c[2] == 0) return 0;
@@ -46,17 +70,26 @@ PV_HD int fm_solve_cubic(const double c[4], double x[3]) {
     const double Q = (a1 * a1 - 3 * a2) * (1. / 9), R = (2 * a1 * a1 * a1 - 9 * a1 * a2 + 27 * a3) * (1. / 54), Qc = Q * Q * Q;
     double d = Qc - R * R;
     if (d > 0) {
-        const double theta = acos(R / sqrt(Qc)), t0 = -2 * sqrt(Q), t1 = theta * (1. / 3), t2 = a1 * (1. / 3);
-        x[0] = t0 * cos(t1) - t2, x[1] = t0 * cos(t1 + (2. * pi / 3)) - t2, x[2] = t0 * cos(t1 + (4. * pi / 3)) - t2;
+        // three real roots t0 cos(theta / 3 + 2 pi k / 3) - t2, cos theta = R / sqrt(Q^3), in the order k = 0, 1, 2 of the closed form.
+        // c = cos(theta / 3) is the root of 4 c^3 - 3 c = cos theta in [1/2, 1] (theta in [0, pi]); the polynomial is increasing there: 64 bisection steps.
+        const double r = R / sqrt(Qc), t0 = -2 * sqrt(Q), t2 = a1 * (1. / 3);
+        double lo = 0.5, hi = 1.0;
+        for (int it = 0; it < 64; ++it) {
+            const double mid = 0.5 * (lo + hi);
+            if ((4.0 * mid * mid - 3.0) * mid < r) lo = mid;
+            else hi = mid;
+        }
+        const double c3 = 0.5 * (lo + hi), s3 = sqrt((1.0 - c3) * (1.0 + c3)), h3 = 0.86602540378443864676; // sin(theta / 3) >= 0; sqrt(3) / 2
+        x[0] = t0 * c3 - t2, x[1] = t0 * (-0.5 * c3 - s3 * h3) - t2, x[2] = t0 * (-0.5 * c3 + s3 * h3) - t2;
         return 3;
     }
     if (d == 0) {
-        if (R >= 0) x[0] = -2 * pow(R, 1. / 3) - a1 / 3, x[1] = pow(R, 1. / 3) - a1 / 3;
-        else x[0] = 2 * pow(-R, 1. / 3) - a1 / 3, x[1] = -pow(-R, 1. / 3) - a1 / 3;
+        if (R >= 0) x[0] = -2 * fm_cbrt(R) - a1 / 3, x[1] = fm_cbrt(R) - a1 / 3;
+        else x[0] = 2 * fm_cbrt(-R) - a1 / 3, x[1] = -fm_cbrt(-R) - a1 / 3;
         return 2;
     }
     d = sqrt(-d);
-    double e = pow(d + fabs(R), 1. / 3);
+    double e = fm_cbrt(d + fabs(R));
     if (R > 0) e = -e;
     x[0] = (e + Q / e) - a1 * (1. / 3);
     return 1;

@@ -197,7 +197,7 @@ SEQ_STATE = 1.0e-6       # north_star's bar on every window state, while the two
 SEQ_POSE_AFTER_FLIP = 5.0e-2  # [m] reported poses once the reference's own best-plane coin flip has made the two runs different experiments
 
 
-def compare_seq(log_ref, log_dropin, fx, kp_px=2.0e-3, allow_divergence=False):
+def compare_seq(log_ref, log_dropin, fx, kp_px=2.0e-3, allow_divergence=False, pose_after_flip=SEQ_POSE_AFTER_FLIP):
     """The reference's own pvio::PVIO over a sequence, twice (oracle/ref/seq_capi.cpp): with the reference's BundleAdjustor / visual_inertial_pnp
     (libpvio_ref.so) and with the product's linked in their place (libpvio_dropin*.so).  Records 1 / 8 / 9 after EVERY camera frame, compared strictly:
       integers   frame ids, track id + length of every keypoint, window frame ids / keyframe / fix flags, TF_VALID / TF_PLANE of every window track,
@@ -227,7 +227,7 @@ def compare_seq(log_ref, log_dropin, fx, kp_px=2.0e-3, allow_divergence=False):
             dpose = float(np.abs(Da[-8:] - Db[-8:]).max())
             if flipped:
                 info["max_pose_after_flip"] = max(info["max_pose_after_flip"], dpose)
-                assert dpose <= SEQ_POSE_AFTER_FLIP, "frame %d: reported pose differs by %.3g after the coin flip" % (int(Ia[0]), dpose)
+                assert dpose <= pose_after_flip, "frame %d: reported pose differs by %.3g after the coin flip" % (int(Ia[0]), dpose)
         if flipped:
             continue
         same = tag == tagb and Ia.shape == Ib.shape and bool((Ia == Ib).all())

@@ -47,7 +47,7 @@ int oracle_pyramid_sizes(int, int, int *, int *);
 void oracle_klt_track(int, const int *, const int *, const uint8_t *const *, const int16_t *const *, const uint8_t *const *, int, const float *, float *, uint8_t *);
 void oracle_harris_response(const uint8_t *, int, int, float *);
 int oracle_good_features(const float *, int, int, int, double, double, float *, float *);
-int32_t oracle_find_fundamental_ransac(int32_t, const float *, const float *, double, double, int32_t, uint8_t *, double *);
+int32_t oracle_find_fundamental_ransac_defined(int32_t, const float *, const float *, double, double, int32_t, uint8_t *, double *);
 void oracle_poisson_insert(double, int, const double *, int, const double *, uint8_t *);
 void oracle_select_tracked(int, const double *, const uint64_t *, double, uint8_t *);
 void oracle_predict_keypoints(const double *, const double *, const double *, const double *, const double *, const double *, int, const double *, double *);
@@ -85,7 +85,7 @@ namespace pvio {
 int find_fundamental_ransac(int n, const float *p, const float *q, double threshold, double confidence, std::vector<uint8_t> &mask, double F_out[9], int max_iterations) {
     mask.assign((size_t)std::max(n, 0), 0);
     double F[9];
-    return oracle_find_fundamental_ransac(n, p, q, threshold, confidence, max_iterations, mask.data(), F_out ? F_out : F);
+    return oracle_find_fundamental_ransac_defined(n, p, q, threshold, confidence, max_iterations, mask.data(), F_out ? F_out : F);
 }
 
 void predict_keypoints(const Frame &curr, const Frame &next, std::vector<vector<2>> &next_pixels) {

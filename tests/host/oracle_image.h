@@ -20,7 +20,7 @@ int oracle_pyramid_sizes(int, int, int *, int *);
 void oracle_klt_track(int, const int *, const int *, const uint8_t *const *, const int16_t *const *, const uint8_t *const *, int, const float *, float *, uint8_t *);
 void oracle_harris_response(const uint8_t *, int, int, float *);
 int oracle_good_features(const float *, int, int, int, double, double, float *, float *);
-int32_t oracle_find_fundamental_ransac(int32_t, const float *, const float *, double, double, int32_t, uint8_t *, double *);
+int32_t oracle_find_fundamental_ransac_defined(int32_t, const float *, const float *, double, double, int32_t, uint8_t *, double *);
 void oracle_poisson_insert(double, int, const double *, int, const double *, uint8_t *);
 }
 
@@ -114,7 +114,7 @@ class OracleImage : public Image {
         if (l.size() >= 8) { // :113-129
             std::vector<uint8_t> mask(l.size(), 0);
             double F[9];
-            oracle_find_fundamental_ransac((int32_t)l.size(), pp.data(), qq.data(), 1.0, 0.99, 1000, mask.data(), F);
+            oracle_find_fundamental_ransac_defined((int32_t)l.size(), pp.data(), qq.data(), 1.0, 0.99, 1000, mask.data(), F);
             for (size_t i = 0; i < l.size(); ++i)
                 if (mask[i] == 0) status[l[i]] = 0;
         }

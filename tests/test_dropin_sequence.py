@@ -150,7 +150,7 @@ def test_reference_pvio_with_the_whole_product_gpu(tmp_path):
         json.dump(out, open(path, "w"), indent=1)
 
 
-def _long_sequence(tmp_path, scene, n_frames=360, window=8, gap=3):
+def _long_sequence(tmp_path, scene, n_frames=360, window=8, gap=3, pose_after_flip=chain_compare.SEQ_POSE_AFTER_FLIP):
     """reference's pvio::PVIO + reference back-end + oracle front end against the same pvio::PVIO with the WHOLE product below its seams, over a long sequence
     on the sweep trajectory; both trajectories against the ground truth (ATE)."""
     _libs()
@@ -163,7 +163,7 @@ def _long_sequence(tmp_path, scene, n_frames=360, window=8, gap=3):
         os.makedirs(keep, exist_ok=True)
         for f in (a + ".log", b + ".log", a + ".tum", b + ".tum", a + ".gt.npy"):
             shutil.copy(f, keep)
-    info = chain_compare.compare_seq(a + ".log", b + ".log", hh.K4[0], allow_divergence=True)
+    info = chain_compare.compare_seq(a + ".log", b + ".log", hh.K4[0], allow_divergence=True, pose_after_flip=pose_after_flip)
     gt = np.load(a + ".gt.npy")
     ate_ref, n_ref = chain_compare.ate_rmse(a + ".tum", gt)
     ate_prod, n_prod = chain_compare.ate_rmse(b + ".tum", gt)
@@ -177,27 +177,26 @@ def _long_sequence(tmp_path, scene, n_frames=360, window=8, gap=3):
 @pytest.mark.gpu
 def test_long_sequence_ate_reference_vs_whole_product_gpu(tmp_path):
     """VERDICT r4 item 8 ("final ATE equal" on more than a handful of keyframe solves): 360 frames at 512 x 384 (18 s, 31 keyframe solves with a marginalization
-    each, window of 8 like config/euroc.yaml:50), relief scene (no planes).  Measured (profiles/r5_seq_long.json): identical track ids, flags and keypoints
-    (0 px) and every window state within 1.3e-9 for the first 63 frames -- with the inputs AND outputs of all 62 LK calls bit-identical between the CPU
-    oracle's front end and the product's kernels (PVIO_KLT_DUMP).  Then the fundamental-matrix RANSAC meets a TIE: two hypotheses with 115 inliers each of
-    127 survivors, and the oracle (Jacobi null space) and the product (Householder null space) keep different ones -- a correspondence on the 1-pixel
-    threshold moved one hypothesis' count by one (tests/test_host_ransac.py::test_sequence_divergences_are_ransac_ties_between_equal_hypotheses replays it
-    from a fixture).  Two tracks survive in one run only, a corner is detected in one run only, and from there the runs are different experiments (nothing in
-    the reference says which tied hypothesis OpenCV would keep): reported poses within 1.9 cm of each other over the remaining 297 frames, ATE 3.85 cm
-    (reference back-end + oracle front end) against 3.98 cm (whole product).
+    each, window of 8 like config/euroc.yaml:50) on the sweep trajectory; the reference's pvio::PVIO with the reference's back-end and the CPU oracle's front
+    end against the same pvio::PVIO with the whole product below its seams.
+    Relief scene (no planes), measured (profiles/r5_seq_long.json): identical track ids, flags and keypoints (0 px) in ALL 360 frames, every window state within
+    1.3e-9, reported poses within 1.3e-9 m, ATE 3.978084347 cm against 3.978084319 cm.  (Before the seven-point step of the F-matrix RANSAC got a defined
+    arithmetic the same run stayed identical for 63 frames and ended at a tie between two hypotheses of equal inlier count:
+    tests/test_host_ransac.py::test_sequence_divergences_are_ransac_ties_between_equal_hypotheses.)
     PVIO_LONG_SEQUENCE_WALL=1 adds the wall scene (planes extracted, cast and constrained): strict until the reference's own best-plane coin flip
-    (chain_compare.compare_seq), reported poses within 5 cm after it, both ATEs reported."""
+    (chain_compare.compare_seq; frame 34 here), after which the two runs are different experiments of a pipeline whose own ATE on this scene is 13 cm:
+    reported poses up to 17.5 cm apart, ATE 13.1 cm (reference) against 12.6 cm (product)."""
     import json
     out = {}
     info = _long_sequence(tmp_path, "full_relief_sweep")
     print("long sequence, relief scene:", info)
-    assert info["frames"] == 360 and info["strict_frames"] >= 60 and info["max_state"] <= 1e-6 and info["max_kp_px"] <= 1e-3
-    assert info["ate_difference_m"] <= 5e-3 and info["ate_rmse_product_m"] < 0.08
+    assert info["frames"] == 360 and info["strict_frames"] == 360 and info["keyframes"] >= 30 and info["max_state"] <= 1e-6 and info["max_kp_px"] <= 1e-3
+    assert info["first_divergence"] is None and info["ate_difference_m"] <= 1e-6 and info["ate_rmse_product_m"] < 0.08
     out["relief"] = info
     if os.environ.get("PVIO_LONG_SEQUENCE_WALL"):
-        info = _long_sequence(tmp_path, "full_sweep")
+        info = _long_sequence(tmp_path, "full_sweep", pose_after_flip=0.25)
         print("long sequence, wall scene (planes on):", info)
-        assert info["frames"] == 360 and info["keyframes"] >= 1 and info["planes_seen"] >= 1
+        assert info["frames"] == 360 and info["strict_frames"] >= 30 and info["first_divergence"] is None
         # (the REFERENCE's own run of this scene has an ATE of 13 cm: its plane factors pull the window, see SURVEY App. D quirk 3; what is held is that the product's run
         # stays with the reference's, not that either is good)
         assert info["ate_difference_m"] < 0.03
