@@ -230,7 +230,7 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st, bool ma
     // them one after another): 48 rows = 12 161 against 14 112 iterations/s, k_linearize 18.4 -> 29.2 us for 0.4 us less in k_reduce.
     static const int lm_wgs_cap = std::getenv("PVIO_HIP_LM_WGS") ? std::atoi(std::getenv("PVIO_HIP_LM_WGS")) : 0;
     int lm_cus = std::max(1, cus - dm.G_plane - dm.G_pre - dm.G_prior);
-    if (lm_wgs_cap > 0) lm_cus = std::min(lm_cus, lm_wgs_cap);
+    if (lm_wgs_cap > 0) lm_cus = lm_wgs_cap; // (may exceed the free CUs: more than one workgroup per CU where registers and LDS allow)
     const int slots_lds = (int)std::max<size_t>(1, std::min<size_t>(lds_budget / 8 / (40 * N + 46), (size_t)kLinThreads));
     const int slots_spread = std::max(1, (M + lm_cus - 1) / lm_cus);
     dm.lm_slots = std::min(slots_lds, slots_spread);
