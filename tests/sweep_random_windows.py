@@ -24,8 +24,8 @@ bad = 0
 for seed in range(60):
     kw, pb = ba_compare.sweep_window(O, seed)  # (the bounded pytest of the same windows: tests/test_gpu_ba.py::test_gpu_window_sweep_within_oracle_spread)
     try:
-        r = ba_compare.check_against_oracle(ctx, O, pb)
-        print(seed, kw['n_frames'], kw['n_landmarks'], kw['use_inertial'], 'ok', '%.1e' % r['worst_state_diff'], r['iterations'], flush=True)
+        r = ba_compare.check_against_oracle_within_spread(ctx, O, pb)  # 1e-6, or 4 x the oracle's own spread between summation orders where that is larger
+        print(seed, kw['n_frames'], kw['n_landmarks'], kw['use_inertial'], 'ok', '%.1e' % r['worst_state_diff'], r['iterations'], 'tol %.1e' % r['tol'], flush=True)
     except AssertionError as e:
         bad += 1
         print(seed, kw, 'FAIL', str(e)[:300], flush=True)
