@@ -30,6 +30,9 @@
 
 #if defined(__clang__)
 #pragma clang fp contract(off) // (file scope: holds for everything below in the translation unit; klt.hip's own float kernels say the same per function)
+#elif defined(__GNUC__)
+#pragma GCC push_options
+#pragma GCC optimize("fp-contract=off") // g++ contracts by default (-ffp-contract=fast) unless the build says otherwise: the functions below must not
 #endif
 
 namespace pvfm {
@@ -232,3 +235,7 @@ inline int fm_update_iterations(double p, double ep, int model_points, int max_i
 }
 
 } // namespace pvfm
+
+#if !defined(__clang__) && defined(__GNUC__)
+#pragma GCC pop_options
+#endif
