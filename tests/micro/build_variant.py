@@ -71,7 +71,16 @@ RECIPES = {
     "rsqrt_newton": dict(subs=[("constexpr bool kRsqrtCubic = true;", "constexpr bool kRsqrtCubic = false;")]),
     "fail_per_pivot": dict(subs=[("constexpr bool kDenseFailAtEnd = !kDenseConservative;", "constexpr bool kDenseFailAtEnd = false;")]),
     "conservative": dict(defines=["PVIO_DENSE_CONSERVATIVE"]),  # what build() ships when hipcc is not csrc/KNOWN_GOOD_TOOLCHAIN
-    "loop_stamps": dict(defines=["PVIO_DENSE_LOOP_STAMPS"]),  # the per-panel stamp sites 8-17 (tests/prof_phases.py reads them)
+    "loop_stamps": dict(defines=["PVIO_DENSE_LOOP_STAMPS"]),
+    # round 5: the two LDS counters of the look-ahead form moved by RELAXED stores / adds behind a compiler barrier instead of release operations: the
+    # LDS executes one wave's instructions in order, so the counter still becomes visible after the data, and the producer does not wait for its writes
+    # to drain (s_waitcnt lgkmcnt(0)) before it moves the counter
+    "relaxed_signals": dict(subs=[("""    if ((threadIdx.x & 63) == 0) __hip_atomic_store(flag, val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);""",
+                                   """    asm volatile("" ::: "memory");
+    if ((threadIdx.x & 63) == 0) __hip_atomic_store(flag, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);"""),
+                                  ("""    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);""",
+                                   """    asm volatile("" ::: "memory");
+    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);""")]),  # the per-panel stamp sites 8-17 (tests/prof_phases.py reads them)
 }
 
 if __name__ == "__main__":
