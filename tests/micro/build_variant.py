@@ -72,6 +72,14 @@ RECIPES = {
     "fail_per_pivot": dict(subs=[("constexpr bool kDenseFailAtEnd = !kDenseConservative;", "constexpr bool kDenseFailAtEnd = false;")]),
     "conservative": dict(defines=["PVIO_DENSE_CONSERVATIVE"]),  # what build() ships when hipcc is not csrc/KNOWN_GOOD_TOOLCHAIN
     "loop_stamps": dict(defines=["PVIO_DENSE_LOOP_STAMPS"]),
+    # round 5, TIMING ABLATIONS of the look-ahead panel loop (results are WRONG by construction; only tests/prof_phases.py's `factorization done - first panel`
+    # of the first factoring launch is read off them: profiles/r5_ablation_panel_loop.txt).  No failure test, so that garbage pivots do not end the loop early.
+    "abl_norows": dict(subs=[('#pragma unroll\n                        for (int t = 0; t < kPass; ++t)\n#pragma unroll\n                            for (int c2 = cc + 1; c2 < kPanel; ++c2) x[t][c2] -= x[t][cc] * Ls[c2][cc];\n                    }\n                    // A pivot that is negative, zero, infinite or NaN', '                    }\n                    // A pivot that is negative, zero, infinite or NaN'), ('                    if (kDenseFailAtEnd) fail |= (inv[kPanel - 1] * 0.0 == 0.0) ? 0 : 1;', '                    /* ablation: no failure test */')]),
+    "abl_noblock": dict(subs=[('#pragma unroll\n                        for (int r = cc + 1; r < kPanel; ++r)\n#pragma unroll\n                            for (int c2 = cc + 1; c2 <= r; ++c2) Ld[r][c2] -= Ld[r][cc] * Ls[c2][cc];\n#pragma unroll\n                        for (int t = 0; t < kPass; ++t)', '#pragma unroll\n                        for (int t = 0; t < kPass; ++t)'), ('                    if (kDenseFailAtEnd) fail |= (inv[kPanel - 1] * 0.0 == 0.0) ? 0 : 1;', '                    /* ablation: no failure test */')]),
+    "abl_nomfma": dict(subs=[('        _Pragma("unroll") for (int q = 0; q < dt_col_slot<LA>((g) + 1) - dt_col_slot<LA>(g); ++q)                      \\\n            acc[dt_col_slot<LA>(g) + q] = __builtin_amdgcn_mfma_f64_16x16x4f64(opA[q][0], opB[g][0], acc[dt_col_slot<LA>(g) + q], 0, 0, 0); \\\n        _Pragma("unroll") for (int q = 0; q < dt_col_slot<LA>((g) + 1) - dt_col_slot<LA>(g); ++q)                      \\\n            acc[dt_col_slot<LA>(g) + q] = __builtin_amdgcn_mfma_f64_16x16x4f64(opA[q][1], opB[g][1], acc[dt_col_slot<LA>(g) + q], 0, 0, 0); \\', '        _Pragma("unroll") for (int q = 0; q < dt_col_slot<LA>((g) + 1) - dt_col_slot<LA>(g); ++q)                      \\\n            acc[dt_col_slot<LA>(g) + q][0] += opA[q][0] * opB[g][0] + opA[q][1] * opB[g][1]; /* ablation: one FMA pair instead of two MFMAs */ \\'), ('                    if (kDenseFailAtEnd) fail |= (inv[kPanel - 1] * 0.0 == 0.0) ? 0 : 1;', '                    /* ablation: no failure test */')]),
+    "abl_noarith": dict(subs=[('#pragma unroll\n                        for (int r = cc + 1; r < kPanel; ++r)\n#pragma unroll\n                            for (int c2 = cc + 1; c2 <= r; ++c2) Ld[r][c2] -= Ld[r][cc] * Ls[c2][cc];\n#pragma unroll\n                        for (int t = 0; t < kPass; ++t)', '#pragma unroll\n                        for (int t = 0; t < kPass; ++t)'), ('#pragma unroll\n                        for (int t = 0; t < kPass; ++t)\n#pragma unroll\n                            for (int c2 = cc + 1; c2 < kPanel; ++c2) x[t][c2] -= x[t][cc] * Ls[c2][cc];\n                    }\n                    // A pivot that is negative, zero, infinite or NaN', '                    }\n                    // A pivot that is negative, zero, infinite or NaN'), ('                    if (kDenseFailAtEnd) fail |= (inv[kPanel - 1] * 0.0 == 0.0) ? 0 : 1;', '                    /* ablation: no failure test */')]),
+    "abl_skeleton": dict(subs=[('#pragma unroll\n                        for (int r = cc + 1; r < kPanel; ++r)\n#pragma unroll\n                            for (int c2 = cc + 1; c2 <= r; ++c2) Ld[r][c2] -= Ld[r][cc] * Ls[c2][cc];\n#pragma unroll\n                        for (int t = 0; t < kPass; ++t)', '#pragma unroll\n                        for (int t = 0; t < kPass; ++t)'), ('#pragma unroll\n                        for (int t = 0; t < kPass; ++t)\n#pragma unroll\n                            for (int c2 = cc + 1; c2 < kPanel; ++c2) x[t][c2] -= x[t][cc] * Ls[c2][cc];\n                    }\n                    // A pivot that is negative, zero, infinite or NaN', '                    }\n                    // A pivot that is negative, zero, infinite or NaN'), ('        _Pragma("unroll") for (int q = 0; q < dt_col_slot<LA>((g) + 1) - dt_col_slot<LA>(g); ++q)                      \\\n            acc[dt_col_slot<LA>(g) + q] = __builtin_amdgcn_mfma_f64_16x16x4f64(opA[q][0], opB[g][0], acc[dt_col_slot<LA>(g) + q], 0, 0, 0); \\\n        _Pragma("unroll") for (int q = 0; q < dt_col_slot<LA>((g) + 1) - dt_col_slot<LA>(g); ++q)                      \\\n            acc[dt_col_slot<LA>(g) + q] = __builtin_amdgcn_mfma_f64_16x16x4f64(opA[q][1], opB[g][1], acc[dt_col_slot<LA>(g) + q], 0, 0, 0); \\', '        _Pragma("unroll") for (int q = 0; q < dt_col_slot<LA>((g) + 1) - dt_col_slot<LA>(g); ++q)                      \\\n            acc[dt_col_slot<LA>(g) + q][0] += opA[q][0] * opB[g][0] + opA[q][1] * opB[g][1]; /* ablation: one FMA pair instead of two MFMAs */ \\'), ('                    if (kDenseFailAtEnd) fail |= (inv[kPanel - 1] * 0.0 == 0.0) ? 0 : 1;', '                    /* ablation: no failure test */')]),
+    "abl_nofailtest": dict(subs=[('                    if (kDenseFailAtEnd) fail |= (inv[kPanel - 1] * 0.0 == 0.0) ? 0 : 1;', '                    /* ablation: no failure test */')]),
     # round 5: the two LDS counters of the look-ahead form moved by RELAXED stores / adds behind a compiler barrier instead of release operations: the
     # LDS executes one wave's instructions in order, so the counter still becomes visible after the data, and the producer does not wait for its writes
     # to drain (s_waitcnt lgkmcnt(0)) before it moves the counter
