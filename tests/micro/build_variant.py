@@ -79,6 +79,13 @@ RECIPES = {
     "abl_nomfma": dict(subs=[('        _Pragma("unroll") for (int q = 0; q < dt_col_slot<LA>((g) + 1) - dt_col_slot<LA>(g); ++q)                      \\\n            acc[dt_col_slot<LA>(g) + q] = __builtin_amdgcn_mfma_f64_16x16x4f64(opA[q][0], opB[g][0], acc[dt_col_slot<LA>(g) + q], 0, 0, 0); \\\n        _Pragma("unroll") for (int q = 0; q < dt_col_slot<LA>((g) + 1) - dt_col_slot<LA>(g); ++q)                      \\\n            acc[dt_col_slot<LA>(g) + q] = __builtin_amdgcn_mfma_f64_16x16x4f64(opA[q][1], opB[g][1], acc[dt_col_slot<LA>(g) + q], 0, 0, 0); \\', '        _Pragma("unroll") for (int q = 0; q < dt_col_slot<LA>((g) + 1) - dt_col_slot<LA>(g); ++q)                      \\\n            acc[dt_col_slot<LA>(g) + q][0] += opA[q][0] * opB[g][0] + opA[q][1] * opB[g][1]; /* ablation: one FMA pair instead of two MFMAs */ \\'), ('                    if (kDenseFailAtEnd) fail |= (inv[kPanel - 1] * 0.0 == 0.0) ? 0 : 1;', '                    /* ablation: no failure test */')]),
     "abl_noarith": dict(subs=[('#pragma unroll\n                        for (int r = cc + 1; r < kPanel; ++r)\n#pragma unroll\n                            for (int c2 = cc + 1; c2 <= r; ++c2) Ld[r][c2] -= Ld[r][cc] * Ls[c2][cc];\n#pragma unroll\n                        for (int t = 0; t < kPass; ++t)', '#pragma unroll\n                        for (int t = 0; t < kPass; ++t)'), ('#pragma unroll\n                        for (int t = 0; t < kPass; ++t)\n#pragma unroll\n                            for (int c2 = cc + 1; c2 < kPanel; ++c2) x[t][c2] -= x[t][cc] * Ls[c2][cc];\n                    }\n                    // A pivot that is negative, zero, infinite or NaN', '                    }\n                    // A pivot that is negative, zero, infinite or NaN'), ('                    if (kDenseFailAtEnd) fail |= (inv[kPanel - 1] * 0.0 == 0.0) ? 0 : 1;', '                    /* ablation: no failure test */')]),
     "abl_skeleton": dict(subs=[('#pragma unroll\n                        for (int r = cc + 1; r < kPanel; ++r)\n#pragma unroll\n                            for (int c2 = cc + 1; c2 <= r; ++c2) Ld[r][c2] -= Ld[r][cc] * Ls[c2][cc];\n#pragma unroll\n                        for (int t = 0; t < kPass; ++t)', '#pragma unroll\n                        for (int t = 0; t < kPass; ++t)'), ('#pragma unroll\n                        for (int t = 0; t < kPass; ++t)\n#pragma unroll\n                            for (int c2 = cc + 1; c2 < kPanel; ++c2) x[t][c2] -= x[t][cc] * Ls[c2][cc];\n                    }\n                    // A pivot that is negative, zero, infinite or NaN', '                    }\n                    // A pivot that is negative, zero, infinite or NaN'), ('        _Pragma("unroll") for (int q = 0; q < dt_col_slot<LA>((g) + 1) - dt_col_slot<LA>(g); ++q)                      \\\n            acc[dt_col_slot<LA>(g) + q] = __builtin_amdgcn_mfma_f64_16x16x4f64(opA[q][0], opB[g][0], acc[dt_col_slot<LA>(g) + q], 0, 0, 0); \\\n        _Pragma("unroll") for (int q = 0; q < dt_col_slot<LA>((g) + 1) - dt_col_slot<LA>(g); ++q)                      \\\n            acc[dt_col_slot<LA>(g) + q] = __builtin_amdgcn_mfma_f64_16x16x4f64(opA[q][1], opB[g][1], acc[dt_col_slot<LA>(g) + q], 0, 0, 0); \\', '        _Pragma("unroll") for (int q = 0; q < dt_col_slot<LA>((g) + 1) - dt_col_slot<LA>(g); ++q)                      \\\n            acc[dt_col_slot<LA>(g) + q][0] += opA[q][0] * opB[g][0] + opA[q][1] * opB[g][1]; /* ablation: one FMA pair instead of two MFMAs */ \\'), ('                    if (kDenseFailAtEnd) fail |= (inv[kPanel - 1] * 0.0 == 0.0) ? 0 : 1;', '                    /* ablation: no failure test */')]),
+    "relaxed_nosleep": dict(subs=[("""    if ((threadIdx.x & 63) == 0) __hip_atomic_store(flag, val, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);""",
+                                   """    asm volatile("" ::: "memory");
+    if ((threadIdx.x & 63) == 0) __hip_atomic_store(flag, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);"""),
+                                  ("""    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);""",
+                                   """    asm volatile("" ::: "memory");
+    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);"""),
+                                  ("val < target) __builtin_amdgcn_s_sleep(1);", "val < target) __builtin_amdgcn_s_sleep(0);")]),
     "abl_nofailtest": dict(subs=[('                    if (kDenseFailAtEnd) fail |= (inv[kPanel - 1] * 0.0 == 0.0) ? 0 : 1;', '                    /* ablation: no failure test */')]),
     # round 5: the two LDS counters of the look-ahead form moved by RELAXED stores / adds behind a compiler barrier instead of release operations: the
     # LDS executes one wave's instructions in order, so the counter still becomes visible after the data, and the producer does not wait for its writes
