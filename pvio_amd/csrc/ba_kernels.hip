@@ -179,6 +179,18 @@ constexpr int kDbgNegativePivot = 1000;
 constexpr bool kDenseFailAtEnd = !kDenseConservative; // look-ahead form: a bad pivot is detected once per panel (see the factor wave's loop)
 // update waves of the look-ahead form: operands of the tile columns requested in groups of four, dead groups skipped
 constexpr bool kDenseOperandGroups = !kDenseConservative;
+// Round 5: the two hand-overs of a panel of the look-ahead form -- "the panel's L rows are in LDS" (A) and "the next panel's columns are published" (B) --
+// through the HARDWARE barrier (two s_barrier per panel, executed by all four waves) instead of two LDS counters polled with s_sleep.  The roles and the
+// overlap are the same: the factor wave passes A(p), B(p) back to back and factors panel p + 1 while the update waves, between B(p) and A(p + 1), apply panel p
+// to the rest of the trailing matrix.  What goes is the poll: the timing ablations (profiles/r5_ablation_panel_loop.txt) put 1.8 k of a panel's 4.0 k cycles
+// into the bare hand-shake, and a wave that sleeps in a poll sees a counter move ~190 cycles after it did (tools/ubench/wave_costs.hip); a barrier
+// releases within tens.  14 127 -> 14 449 iterations/s on one box (profiles/r5_ab_la_barrier.txt).  A failed pivot no longer ends the loop early (every
+// wave has to meet every barrier): the factorization finishes on NaNs and is discarded behind the loop as before.  -DPVIO_DENSE_LA_COUNTERS: the counter form.
+#ifdef PVIO_DENSE_LA_COUNTERS
+constexpr bool kDenseLaBarrier = false;
+#else
+constexpr bool kDenseLaBarrier = true;
+#endif
 // the per-panel profiling stamps of the look-ahead loop (sites 8-17) cost ~45 scalar instructions and ten branches per panel even when profiling is
 // off: compiled in only with -DPVIO_DENSE_LOOP_STAMPS (tests/micro/build_variant.py loop_stamps)
 #ifdef PVIO_DENSE_LOOP_STAMPS
@@ -2332,7 +2344,10 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
         __syncthreads(); // every wave holds its tiles: the tile image may be overwritten from here on
         int lfo = 0;     // offset of the current panel in Lf (panel p keeps rows j0 .. LDV - 1, 8 doubles each)
         if constexpr (LA) {
-            // ---------------- look-ahead form: no workgroup barrier inside the loop ----------------
+            // ---------------- look-ahead form ----------------
+            // Hand-overs: kDenseLaBarrier (round 5, default) -- two s_barrier per panel, A(p) "L rows of panel p stored" and B(p) "columns of panel p + 1
+            // published"; wave 0 executes [B(p - 1)] work A(p), waves 1..3 execute A(p) next-column-update publish B(p) rest-of-the-update: the same order of
+            // events as with the counters below, which remain as the other form:
             // flag_pub counts the 8-column blocks published into Xs, one count per update wave and block (3 per panel);
             // flag_L counts the panels whose L rows are complete in Lf (negative: a non-positive pivot, everybody leaves).
             //   wave 0, panel p:   wait flag_pub >= 3 (p + 1) -> diagonal block + all rows of the panel from Xs -> L rows to Lf(p)
@@ -2364,7 +2379,11 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
                         for (int h = 0; h < 4; ++h) dg2[h] = *reinterpret_cast<const lds_d2 *>(yv + j0 + 2 * h), rh2[h] = *reinterpret_cast<const lds_d2 *>(diagH + j0 + 2 * h);
                         PV_ORDER(); // (the requests stay in front of the wait)
                     }
-                    dense_wait(flag_pub, 3 * (pidx + 1));
+                    if (kDenseLaBarrier) {
+                        if (pidx > 0) __syncthreads(); // barrier B(p - 1): the update waves have published this panel's columns
+                    } else {
+                        dense_wait(flag_pub, 3 * (pidx + 1));
+                    }
                     double Ld[kPanel][kPanel], inv[kPanel];
 #pragma unroll
                     for (int r = 0; r < kPanel; ++r)
@@ -2426,8 +2445,11 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
                     if (j0 == 80) PV_LOOP_STAMP2(14);
                     if (fail) { // uniform
                         if (lane == 0) sh_fail = 1;
-                        dense_signal_set(flag_L, -1);
-                        break;
+                        if (!kDenseLaBarrier) {
+                            dense_signal_set(flag_L, -1);
+                            break;
+                        }
+                        // (barrier form: every wave meets every barrier, so the loop is walked to its end on NaNs; the result is discarded behind it)
                     }
                     if (lane == 0) { // 1 / L_jj for the back substitution: every lane holds all eight, one writes them (four 16-byte writes instead of a select chain)
 #pragma unroll
@@ -2454,16 +2476,19 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
                     }
                     if (j0 == 0) PV_LOOP_STAMP2(10);
                     if (j0 == 80) PV_LOOP_STAMP2(15);
-                    dense_signal_set(flag_L, pidx + 1); // (release: the rows above are in LDS before the counter moves)
+                    if (kDenseLaBarrier) __syncthreads(); // barrier A(p): the panel's L rows are in LDS
+                    else dense_signal_set(flag_L, pidx + 1); // (release: the rows above are in LDS before the counter moves)
                     if (j0 == 0) { PV_LOOP_STAMP2(11); PV_LOOP_STAMP2(12); }
                     if (j0 == 80) { PV_LOOP_STAMP2(16); PV_LOOP_STAMP2(17); }
                     lfo += LS * (LDV - j0);
                 }
+                if (kDenseLaBarrier) __syncthreads(); // barrier B(last panel): the update waves' last one has a partner
             } else {
                 int pidx = 0;
                 for (int j0 = 0; j0 < Pp; j0 += kPanel, ++pidx) {
                     const int k0 = j0 + kPanel, b0 = k0 >> 4, o2 = k0 & 15;
-                    if (dense_wait(flag_L, pidx + 1) < 0) break;
+                    if (kDenseLaBarrier) __syncthreads(); // barrier A(p)
+                    else if (dense_wait(flag_L, pidx + 1) < 0) break;
                     const int R = nbk - b0; // live tile columns g = 0 .. R - 1 (from the end); the one that is factored next is g = R - 1
                     const double *Lpan = Lf + lfo - LS * j0 + 2 * lk + LS * lr; // + 16 LS * tile row -> this lane's operand pair
                     lds_d2 opA[kNQ], opB[kDenseCols];
@@ -2503,7 +2528,8 @@ __global__ void __launch_bounds__(LDSMAT ? kDenseThreads : 2 * kDenseThreads) k_
                                         asm volatile("" ::: "memory"); // keep this a real (uniform) branch: nothing of the publish is hoisted
                                         PV_PUBLISH_ROW(dt_col_slot<LA>(g) + q, nbk - 1 - hq[q], o2);
                                     }
-                                dense_signal_add(flag_pub); // (release; one count per wave and panel, whether it owns a row here or not)
+                                if (kDenseLaBarrier) __syncthreads(); // barrier B(p): this panel's next columns are published (R >= 1 in every panel: the rhs row's tile column)
+                                else dense_signal_add(flag_pub); // (release; one count per wave and panel, whether it owns a row here or not)
                             }
                         }
 #undef PV_LA_COLUMN

@@ -86,6 +86,12 @@ RECIPES = {
                                    """    asm volatile("" ::: "memory");
     if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);"""),
                                   ("val < target) __builtin_amdgcn_s_sleep(1);", "val < target) __builtin_amdgcn_s_sleep(0);")]),
+    "abl_skel_norsq": dict(subs=[('#pragma unroll\n                        for (int r = cc + 1; r < kPanel; ++r)\n#pragma unroll\n                            for (int c2 = cc + 1; c2 <= r; ++c2) Ld[r][c2] -= Ld[r][cc] * Ls[c2][cc];\n#pragma unroll\n                        for (int t = 0; t < kPass; ++t)', '#pragma unroll\n                        for (int t = 0; t < kPass; ++t)'), ('#pragma unroll\n                        for (int t = 0; t < kPass; ++t)\n#pragma unroll\n                            for (int c2 = cc + 1; c2 < kPanel; ++c2) x[t][c2] -= x[t][cc] * Ls[c2][cc];\n                    }\n                    // A pivot that is negative, zero, infinite or NaN', '                    }\n                    // A pivot that is negative, zero, infinite or NaN'), ('        _Pragma("unroll") for (int q = 0; q < dt_col_slot<LA>((g) + 1) - dt_col_slot<LA>(g); ++q)                      \\\n            acc[dt_col_slot<LA>(g) + q] = __builtin_amdgcn_mfma_f64_16x16x4f64(opA[q][0], opB[g][0], acc[dt_col_slot<LA>(g) + q], 0, 0, 0); \\\n        _Pragma("unroll") for (int q = 0; q < dt_col_slot<LA>((g) + 1) - dt_col_slot<LA>(g); ++q)                      \\\n            acc[dt_col_slot<LA>(g) + q] = __builtin_amdgcn_mfma_f64_16x16x4f64(opA[q][1], opB[g][1], acc[dt_col_slot<LA>(g) + q], 0, 0, 0); \\', '        _Pragma("unroll") for (int q = 0; q < dt_col_slot<LA>((g) + 1) - dt_col_slot<LA>(g); ++q)                      \\\n            acc[dt_col_slot<LA>(g) + q][0] += opA[q][0] * opB[g][0] + opA[q][1] * opB[g][1]; /* ablation: one FMA pair instead of two MFMAs */ \\'), ('                    if (kDenseFailAtEnd) fail |= (inv[kPanel - 1] * 0.0 == 0.0) ? 0 : 1;', '                    /* ablation: no failure test */'), ('                        inv[cc] = fast_rsqrt(dd);\n                        const double inv2 = inv[cc] * inv[cc];', '                        inv[cc] = 1.0;\n                        const double inv2 = dd;')]),
+    "abl_skel_norowio": dict(subs=[('#pragma unroll\n                        for (int r = cc + 1; r < kPanel; ++r)\n#pragma unroll\n                            for (int c2 = cc + 1; c2 <= r; ++c2) Ld[r][c2] -= Ld[r][cc] * Ls[c2][cc];\n#pragma unroll\n                        for (int t = 0; t < kPass; ++t)', '#pragma unroll\n                        for (int t = 0; t < kPass; ++t)'), ('#pragma unroll\n                        for (int t = 0; t < kPass; ++t)\n#pragma unroll\n                            for (int c2 = cc + 1; c2 < kPanel; ++c2) x[t][c2] -= x[t][cc] * Ls[c2][cc];\n                    }\n                    // A pivot that is negative, zero, infinite or NaN', '                    }\n                    // A pivot that is negative, zero, infinite or NaN'), ('        _Pragma("unroll") for (int q = 0; q < dt_col_slot<LA>((g) + 1) - dt_col_slot<LA>(g); ++q)                      \\\n            acc[dt_col_slot<LA>(g) + q] = __builtin_amdgcn_mfma_f64_16x16x4f64(opA[q][0], opB[g][0], acc[dt_col_slot<LA>(g) + q], 0, 0, 0); \\\n        _Pragma("unroll") for (int q = 0; q < dt_col_slot<LA>((g) + 1) - dt_col_slot<LA>(g); ++q)                      \\\n            acc[dt_col_slot<LA>(g) + q] = __builtin_amdgcn_mfma_f64_16x16x4f64(opA[q][1], opB[g][1], acc[dt_col_slot<LA>(g) + q], 0, 0, 0); \\', '        _Pragma("unroll") for (int q = 0; q < dt_col_slot<LA>((g) + 1) - dt_col_slot<LA>(g); ++q)                      \\\n            acc[dt_col_slot<LA>(g) + q][0] += opA[q][0] * opB[g][0] + opA[q][1] * opB[g][1]; /* ablation: one FMA pair instead of two MFMAs */ \\'), ('                    if (kDenseFailAtEnd) fail |= (inv[kPanel - 1] * 0.0 == 0.0) ? 0 : 1;', '                    /* ablation: no failure test */'), ('                            const lds_d2 g2 = *reinterpret_cast<const lds_d2 *>(xrow[t] + 2 * h);', '                            const lds_d2 g2 = {dg2[h][0], dg2[h][1]}; /* ablation: no row reads */'), ('                                Lrow[h] = pr;', '                                if (h == 7) Lrow[h] = pr; /* ablation: no row stores */')]),
+    "abl_skel_bare": dict(subs=[('#pragma unroll\n                        for (int r = cc + 1; r < kPanel; ++r)\n#pragma unroll\n                            for (int c2 = cc + 1; c2 <= r; ++c2) Ld[r][c2] -= Ld[r][cc] * Ls[c2][cc];\n#pragma unroll\n                        for (int t = 0; t < kPass; ++t)', '#pragma unroll\n                        for (int t = 0; t < kPass; ++t)'), ('#pragma unroll\n                        for (int t = 0; t < kPass; ++t)\n#pragma unroll\n                            for (int c2 = cc + 1; c2 < kPanel; ++c2) x[t][c2] -= x[t][cc] * Ls[c2][cc];\n                    }\n                    // A pivot that is negative, zero, infinite or NaN', '                    }\n                    // A pivot that is negative, zero, infinite or NaN'), ('        _Pragma("unroll") for (int q = 0; q < dt_col_slot<LA>((g) + 1) - dt_col_slot<LA>(g); ++q)                      \\\n            acc[dt_col_slot<LA>(g) + q] = __builtin_amdgcn_mfma_f64_16x16x4f64(opA[q][0], opB[g][0], acc[dt_col_slot<LA>(g) + q], 0, 0, 0); \\\n        _Pragma("unroll") for (int q = 0; q < dt_col_slot<LA>((g) + 1) - dt_col_slot<LA>(g); ++q)                      \\\n            acc[dt_col_slot<LA>(g) + q] = __builtin_amdgcn_mfma_f64_16x16x4f64(opA[q][1], opB[g][1], acc[dt_col_slot<LA>(g) + q], 0, 0, 0); \\', '        _Pragma("unroll") for (int q = 0; q < dt_col_slot<LA>((g) + 1) - dt_col_slot<LA>(g); ++q)                      \\\n            acc[dt_col_slot<LA>(g) + q][0] += opA[q][0] * opB[g][0] + opA[q][1] * opB[g][1]; /* ablation: one FMA pair instead of two MFMAs */ \\'), ('                    if (kDenseFailAtEnd) fail |= (inv[kPanel - 1] * 0.0 == 0.0) ? 0 : 1;', '                    /* ablation: no failure test */'), ('                        inv[cc] = fast_rsqrt(dd);\n                        const double inv2 = inv[cc] * inv[cc];', '                        inv[cc] = 1.0;\n                        const double inv2 = dd;'), ('                            const lds_d2 g2 = *reinterpret_cast<const lds_d2 *>(xrow[t] + 2 * h);', '                            const lds_d2 g2 = {dg2[h][0], dg2[h][1]}; /* ablation: no row reads */'), ('                                Lrow[h] = pr;', '                                if (h == 7) Lrow[h] = pr; /* ablation: no row stores */')]),
+    # round 5: the look-ahead form with the hardware barrier in place of the two LDS counters: two s_barrier per panel executed by all four waves (A: the
+    # L rows are stored; B: the next columns are published); the factor wave still runs one panel ahead of the update waves' trailing work
+    "la_barrier": dict(subs=[('                    dense_wait(flag_pub, 3 * (pidx + 1));', "                    if (pidx > 0) __syncthreads(); /* barrier B(p - 1): the update waves have published this panel's columns */"), ('                    if (fail) { // uniform\n                        if (lane == 0) sh_fail = 1;\n                        dense_signal_set(flag_L, -1);\n                        break;\n                    }', '                    if (fail && lane == 0) sh_fail = 1; /* barrier form: every wave walks all panels (a failed factorization finishes on NaNs), no early exit */'), ('                    dense_signal_set(flag_L, pidx + 1); // (release: the rows above are in LDS before the counter moves)', "                    __syncthreads(); /* barrier A(p): the panel's L rows are in LDS */"), ('                    lfo += LS * (LDV - j0);\n                }\n            } else {\n                int pidx = 0;', '                    lfo += LS * (LDV - j0);\n                }\n                __syncthreads(); /* barrier B(last) */\n            } else {\n                int pidx = 0;'), ('                    if (dense_wait(flag_L, pidx + 1) < 0) break;', '                    __syncthreads(); /* barrier A(p) */'), ('                                dense_signal_add(flag_pub); // (release; one count per wave and panel, whether it owns a row here or not)', "                                __syncthreads(); /* barrier B(p): this panel's next columns are published */")]),
     "abl_nofailtest": dict(subs=[('                    if (kDenseFailAtEnd) fail |= (inv[kPanel - 1] * 0.0 == 0.0) ? 0 : 1;', '                    /* ablation: no failure test */')]),
     # round 5: the two LDS counters of the look-ahead form moved by RELAXED stores / adds behind a compiler barrier instead of release operations: the
     # LDS executes one wave's instructions in order, so the counter still becomes visible after the data, and the producer does not wait for its writes
