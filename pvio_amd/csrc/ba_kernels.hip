@@ -1203,22 +1203,43 @@ __global__ void __launch_bounds__(kLinThreads) k_linearize(View v) {
 constexpr int kRedElems = 16, kRedGroups = 64; // one block = 16 output elements (one 128-byte line per partial row) x 64 partial groups:
                                                 // the partials are pulled by ~8x more CUs than there are kilobytes per element
 // IMU factor blocks (odd factor first) and marginalization prior added to entry ((fa, ka), (fb, kb)), fb <= fa, of the
-// unscaled reduced system whose landmark / plane part is `val`
-__device__ __forceinline__ double reduced_entry_terms(const View &v, double val, int fa, int ka, int fb, int kb) {
-    if (v.dm.n_rot > 0 && fa == fb && ka < 3 && kb < 3) val += v.rot_H[9 * fa + 3 * ka + kb]; // rotation prior of the frame
-    if (v.dm.d != 15) return val;
+// unscaled reduced system whose landmark / plane part is `val`.  In two steps since round 5 -- FETCH the terms (every load's address depends on the entry
+// alone, so all of them can be in flight while the partial rows are summed), APPLY them to the sum in the order the one-step form used:
+// k_reduce's 6 us were a chain of dependent trips (partials -> task -> factor flags -> factor blocks written by k_linearize on other XCDs).
+struct EntryTerms {
+    double rot, hA, hB, pri;
+    int use; // 1: rotation prior, 2: IMU factor blocks, 4: odd frame (order of the two IMU terms), 8: marginalization prior
+};
+__device__ __forceinline__ EntryTerms fetch_entry_terms(const View &v, int fa, int ka, int fb, int kb) {
+    EntryTerms t;
+    t.rot = 0.0, t.hA = 0.0, t.hB = 0.0, t.pri = 0.0, t.use = 0;
+    if (v.dm.n_rot > 0 && fa == fb && ka < 3 && kb < 3) t.rot = v.rot_H[9 * fa + 3 * ka + kb], t.use |= 1; // rotation prior of the frame
+    if (v.dm.d != 15) return t;
     const int N = v.dm.N;
     if (v.dm.G_pre) {
-        // factor j couples frames j - 1 (local 0..14) and j (local 15..29)
+        // factor j couples frames j - 1 (local 0..14) and j (local 15..29).  The blocks are requested whether or not the factor exists (an absent factor's
+        // block was never written: select, below, not multiply): their addresses do not wait for the flags
         const bool same = fa == fb, adj = fa == fb + 1;
-        const double hA = (fa >= 1 && (same || adj) && v.pre_valid[fa]) ? v.pre_H[(size_t)fa * 900 + (15 + ka) * 30 + (same ? 15 : 0) + kb] : 0.0;
-        const double hB = (same && fa + 1 < N && v.pre_valid[fa + 1]) ? v.pre_H[(size_t)(fa + 1) * 900 + ka * 30 + kb] : 0.0;
-        val = (fa & 1) ? (val + hA) + hB : (val + hB) + hA;
+        const bool candA = fa >= 1 && (same || adj), candB = same && fa + 1 < N;
+        const unsigned pvA = candA ? v.pre_valid[fa] : 0u, pvB = candB ? v.pre_valid[fa + 1] : 0u;
+        const double xA = candA ? v.pre_H[(size_t)fa * 900 + (15 + ka) * 30 + (same ? 15 : 0) + kb] : 0.0;
+        const double xB = candB ? v.pre_H[(size_t)(fa + 1) * 900 + ka * 30 + kb] : 0.0;
+        t.hA = pvA ? xA : 0.0, t.hB = pvB ? xB : 0.0;
+        t.use |= 2 | ((fa & 1) ? 4 : 0);
     }
-    if (v.dm.prior_n <= 0) return val;
+    if (v.dm.prior_n <= 0) return t;
     const int pa = v.prior_slot[fa], pb = v.prior_slot[fb];
-    if (pa >= 0 && pb >= 0) val += v.prior_H[(size_t)(15 * pa + ka) * (15 * v.dm.prior_n) + 15 * pb + kb];
+    if (pa >= 0 && pb >= 0) t.pri = v.prior_H[(size_t)(15 * pa + ka) * (15 * v.dm.prior_n) + 15 * pb + kb], t.use |= 8;
+    return t;
+}
+__device__ __forceinline__ double apply_entry_terms(const EntryTerms &t, double val) {
+    if (t.use & 1) val += t.rot;
+    if (t.use & 2) val = (t.use & 4) ? (val + t.hA) + t.hB : (val + t.hB) + t.hA;
+    if (t.use & 8) val += t.pri;
     return val;
+}
+__device__ __forceinline__ double reduced_entry_terms(const View &v, double val, int fa, int ka, int fb, int kb) {
+    return apply_entry_terms(fetch_entry_terms(v, fa, ka, fb, kb), val);
 }
 
 // Blocks [0, nb_red) produce `red` (tiles element-major, pose vectors, scalars).  With the tile image on (single GPU,
@@ -1263,6 +1284,24 @@ __global__ void __launch_bounds__(kRedElems *kRedGroups) k_reduce(View v, int nb
     const int G = v.dm.G_lm + v.dm.G_plane;
     const int el = threadIdx.x & (kRedElems - 1), gg = threadIdx.x / kRedElems;
     const size_t e = (size_t)blockIdx.x * kRedElems + el;
+    // the image entry this thread will finish (gg == 0): its position and every other term of it are requested up front, next to the partial rows
+    bool img_here = false;
+    int img_row = 0, img_col = 0;
+    EntryTerms img_terms;
+    img_terms.rot = img_terms.hA = img_terms.hB = img_terms.pri = 0.0, img_terms.use = 0;
+    double img_cr = 1.0, img_cc = 1.0;
+    if (gg == 0 && v.dm.use_img && phase != 1 && e < nS) {
+        const int n_tasks = v.dm.n_tasks, ee = (int)e, q = ee / n_tasks, t = ee - q * n_tasks, d = v.dm.d;
+        int fi, fj, si, sj;
+        unpack_task(v.task_desc[t], fi, fj, si, sj);
+        const int ra = 3 * si + q / 3, ca = 3 * sj + q % 3; // coordinates inside frames fi (row of the task) and fj, fi <= fj
+        if (fi != fj || ra >= ca) { // (diagonal blocks come in full: their upper half is not stored)
+            img_here = true;
+            img_row = fi != fj ? d * fj + ca : d * fi + ra, img_col = fi != fj ? d * fi + ra : d * fi + ca;
+            img_terms = fi != fj ? fetch_entry_terms(v, fj, ca, fi, ra) : fetch_entry_terms(v, fi, ra, fi, ca);
+            if (v.dm.img_scaled) img_cr = v.cpl[img_row], img_cc = v.cpl[img_col]; // (only used once the scaling exists)
+        }
+    }
     // stage 1: group gg sums partials g = gg, gg + 16, ... (coalesced across el), four independent accumulators
     double s = 0;
     if (phase == 2) {
@@ -1305,17 +1344,10 @@ __global__ void __launch_bounds__(kRedElems *kRedGroups) k_reduce(View v, int nb
             // scalars (zero in the others' slots); after the sum the slots hold every rank's maximum (k_dense takes the max)
             for (int w = 0; w < v.dm.world; ++w) v.red[total + w] = (w == v.dm.rank) ? r : 0.0;
         }
-        if (v.dm.use_img && phase != 1 && e < nS) {
-            const int n_tasks = v.dm.n_tasks, ee = (int)e, q = ee / n_tasks, t = ee - q * n_tasks, d = v.dm.d;
-            int fi, fj, si, sj;
-            unpack_task(v.task_desc[t], fi, fj, si, sj);
-            const int ra = 3 * si + q / 3, ca = 3 * sj + q % 3; // coordinates inside frames fi (row of the task) and fj, fi <= fj
-            if (fi != fj || ra >= ca) { // (diagonal blocks come in full: their upper half is not stored)
-                const int row = fi != fj ? d * fj + ca : d * fi + ra, col = fi != fj ? d * fi + ra : d * fi + ca;
-                double val = fi != fj ? reduced_entry_terms(v, r, fj, ca, fi, ra) : reduced_entry_terms(v, r, fi, ra, fi, ca);
-                if (scale_img) val = -(val * (v.cpl[row] * v.cpl[col]));
-                v.img[mat_at(row, col)] = val;
-            }
+        if (img_here) {
+            double val = apply_entry_terms(img_terms, r);
+            if (scale_img) val = -(val * (img_cr * img_cc));
+            v.img[mat_at(img_row, img_col)] = val;
         }
     }
 }
