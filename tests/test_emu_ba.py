@@ -281,3 +281,20 @@ def test_emulated_identical_candidates_metric_window(emu_ctx_reuse, oracle):
         sm = BASummary(pb, trace=False)
         emu_ctx_reuse.solve_resident(sm)
         assert sm.num_iterations == 10 and emu_ctx_reuse.last_candidate_repeats() == 3
+
+
+def test_emulated_counter_form_of_the_lookahead_loop(oracle):
+    """k_dense's look-ahead loop has two forms of its hand-overs: two hardware barriers per panel (round 5, shipped) and two polled LDS counters
+    (-DPVIO_DENSE_LA_COUNTERS, rounds 3-4, kept for A/Bs: tests/micro/build_variant.py la_counters).  The counter form in its own emulated build (the two
+    builds define the same kernel symbols: one process each): the metric window and a small VIO window against the oracle, as for the shipped form."""
+    import sys
+    subprocess.check_call(["make", "-s", "-C", EMU_DIR, "libpvio_hipemu_counters.so"])
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import ba_compare\nfrom oracle import oracle_py as O\nfrom pvio_amd import capi\nfrom pvio_amd.solver import HipContext\nO.build()\n"
+            "ctx = HipContext(lib=capi.load(%r), use_graph=True)\n"
+            "for kw in (ba_compare.BIG_CASES['metric_10x1000_vio'], ba_compare.CASES['vio_small'], ba_compare.CASES['vio_11_frames_lds_limit']):\n"
+            "    print(ba_compare.check_against_oracle(ctx, O, ba_compare.make(O, **kw)))\n") % (
+        os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)), os.path.join(EMU_DIR, "libpvio_hipemu_counters.so"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    assert r.stdout.count("worst_state_diff") == 3
