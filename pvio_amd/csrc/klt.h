@@ -41,6 +41,9 @@ class Klt {
     void *d_pts_ = nullptr;
     size_t pts_cap_ = 0;
     void *h_pts_ = nullptr; // pinned mirror of d_pts_
+    int n_simds_ = 0;    // 4 x CUs
+    int lk_units_ = -1;  // PVIO_HIP_LK_UNITS: 1 always / 0 never the unit queue (experiments and tests); default: when tracks > SIMDs
+    int lk_blocks_ = 0;  // PVIO_HIP_LK_BLOCKS: blocks of the unit queue (default one per CU)
     void *d_fm_ = nullptr, *h_fm_ = nullptr; // fundamental_ransac: points, samples, counts, models, mask words (+ pinned mirror)
     size_t fm_cap_ = 0;
     int last_fm_hypotheses_ = 0;

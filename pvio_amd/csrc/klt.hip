@@ -248,18 +248,19 @@ __device__ __forceinline__ void lk_tap_pairs(uint64_t w, int *pr) {
     for (int k = 0; k < 7; ++k) pr[k] = (int)(((w >> (8 * k)) & 255u) | (((w >> (8 * k + 8)) & 255u) << 16));
 }
 __device__ __forceinline__ void lk_load_tap_pairs(const uint8_t *s, int *pr) { lk_tap_pairs(*reinterpret_cast<const lk_u64_any *>(s), pr); }
-// derivative rows come as (x, y) int16 pairs per pixel: (x_k, x_k+1) and (y_k, y_k+1) pairs, k = 0..6
+// derivative rows come as (x, y) int16 pairs per pixel: (x_k, x_k+1) and (y_k, y_k+1) pairs, k = 0..6 -- one v_perm_b32 each
+// (bytes 0-3 = the second operand, 4-7 = the first): the low halves of (d_k, d_k+1), and their high halves
 __device__ __forceinline__ void lk_deriv_pairs(const lk_drv_raw &r, int *px, int *py) {
-    int d[8];
+    uint32_t d[8];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        d[k] = (int)((uint32_t)(uint16_t)r.lo.v[2 * k] | ((uint32_t)(uint16_t)r.lo.v[2 * k + 1] << 16));
-        d[4 + k] = (int)((uint32_t)(uint16_t)r.hi.v[2 * k] | ((uint32_t)(uint16_t)r.hi.v[2 * k + 1] << 16));
+        d[k] = (uint32_t)(uint16_t)r.lo.v[2 * k] | ((uint32_t)(uint16_t)r.lo.v[2 * k + 1] << 16);
+        d[4 + k] = (uint32_t)(uint16_t)r.hi.v[2 * k] | ((uint32_t)(uint16_t)r.hi.v[2 * k + 1] << 16);
     }
 #pragma unroll
     for (int k = 0; k < 7; ++k) {
-        px[k] = (int)(((uint32_t)d[k] & 0xffffu) | ((uint32_t)d[k + 1] << 16));
-        py[k] = (int)(((uint32_t)d[k] >> 16) | ((uint32_t)d[k + 1] & 0xffff0000u));
+        px[k] = (int)__builtin_amdgcn_perm(d[k + 1], d[k], 0x05040100u);
+        py[k] = (int)__builtin_amdgcn_perm(d[k + 1], d[k], 0x07060302u);
     }
 }
 __device__ __forceinline__ lk_drv_raw lk_load_derivs_raw(const int16_t *d) {
@@ -321,8 +322,9 @@ __device__ __forceinline__ int lk_template_form(const LkTplRaw &t, bool live, Lk
         T.ti[k] = lk_dot2(q1[k], wB, lk_dot2(q0[k], wA, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
         T.tx[k] = lk_dot2(x1[k], wB, lk_dot2(x0[k], wA, 1 << (W_BITS - 1))) >> W_BITS;
         T.ty[k] = lk_dot2(y1[k], wB, lk_dot2(y0[k], wA, 1 << (W_BITS - 1))) >> W_BITS;
-        if (live) sA11 += (float)(T.tx[k] * T.tx[k]), sA12 += (float)(T.tx[k] * T.ty[k]), sA22 += (float)(T.ty[k] * T.ty[k]);
+        sA11 += (float)(T.tx[k] * T.tx[k]), sA12 += (float)(T.tx[k] * T.ty[k]), sA22 += (float)(T.ty[k] * T.ty[k]);
     }
+    if (!live) sA11 = 0.f, sA12 = 0.f, sA22 = 0.f; // (selected after the sums, not a branch around each term)
     const float a11 = wave_sum_f(sA11) * FLT_SCALE, a12 = wave_sum_f(sA12) * FLT_SCALE, a22 = wave_sum_f(sA22) * FLT_SCALE;
     const float D = a11 * a22 - a12 * a12;
     const float minEig = (a22 + a11 - sqrtf((a11 - a22) * (a11 - a22) + 4.f * a12 * a12)) / (float)(2 * kWin * kWin);
@@ -332,96 +334,157 @@ __device__ __forceinline__ int lk_template_form(const LkTplRaw &t, bool live, Lk
     return 0;
 }
 
+// One pyramid level of one track (one wave): the position handed down, the level's template, its iterations.
 // One template at a time (formed at its level).  Forming the templates of all levels up front -- their loads and the
 // first search window of the coarsest level in flight together -- was built and measured: 33.2 us against 31.7 us for
 // 1500 tracks (205 VGPRs, two waves per SIMD); requesting each level's first search window before its template is
-// formed: no change.  The level chain is not bound by those loads but by the dependent arithmetic of the iterations.
-__global__ void __launch_bounds__(256) k_lk_track(TrackArgs a) {
+// formed: no change.
+__device__ __forceinline__ void lk_level(const LevelDesc &I, const LevelDesc &J, int level, bool coarsest, float pxf, float pyf, int lane, float &outx, float &outy, int &st) {
 #if defined(__clang__)
 #pragma clang fp contract(off)
 #endif
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int p = blockIdx.x * 4 + wv;
-    if (p >= a.n) return; // whole wave exits together
     const bool live = lane < kWin * 3;
     const int wy = live ? lane / 3 : 0, wx = live ? kRun * (lane - 3 * wy) : 0;
     const float half = (kWin - 1) * 0.5f, FLT_SCALE = 1.f / (1 << 20);
     constexpr int W_BITS = LK_W_BITS;
-    const float pxf = a.prev_xy[2 * p], pyf = a.prev_xy[2 * p + 1];
-    float outx = a.next_xy[2 * p], outy = a.next_xy[2 * p + 1];
-    int st = 1;
+    const float sc = (float)(1. / (1 << level));
+    float nx, ny;
+    if (coarsest) nx = outx * sc, ny = outy * sc; // OPTFLOW_USE_INITIAL_FLOW
+    else nx = outx * 2.f, ny = outy * 2.f;
+    outx = nx, outy = ny;
+    LkTplRaw raw;
     LkTpl T;
-    int r0[kRun], r1[kRun], cinx, ciny; // the lane's (tap, right neighbour) pairs of the search window, kept while its integer origin stays
-#pragma unroll
-    for (int li = 0; li < kLevels; ++li) {
-        const int level = kLevels - 1 - li;
-        if (level >= a.n_levels) continue;
-        const LevelDesc J = a.next[level];
-        const float sc = (float)(1. / (1 << level));
-        float nx, ny;
-        if (level == a.n_levels - 1) nx = outx * sc, ny = outy * sc; // OPTFLOW_USE_INITIAL_FLOW
-        else nx = outx * 2.f, ny = outy * 2.f;
-        outx = nx, outy = ny;
-        LkTplRaw raw;
-        int skip = lk_template_load(a.prev[level], level, pxf, pyf, wy, wx, raw); // wave-uniform
-        if (!skip) skip = lk_template_form(raw, live, T);
-        if (skip) { // template outside the image / degenerate gradient matrix
-            if (level == 0) st = 0;
-            continue;
-        }
-        const LkTpl &Tl = T;
-        const float a11 = Tl.A11, a12 = Tl.A12, a22 = Tl.A22, D = Tl.Dinv;
-        nx -= half, ny -= half;
-        float pdx = 0, pdy = 0;
-        cinx = -(1 << 30), ciny = -(1 << 30);
-        for (int j = 0; j < 30; ++j) {
-            const int inx = (int)floorf(nx), iny = (int)floorf(ny);
-            if (inx < -kWin || inx >= J.w || iny < -kWin || iny >= J.h) {
-                if (level == 0) st = 0;
-                break;
-            }
-            const float fa = nx - (float)inx, fb = ny - (float)iny;
-            const int iw00 = (int)rintf((1.f - fa) * (1.f - fb) * (float)(1 << W_BITS));
-            const int iw01 = (int)rintf(fa * (1.f - fb) * (float)(1 << W_BITS));
-            const int iw10 = (int)rintf((1.f - fa) * fb * (float)(1 << W_BITS));
-            const int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
-            if (inx != cinx || iny != ciny) { // uniform: the window only moves to other pixels every few iterations
-                const uint8_t *s0 = J.img + (size_t)(iny + wy + kPad) * J.pitch + (inx + wx + kPad), *s1 = s0 + J.pitch;
-                lk_load_tap_pairs(s0, r0), lk_load_tap_pairs(s1, r1);
-                cinx = inx, ciny = iny;
-            }
-            const int wA = iw00 | (iw01 << 16), wB = iw10 | (iw11 << 16);
-            float sb1 = 0, sb2 = 0;
-#pragma unroll
-            for (int k = 0; k < kRun; ++k) {
-                const int diff = (lk_dot2(r1[k], wB, lk_dot2(r0[k], wA, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5)) - Tl.ti[k];
-                sb1 += (float)__mul24(diff, Tl.tx[k]), sb2 += (float)__mul24(diff, Tl.ty[k]);
-            }
-            if (!live) sb1 = 0.f, sb2 = 0.f;
-            const float b1 = wave_sum_f(sb1) * FLT_SCALE, b2 = wave_sum_f(sb2) * FLT_SCALE;
-            const float dx = (a12 * b2 - a22 * b1) * D, dy = (a12 * b1 - a11 * b2) * D;
-            nx += dx, ny += dy;
-            outx = nx + half, outy = ny + half;
-            // OpenCV's two termination tests are DOUBLE comparisons (lkpyramid.cpp: `delta.ddot(delta) <= criteria.epsilon` with the double
-            // epsilon 0.01 squared by calcOpticalFlowPyrLK = 1.0000000000000002e-4; `std::abs(delta.x + prevDelta.x) < 0.01`: a float sum
-            // against the double literal): a float comparison decides differently within an ulp of either threshold.  Wave-uniform, twice per iteration.
-            if ((double)dx * (double)dx + (double)dy * (double)dy <= 0.01 * 0.01) break;
-            if (j > 0 && (double)fabsf(dx + pdx) < 0.01 && (double)fabsf(dy + pdy) < 0.01) {
-                outx -= dx * 0.5f, outy -= dy * 0.5f;
-                break;
-            }
-            pdx = dx, pdy = dy;
-        }
-        if (st && level == 0) {
-            const int ix = (int)floorf(outx - half), iy = (int)floorf(outy - half);
-            if (ix < -kWin || ix >= J.w || iy < -kWin || iy >= J.h) st = 0;
-        }
+    int skip = lk_template_load(I, level, pxf, pyf, wy, wx, raw); // wave-uniform
+    if (!skip) skip = lk_template_form(raw, live, T);
+    if (skip) { // template outside the image / degenerate gradient matrix
+        if (level == 0) st = 0;
+        return;
     }
-    // opencv_image.cpp:104-109: 20-px border of the full-resolution image
+    const float a11 = T.A11, a12 = T.A12, a22 = T.A22, D = T.Dinv;
+    nx -= half, ny -= half;
+    float pdx = 0, pdy = 0;
+    int r0[kRun], r1[kRun]; // the lane's (tap, right neighbour) pairs of the search window, kept while its integer origin stays
+    int cinx = -(1 << 30), ciny = -(1 << 30);
+    for (int j = 0; j < 30; ++j) {
+        const int inx = (int)floorf(nx), iny = (int)floorf(ny);
+        if (inx < -kWin || inx >= J.w || iny < -kWin || iny >= J.h) {
+            if (level == 0) st = 0;
+            break;
+        }
+        const float fa = nx - (float)inx, fb = ny - (float)iny;
+        const int iw00 = (int)rintf((1.f - fa) * (1.f - fb) * (float)(1 << W_BITS));
+        const int iw01 = (int)rintf(fa * (1.f - fb) * (float)(1 << W_BITS));
+        const int iw10 = (int)rintf((1.f - fa) * fb * (float)(1 << W_BITS));
+        const int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+        if (inx != cinx || iny != ciny) { // uniform: the window only moves to other pixels every few iterations
+            const uint8_t *s0 = J.img + (size_t)(iny + wy + kPad) * J.pitch + (inx + wx + kPad), *s1 = s0 + J.pitch;
+            lk_load_tap_pairs(s0, r0), lk_load_tap_pairs(s1, r1);
+            cinx = inx, ciny = iny;
+        }
+        const int wA = iw00 | (iw01 << 16), wB = iw10 | (iw11 << 16);
+        float sb1 = 0, sb2 = 0;
+#pragma unroll
+        for (int k = 0; k < kRun; ++k) {
+            const int diff = (lk_dot2(r1[k], wB, lk_dot2(r0[k], wA, 1 << (W_BITS - 5 - 1))) >> (W_BITS - 5)) - T.ti[k];
+            sb1 += (float)__mul24(diff, T.tx[k]), sb2 += (float)__mul24(diff, T.ty[k]);
+        }
+        if (!live) sb1 = 0.f, sb2 = 0.f;
+        const float b1 = wave_sum_f(sb1) * FLT_SCALE, b2 = wave_sum_f(sb2) * FLT_SCALE;
+        const float dx = (a12 * b2 - a22 * b1) * D, dy = (a12 * b1 - a11 * b2) * D;
+        nx += dx, ny += dy;
+        outx = nx + half, outy = ny + half;
+        // OpenCV's two termination tests are DOUBLE comparisons (lkpyramid.cpp: `delta.ddot(delta) <= criteria.epsilon` with the double
+        // epsilon 0.01 squared by calcOpticalFlowPyrLK = 1.0000000000000002e-4; `std::abs(delta.x + prevDelta.x) < 0.01`: a float sum
+        // against the double literal): a float comparison decides differently within an ulp of either threshold.  Wave-uniform, twice per
+        // iteration (deciding in float wherever that is provably the same, FP64 only near the thresholds: measured, no gain -- profiles/r5_ab_klt_float_tests.txt).
+        if ((double)dx * (double)dx + (double)dy * (double)dy <= 0.01 * 0.01) break;
+        if (j > 0 && (double)fabsf(dx + pdx) < 0.01 && (double)fabsf(dy + pdy) < 0.01) {
+            outx -= dx * 0.5f, outy -= dy * 0.5f;
+            break;
+        }
+        pdx = dx, pdy = dy;
+    }
+    if (st && level == 0) {
+        const int ix = (int)floorf(outx - half), iy = (int)floorf(outy - half);
+        if (ix < -kWin || ix >= J.w || iy < -kWin || iy >= J.h) st = 0;
+    }
+}
+// the end of a track: opencv_image.cpp:104-109, the 20-px border of the full-resolution image
+__device__ __forceinline__ void lk_finish(const TrackArgs &a, int p, int lane, float outx, float outy, int st) {
     if (outx < 20 || outx >= (float)(a.prev[0].w - 20) || outy < 20 || outy >= (float)(a.prev[0].h - 20)) st = 0;
     if (lane == 0) {
         a.next_xy[2 * p] = outx, a.next_xy[2 * p + 1] = outy;
         a.status[p] = (uint8_t)st;
+    }
+}
+
+// One wave per track, its levels in turn: the form for track counts that leave every SIMD at most one wave (n <= 4 x CUs).
+__global__ void __launch_bounds__(256) k_lk_track(TrackArgs a) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int p = blockIdx.x * 4 + wv;
+    if (p >= a.n) return; // whole wave exits together
+    const float pxf = a.prev_xy[2 * p], pyf = a.prev_xy[2 * p + 1];
+    float outx = a.next_xy[2 * p], outy = a.next_xy[2 * p + 1];
+    int st = 1;
+#pragma unroll
+    for (int li = 0; li < kLevels; ++li) {
+        const int level = kLevels - 1 - li;
+        if (level >= a.n_levels) continue;
+        lk_level(a.prev[level], a.next[level], level, level == a.n_levels - 1, pxf, pyf, lane, outx, outy, st);
+    }
+    lk_finish(a, p, lane, outx, outy, st);
+}
+
+// More tracks than SIMDs: (track, level) UNITS from a queue in LDS, one workgroup of eight waves per CU.  With a wave per track, 1500
+// tracks leave 476 of the 1024 SIMDs with two waves and 548 with one for the whole launch, and the launch lasts as long as the slowest
+// pair (tests/micro/klt_stamps.py, profiles/r5_klt_stamps.txt: a track alone 28.5k cycles, the slowest wave of 1500 60.5k, their mean
+// 34k).  Here block b owns the tracks b, b + G, b + 2 G, ... (G blocks = CUs) and its waves take units in the order (coarsest level
+// of each of its tracks, then the next level of each, ...): the CU's five or six level chains move from SIMD to SIMD with the wave
+// that happens to be free, so the SIMDs of a CU share its work instead of two of them carrying two tracks from start to end.  A unit
+// needs the position its predecessor hands down: sh_xy[track] behind sh_done[track] (workgroup-scope release / acquire: LDS, no global
+// atomics -- a queue in global memory was built first: one contended agent-scope counter serves ~80 M units/s, 125 us for 1500 tracks,
+// profiles/r5_ab_klt_units_global_queue.txt).  The unit a wave waits for was taken earlier by a wave of the same block, which is
+// resident: it can never wait on a unit that nobody holds.  The per-track arithmetic is lk_level's, untouched: bit-identical results.
+// Measured (profiles/r5_klt_units_check.txt, same box, min of 8): 1500 tracks 31.9 -> 30.2 us, 3000 42.2 -> 39.6, 2048 31.6 -> 32.2 (two
+// waves on every SIMD either way), 6000 61.1 -> 61.0: the rotation buys 5 %, not the 30 % the SIMD arithmetic promised -- what is left
+// is the CU's own share (six tracks of 16 +- 4 iterations each against five) and the serial chain of a track's four levels.
+constexpr int kLkUnitWaves = 8, kLkMaxOwned = 64; // waves per block; tracks a block can own (more tracks than 64 per CU: a wave per track)
+__global__ void __launch_bounds__(64 * kLkUnitWaves) k_lk_track_units(TrackArgs a) {
+    __shared__ int sh_next, sh_done[kLkMaxOwned];
+    __shared__ float sh_xy[2 * kLkMaxOwned];
+    const int lane = threadIdx.x & 63, G = gridDim.x, b = blockIdx.x;
+    const int owned = (a.n - b + G - 1) / G; // tracks b + k G < n
+    if (threadIdx.x == 0) sh_next = 0;
+    if (threadIdx.x < kLkMaxOwned) sh_done[threadIdx.x] = 0;
+    __syncthreads();
+    const int total = a.n_levels * owned;
+    for (;;) {
+        // Every lane takes part (lane 0 adds 1, the others 0): with the fetch under `if (lane == 0)` the compiler threads that branch
+        // with the `if (lane == 0)` of the hand-down at the end of the previous pass, lanes 1-63 go round an inner loop of their own
+        // and meet the readfirstlane without lane 0 -- unit 0 for ever (the first build of this kernel hung on the GPU that way).
+        __builtin_amdgcn_wave_barrier();
+        int u = 0;
+        if (lane == 0) u = __hip_atomic_fetch_add(&sh_next, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        u = __builtin_amdgcn_readfirstlane(u);
+        if (u >= total) break;
+        const int li = u / owned, k = u - li * owned, p = b + k * G, level = a.n_levels - 1 - li;
+        const float pxf = a.prev_xy[2 * p], pyf = a.prev_xy[2 * p + 1];
+        float outx, outy;
+        if (li == 0) outx = a.next_xy[2 * p], outy = a.next_xy[2 * p + 1];
+        else {
+            while (__hip_atomic_load(&sh_done[k], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < li) __builtin_amdgcn_s_sleep(1);
+            outx = sh_xy[2 * k], outy = sh_xy[2 * k + 1];
+        }
+        int st = 1; // only level 0 (the last unit of a track) can clear it
+        const LevelDesc I = level == 0 ? a.prev[0] : level == 1 ? a.prev[1] : level == 2 ? a.prev[2] : a.prev[3];
+        const LevelDesc J = level == 0 ? a.next[0] : level == 1 ? a.next[1] : level == 2 ? a.next[2] : a.next[3];
+        static_assert(kLevels == 4, "level selection above");
+        lk_level(I, J, level, li == 0, pxf, pyf, lane, outx, outy, st);
+        if (level == 0) lk_finish(a, p, lane, outx, outy, st);
+        else if (lane == 0) {
+            sh_xy[2 * k] = outx, sh_xy[2 * k + 1] = outy;
+            __hip_atomic_store(&sh_done[k], li + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
     }
 }
 
@@ -440,6 +503,10 @@ static int level_sizes(int w, int h, int *ws, int *hs) {
 
 Klt::Klt(int device) : device_(device) {
     (void)hipSetDevice(device_);
+    hipDeviceProp_t prop;
+    n_simds_ = hipGetDeviceProperties(&prop, device_) == hipSuccess ? 4 * std::max(1, prop.multiProcessorCount) : 1024;
+    if (const char *e = std::getenv("PVIO_HIP_LK_UNITS")) lk_units_ = std::atoi(e) != 0;
+    if (const char *e = std::getenv("PVIO_HIP_LK_BLOCKS")) lk_blocks_ = std::max(0, std::atoi(e));
     (void)hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking);
     (void)hipEventCreate(&ev0_);
     (void)hipEventCreate(&ev1_);
@@ -668,8 +735,12 @@ int Klt::track(const Image *prev, const Image *next, int n, const float *prev_xy
     char *hp = static_cast<char *>(h_pts_);
     std::memcpy(hp, prev_xy, (size_t)n * 8), std::memcpy(hp + (size_t)n * 8, next_xy, (size_t)n * 8);
     bool ok = hipMemcpyAsync(d_prev, hp, (size_t)n * 16, hipMemcpyHostToDevice, stream_) == hipSuccess;
+    // more tracks than SIMDs: (track, level) units from a queue in LDS, a block of eight waves per CU (see k_lk_track_units); otherwise a wave per track
+    const int blocks = lk_blocks_ > 0 ? lk_blocks_ : n_simds_ / 4;
+    const bool units = (lk_units_ >= 0 ? lk_units_ != 0 : n > n_simds_) && (n + blocks - 1) / blocks <= kLkMaxOwned;
     (void)hipEventRecord(ev0_, stream_);
-    hipLaunchKernelGGL(k_lk_track, dim3((n + 3) / 4), dim3(256), 0, stream_, a);
+    if (units) hipLaunchKernelGGL(k_lk_track_units, dim3(std::min(blocks, n)), dim3(64 * kLkUnitWaves), 0, stream_, a);
+    else hipLaunchKernelGGL(k_lk_track, dim3((n + 3) / 4), dim3(256), 0, stream_, a);
     (void)hipEventRecord(ev1_, stream_);
     ok = ok && hipMemcpyAsync(hp + (size_t)n * 8, d_next, (size_t)n * 9, hipMemcpyDeviceToHost, stream_) == hipSuccess;
     ok = ok && hipStreamSynchronize(stream_) == hipSuccess && hipGetLastError() == hipSuccess;

@@ -158,6 +158,27 @@ inline int __builtin_amdgcn_update_dpp(int /*old*/, int src, int ctrl, int row_m
     if (row_mask != 0xF || bank_mask != 0xF) std::abort();
     return __shfl(src, from);
 }
+inline float __uint_as_float(unsigned u) {
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+inline unsigned __float_as_uint(float f) {
+    unsigned u;
+    std::memcpy(&u, &f, 4);
+    return u;
+}
+// v_perm_b32: byte k of the result is byte sel[k] of the 8 bytes {s1 (0-3), s0 (4-7)}; selectors >= 8 (constants / sign fills) are not used by the kernels
+inline unsigned __builtin_amdgcn_perm(unsigned s0, unsigned s1, unsigned sel) {
+    const unsigned long long both = ((unsigned long long)s0 << 32) | s1;
+    unsigned r = 0;
+    for (int k = 0; k < 4; ++k) {
+        const unsigned b = (sel >> (8 * k)) & 255u;
+        if (b > 7) std::abort();
+        r |= (unsigned)((both >> (8 * b)) & 255u) << (8 * k);
+    }
+    return r;
+}
 // v_dot2_i32_i16
 typedef short hipemu_short2 __attribute__((vector_size(4)));
 inline int __builtin_amdgcn_sdot2(hipemu_short2 a, hipemu_short2 b, int c, bool /*clamp*/) { return (int)a[0] * (int)b[0] + (int)a[1] * (int)b[1] + c; }
@@ -166,6 +187,7 @@ inline int __builtin_amdgcn_sdot2(hipemu_short2 a, hipemu_short2 b, int c, bool 
 inline void __builtin_amdgcn_wave_barrier() { (void)__shfl(0, 0); }
 inline void __builtin_amdgcn_s_sleep(int) { hipemu::spin_yield(); } // a polling loop lets the other fibers run
 #define __HIP_MEMORY_SCOPE_WORKGROUP 2
+#define __HIP_MEMORY_SCOPE_AGENT 4
 template <typename T>
 inline T __hip_atomic_load(const T *p, int, int) { return *reinterpret_cast<const volatile T *>(p); }
 template <typename T>

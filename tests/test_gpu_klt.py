@@ -166,3 +166,29 @@ def test_gpu_lk_border_corner_starts_are_bit_identical(gpu_ctx, oracle):
     print("border corner: 243 starts (%d alive) + %d border points (%d alive): status identical, positions bit-identical" % (n_alive, len(ring), int((s0 > 0).sum())))
     A.release()
     B.release()
+
+
+def test_gpu_lk_unit_queue_is_bit_identical_to_a_wave_per_track(oracle, monkeypatch):
+    """k_lk_track_units ((track, level) units from a queue in LDS, eight waves per CU: the default for more tracks than SIMDs) against
+    k_lk_track (a wave per track) and the oracle, both forced by PVIO_HIP_LK_UNITS in contexts of their own: status bytes identical,
+    positions bit-identical, for track counts on both sides of the default's threshold (blocks that own 1, 6, 24 tracks; fewer tracks
+    than blocks).  The first build of the unit kernel hung the GPU (profiles/r5_ab_klt_units_hang.txt: the compiler threaded the two
+    `lane == 0` branches across the loop's back edge); the per-test time limit bounds this test should that ever come back."""
+    from pvio_amd import synth
+    from pvio_amd.solver import HipContext, HipImage, klt_track
+    monkeypatch.setenv("PVIO_HIP_LK_UNITS", "0")
+    per_track = HipContext(device=0)
+    monkeypatch.setenv("PVIO_HIP_LK_UNITS", "1")
+    units = HipContext(device=0)
+    img0, img1, p, truth, init = synth.make_image_pair(512, 512, 6000)
+    P0, P1 = oracle.build_pyramid(oracle.clahe(img0)), oracle.build_pyramid(oracle.clahe(img1))
+    imgs = [(HipImage(c, img0), HipImage(c, img1)) for c in (per_track, units)]
+    for n in (64, 5, 1500, 1025, 6000, 257):
+        qa, sa, _ = klt_track(per_track, imgs[0][0], imgs[0][1], p[:n], init[:n])
+        qb, sb, _ = klt_track(units, imgs[1][0], imgs[1][1], p[:n], init[:n])
+        assert (sa == sb).all() and qa.tobytes() == qb.tobytes(), n
+        if n <= 1500:
+            q0, s0 = oracle.klt_track(P0, P1, p[:n], init[:n])
+            assert (s0 == sb).all() and np.abs(q0 - qb)[s0 > 0].max() == 0.0
+    for c in (per_track, units):
+        c.close()
