@@ -37,9 +37,11 @@ def _follows_ground_truth(prefix, tol):
     return float(np.linalg.norm(tum[:, 1:4] - gt[idx, 1:4], axis=1).max()) < tol
 
 
-def test_chain_parity_emulated(tmp_path):
+def test_chain_parity_emulated(tmp_path, monkeypatch):
     """30 frames at 352 x 264 through the kernel emulator: bootstrap of a 3-keyframe window, PnP on every later frame, keyframe solves
-    and marginalizations of the sliding window (12 frames and no marginalization while the emulator switched fibers with swapcontext())"""
+    and marginalizations of the sliding window (12 frames and no marginalization while the emulator switched fibers with swapcontext()).
+    Both sides dump their LK calls (PVIO_KLT_DUMP): tests/probe_klt_dump.py must find every call bit-identical in inputs and outputs."""
+    monkeypatch.setenv("PVIO_KLT_DUMP", str(tmp_path / "lk"))
     subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "hipemu"), "libpvio_hipemu.so"])
     subprocess.check_call(["make", "-s", "-C", os.path.join(os.path.dirname(HERE), "oracle"), "liboracle.so"])
     a, b = str(tmp_path / "product"), str(tmp_path / "oracle")
@@ -52,6 +54,9 @@ def test_chain_parity_emulated(tmp_path):
     print("free running:", free)
     assert free["frames"] == 30 and free["tracked"] > 2500 and free["new"] > 150 and free["tum_poses"] >= 20 and free["margs"] >= 2
     assert _follows_ground_truth(a, 0.02)
+    import probe_klt_dump
+    calls = probe_klt_dump.read_calls(str(tmp_path / "lk_hip.bin"))
+    assert len(calls) >= 25 and probe_klt_dump.compare(str(tmp_path / "lk_hip.bin"), str(tmp_path / "lk_oracle.bin")) is None
 
 
 @pytest.mark.gpu
