@@ -59,3 +59,40 @@ def test_emulated_lk_unit_queue_is_bit_identical_to_a_wave_per_track(oracle, blo
         assert np.abs(nB - n0)[s0 > 0].max() == 0.0
     for c in (per_track, queue):
         c.close()
+
+
+@pytest.mark.parametrize("size", [(42, 42), (90, 90), (200, 180)])
+def test_emulated_lk_unit_queue_on_short_pyramids_and_border_tracks(oracle, size, monkeypatch):
+    """The unit queue where its level bookkeeping is exercised: pyramids of 1, 3 and 4 levels (a level is dropped once it is no larger
+    than the 21-pixel window), tracks that start ON the image border, outside the 20-pixel gate, with initial guesses outside the image (levels
+    whose template or search window leaves the padded image are skipped or end the track): status bytes identical to the oracle and to the
+    wave-per-track kernel, positions bit-identical."""
+    import numpy as np
+    from pvio_amd import synth
+    from pvio_amd.solver import HipImage, klt_track
+    w, h = size
+    subprocess.check_call(["make", "-s", "-C", EMU_DIR, "libpvio_hipemu.so"])
+    lib = capi.load(os.path.join(EMU_DIR, "libpvio_hipemu.so"))
+    monkeypatch.setenv("PVIO_HIP_LK_UNITS", "0")
+    per_track = HipContext(lib=lib)
+    monkeypatch.setenv("PVIO_HIP_LK_UNITS", "1")
+    monkeypatch.setenv("PVIO_HIP_LK_BLOCKS", "3")
+    queue = HipContext(lib=lib)
+    img0, img1, p, truth, init = synth.make_image_pair(w, h, 24)
+    P0, P1 = oracle.build_pyramid(oracle.clahe(img0)), oracle.build_pyramid(oracle.clahe(img1))
+    assert len(P0) == {42: 1, 90: 3, 200: 4}[w]
+    rng = np.random.default_rng(w)
+    edge = np.array([(0, 0), (w - 1, h - 1), (0.5, h / 2), (w / 2, 0.25), (w - 1, 3), (20, 20), (19.99, h / 2), (w - 20.01, h - 20.01)], np.float32)
+    far = (edge + rng.uniform(-60, 60, edge.shape)).astype(np.float32)  # guesses that may lie far outside the image
+    prev = np.concatenate([p, edge, edge]).astype(np.float32)
+    guess = np.concatenate([init, edge, far]).astype(np.float32)
+    imgs = [(HipImage(c, img0), HipImage(c, img1)) for c in (per_track, queue)]
+    nA, sA, _ = klt_track(per_track, imgs[0][0], imgs[0][1], prev, guess)
+    nB, sB, _ = klt_track(queue, imgs[1][0], imgs[1][1], prev, guess)
+    n0, s0 = oracle.klt_track(P0, P1, prev, guess)
+    assert (sA == sB).all() and (sB == s0).all()
+    assert nA.tobytes() == nB.tobytes()
+    assert (s0 > 0).sum() >= (4 if w > 42 else 0) and (s0 == 0).sum() >= 6  # both outcomes occur
+    assert (nB[s0 > 0] == n0[s0 > 0]).all()
+    for c in (per_track, queue):
+        c.close()
