@@ -25,9 +25,9 @@ def _kernel_isa(tmp_path, source, mangled_prefix):
         if not on and line.startswith(mangled_prefix) and line.rstrip().split(";")[0].rstrip().endswith(":"):
             on = True
         if on:
-            body.append(line)
-            if "s_endpgm" in line:
+            if line.startswith(".Lfunc_end"):
                 break
+            body.append(line)
     assert body, "kernel not found in the ISA"
     return body
 
@@ -55,3 +55,18 @@ def test_lk_track_kernel_is_loop_free_outside_its_iterations(tmp_path):
     body = _kernel_isa(tmp_path, "klt.hip", "_ZN5pvklt10k_lk_trackE")
     depths = [int(m.group(1)) for m in re.finditer(r"Loop Header: Depth=(\d+)", "".join(body))]
     assert depths == [1, 1, 1, 1], depths
+
+
+def test_kernel_isa_is_the_gpu_verified_one():
+    """tools/isa_ledger.py: every kernel's compiled body hashes to what tests/golden/isa_verified.json records as verified on an MI355X.  A
+    kernel edit (or a compiler that decides otherwise) fails here until `pytest -m gpu` and smoke() have passed on a GPU with a library built
+    from the edited tree and `python tools/isa_ledger.py --update "<that run>"` has recorded it -- the emulated tests cannot stand in for that."""
+    import sys
+    if not os.path.exists(HIPCC):
+        pytest.skip("no hipcc")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_ledger
+    diff, why = isa_ledger.compare(verbose=True)
+    if diff is None:
+        pytest.skip(why)
+    assert diff == [], "kernels whose ISA is not the GPU-verified one: %s" % ", ".join(diff)
