@@ -459,9 +459,10 @@ __global__ void __launch_bounds__(64 * kLkUnitWaves) k_lk_track_units(TrackArgs 
     __syncthreads();
     const int total = a.n_levels * owned;
     for (;;) {
-        // Every lane takes part (lane 0 adds 1, the others 0): with the fetch under `if (lane == 0)` the compiler threads that branch
-        // with the `if (lane == 0)` of the hand-down at the end of the previous pass, lanes 1-63 go round an inner loop of their own
-        // and meet the readfirstlane without lane 0 -- unit 0 for ever (the first build of this kernel hung on the GPU that way).
+        // The wave barrier (a convergent no-op) keeps this `if (lane == 0)` apart from the `if (lane == 0)` of the hand-down at the end of the
+        // previous pass: without it the compiler threads the two branches across the back edge, lanes 1-63 go round an inner loop of their
+        // own and meet the readfirstlane without lane 0 -- unit 0 for ever (the first build of this kernel hung on the GPU that way;
+        // tests/test_isa_guards.py checks the loop nest of the compiled kernel).
         __builtin_amdgcn_wave_barrier();
         int u = 0;
         if (lane == 0) u = __hip_atomic_fetch_add(&sh_next, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
