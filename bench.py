@@ -168,7 +168,11 @@ def bench_klt(ctx, args, width=512, height=512, n_points=1500, reps=50):
     for im in live:
         im.release()
     ud.release()
-    for _ in range(5):
+    # warm-up: the legs in front of this one are host work (pyramids through the wrapper, the CPU baseline of the BA leg), the GPU's clocks have
+    # dropped; 5 launches were not enough to bring them back (the same launch read 36.9 us here and 30.9 us in a loop of its own on one box,
+    # profiles/r6_klt_forms_check.txt)
+    t_w = time.perf_counter()
+    while time.perf_counter() - t_w < 0.25:
         klt_track(ctx, A, B, p, init)
     dev_ms, t0 = 0.0, time.perf_counter()
     for _ in range(reps):
@@ -203,14 +207,15 @@ def bench_klt(ctx, args, width=512, height=512, n_points=1500, reps=50):
         r_good, _, _, r_hyp = fundamental_ransac(ctx, rp, rq)
     ransac_ms = 1e3 * (time.perf_counter() - t0) / 20
     alg_bytes = 11616 * n_points  # 4 levels x (22^2 u8 template + 22^2 x 2 int16 derivatives + 22^2 u8 target)
-    # the launch is k_lk_track_units ((track, level) units from a per-CU queue) for more tracks than SIMDs, k_lk_track (a wave per track) otherwise (klt.hip)
+    # the launch form (klt.hip, Klt::track): k_lk_track_levels (a workgroup per track, a wave per pyramid level) while every track is resident at once
+    # (4 n <= 7 waves x SIMDs), k_lk_track (a wave per track) beyond; PVIO_HIP_LK_FORM forces one
     try:
         import torch
         n_simds = 4 * torch.cuda.get_device_properties(0).multi_processor_count
     except Exception:
         n_simds = 1024  # MI355X: 256 CUs
-    units = os.environ.get("PVIO_HIP_LK_UNITS")
-    lk_kernel = "k_lk_track_units" if (units != "0" and (units == "1" or n_points > n_simds)) else "k_lk_track"
+    form = os.environ.get("PVIO_HIP_LK_FORM", "0")
+    lk_kernel = {"1": "k_lk_track", "2": "k_lk_track_units", "3": "k_lk_track_levels"}.get(form, "k_lk_track_levels" if 4 * n_points <= 7 * n_simds else "k_lk_track")
     out = {"metric": "KLT tracks/ms", "value": n_points / dev_ms, "unit": "tracks/ms", "value_incl_h2d_d2h": n_points / wall_ms,
            "workload": "%dx%d u8 pair, %d tracks, win 21x21, 4 levels, <=30 iterations, initial flow given" % (width, height, n_points),
            "tracked": int(st.sum()), "preprocess_ms_per_image": prep_ms, "preprocess_undistorted_ms_per_image": prep_ud_ms, "detect_ms_per_image": detect_ms, "detected_corners": int(len(corners)),
@@ -321,6 +326,13 @@ def bench_scaling_window(ctx, args, rank, world, dist, barrier, preintegrate, n_
     return out
 
 
+def relaunch_command(n, argv):
+    """argv of the one-rank-per-GPU launch of this script (the form the driver uses for N > 1)"""
+    port = os.environ.get("MASTER_PORT", str(29500 + os.getpid() % 2000))
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", port,
+            os.path.abspath(__file__)] + list(argv)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -342,17 +354,24 @@ def main():
         pmc_child(args)
         return
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus 8` without a launcher used to run on ONE GPU and print "n_gpus": 8.  A bare multi-GPU
+        # invocation now becomes the launch the contract describes (one rank per GPU, rendezvous on 127.0.0.1); the line's n_gpus is the
+        # process group's world size, never the flag.
+        os.execv(sys.executable, relaunch_command(args.gpus, sys.argv[1:]))
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+
     # stdout carries exactly ONE line (the JSON): libraries that write to file descriptor 1 (RCCL prints its version banner
     # there at communicator creation) are sent to stderr for the duration of the run
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
 
     import torch
     if not torch.cuda.is_available():
@@ -550,7 +569,7 @@ def main():
         except Exception as e:  # the headline line must still be printed
             scaling_window = {"error": repr(e)}
     cpu = None
-    if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle_py as O
         O.build()
 
@@ -579,17 +598,17 @@ def main():
 
     # ---- KLT leg (second half of BASELINE.json's metric): tracks/ms, pyramids resident, TUM-VI-sized frames ----
     klt = None
-    if rank == 0 and args.gpus == 1 and not args.no_klt:
+    if rank == 0 and world == 1 and not args.no_klt:
         klt = bench_klt(ctx, args)
 
     multi = None
-    if rank == 0 and args.gpus == 1 and not args.no_klt:
+    if rank == 0 and world == 1 and not args.no_klt:
         multi = bench_concurrent_windows(pb_full)
 
     if rank == 0:
         value = iters / elapsed
         out = {
-            "metric": "BA iterations/sec", "value": value, "unit": "iterations/s", "n_gpus": args.gpus, "steps": args.steps,
+            "metric": "BA iterations/sec", "value": value, "unit": "iterations/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%d KF x %d landmarks, %s, %d reprojection factors, <=%d trust-region iterations per solve"

@@ -334,12 +334,21 @@ __device__ __forceinline__ int lk_template_form(const LkTplRaw &t, bool live, Lk
     return 0;
 }
 
-// One pyramid level of one track (one wave): the position handed down, the level's template, its iterations.
-// One template at a time (formed at its level).  Forming the templates of all levels up front -- their loads and the
-// first search window of the coarsest level in flight together -- was built and measured: 33.2 us against 31.7 us for
-// 1500 tracks (205 VGPRs, two waves per SIMD); requesting each level's first search window before its template is
-// formed: no change.
-__device__ __forceinline__ void lk_level(const LevelDesc &I, const LevelDesc &J, int level, bool coarsest, float pxf, float pyf, int lane, float &outx, float &outy, int &st) {
+// One pyramid level of one track (one wave) in two parts: the level's template (depends on the previous image and the point only, not on the
+// position handed down from the coarser level) and the search (the iterations from the handed-down position).  k_lk_track runs them back to back,
+// level after level; k_lk_track_levels forms the templates of all levels at once, a wave each.
+// Within ONE wave, forming the templates of all levels up front -- their loads and the first search window of the coarsest level in flight
+// together -- was built and measured: 33.2 us against 31.7 us for 1500 tracks (205 VGPRs, two waves per SIMD); requesting each level's first
+// search window before its template is formed: no change.
+__device__ __forceinline__ int lk_level_template(const LevelDesc &I, int level, float pxf, float pyf, int lane, LkTpl &T) {
+    const bool live = lane < kWin * 3;
+    const int wy = live ? lane / 3 : 0, wx = live ? kRun * (lane - 3 * wy) : 0;
+    LkTplRaw raw;
+    int skip = lk_template_load(I, level, pxf, pyf, wy, wx, raw); // wave-uniform
+    if (!skip) skip = lk_template_form(raw, live, T);
+    return skip; // template outside the image / degenerate gradient matrix
+}
+__device__ __forceinline__ void lk_level_search(const LevelDesc &J, int level, bool coarsest, const LkTpl &T, int skip, int lane, float &outx, float &outy, int &st) {
 #if defined(__clang__)
 #pragma clang fp contract(off)
 #endif
@@ -352,11 +361,7 @@ __device__ __forceinline__ void lk_level(const LevelDesc &I, const LevelDesc &J,
     if (coarsest) nx = outx * sc, ny = outy * sc; // OPTFLOW_USE_INITIAL_FLOW
     else nx = outx * 2.f, ny = outy * 2.f;
     outx = nx, outy = ny;
-    LkTplRaw raw;
-    LkTpl T;
-    int skip = lk_template_load(I, level, pxf, pyf, wy, wx, raw); // wave-uniform
-    if (!skip) skip = lk_template_form(raw, live, T);
-    if (skip) { // template outside the image / degenerate gradient matrix
+    if (skip) {
         if (level == 0) st = 0;
         return;
     }
@@ -409,6 +414,11 @@ __device__ __forceinline__ void lk_level(const LevelDesc &I, const LevelDesc &J,
         if (ix < -kWin || ix >= J.w || iy < -kWin || iy >= J.h) st = 0;
     }
 }
+__device__ __forceinline__ void lk_level(const LevelDesc &I, const LevelDesc &J, int level, bool coarsest, float pxf, float pyf, int lane, float &outx, float &outy, int &st) {
+    LkTpl T;
+    const int skip = lk_level_template(I, level, pxf, pyf, lane, T);
+    lk_level_search(J, level, coarsest, T, skip, lane, outx, outy, st);
+}
 // the end of a track: opencv_image.cpp:104-109, the 20-px border of the full-resolution image
 __device__ __forceinline__ void lk_finish(const TrackArgs &a, int p, int lane, float outx, float outy, int st) {
     if (outx < 20 || outx >= (float)(a.prev[0].w - 20) || outy < 20 || outy >= (float)(a.prev[0].h - 20)) st = 0;
@@ -433,6 +443,45 @@ __global__ void __launch_bounds__(256) k_lk_track(TrackArgs a) {
         lk_level(a.prev[level], a.next[level], level, level == a.n_levels - 1, pxf, pyf, lane, outx, outy, st);
     }
     lk_finish(a, p, lane, outx, outy, st);
+}
+
+// One WORKGROUP per track, one wave per pyramid level (round 6).  A track's four templates depend on the previous image and the point alone, so the
+// four waves load and form them at the same time (38 % of a track's VALU work and four dependent miss latencies with a wave per track:
+// tests/micro/klt_stamps.py); the searches are a chain -- level l starts from the position level l + 1 ended at -- and pass through the block in level
+// order: wave s searches between workgroup barriers s and s + 1 (hardware barriers: a waiting wave issues nothing and nothing is polled, so the
+// code-generation hazard of the unit queue below cannot occur), the position goes down through two LDS words.  A track's chain is template +
+// searches (~18 k cycles) instead of 4 templates + searches (~28.5 k); 1500 tracks are 6000 waves, all resident at once (62 VGPRs: eight waves per
+// SIMD), so every SIMD carries a quarter of ~6 tracks instead of one or two whole ones.  The arithmetic is lk_level's two halves, untouched: status and
+// positions bit-identical to k_lk_track and the oracle (tests/test_gpu_klt.py).
+__global__ void __launch_bounds__(64 * kLevels) k_lk_track_levels(TrackArgs a) {
+    __shared__ float sh_xy[2][2]; // double-buffered by the parity of the step: a wave's lanes read one pair and write the other
+    const int lane = threadIdx.x & 63, p = blockIdx.x;
+    // step of this wave in the chain (0: the coarsest level).  (The hardware already starts every block on another SIMD -- tools/ubench/wave_placement.hip:
+    // the four waves of a block sit on four SIMDs, wave 0's SIMD differs from block to block, blocks b, b + 256, ... share a CU; rotating the mapping by
+    // hand was 10 % slower, profiles/r6_klt_levels_ab.txt)
+    const int wv = threadIdx.x >> 6;
+    const int level = a.n_levels - 1 - wv; // waves without a level only keep the barrier count
+    const float pxf = a.prev_xy[2 * p], pyf = a.prev_xy[2 * p + 1];
+    static_assert(kLevels == 4, "level selection below");
+    LkTpl T;
+    int skip = 1;
+    if (level >= 0) {
+        const LevelDesc I = level == 0 ? a.prev[0] : level == 1 ? a.prev[1] : level == 2 ? a.prev[2] : a.prev[3];
+        skip = lk_level_template(I, level, pxf, pyf, lane, T);
+    }
+    const LevelDesc J = level <= 0 ? a.next[0] : level == 1 ? a.next[1] : level == 2 ? a.next[2] : a.next[3];
+    for (int s = 0; s < a.n_levels; ++s) {
+        if (s == wv) { // wave-uniform
+            float outx, outy;
+            if (s == 0) outx = a.next_xy[2 * p], outy = a.next_xy[2 * p + 1];
+            else outx = sh_xy[(s - 1) & 1][0], outy = sh_xy[(s - 1) & 1][1];
+            int st = 1; // only level 0 (the last search of a track) can clear it
+            lk_level_search(J, level, s == 0, T, skip, lane, outx, outy, st);
+            if (level == 0) lk_finish(a, p, lane, outx, outy, st);
+            else sh_xy[s & 1][lane & 1] = (lane & 1) ? outy : outx; // every lane stores the wave-uniform value (no lane-0 branch in this loop)
+        }
+        __syncthreads();
+    }
 }
 
 // More tracks than SIMDs: (track, level) UNITS from a queue in LDS, one workgroup of eight waves per CU.  With a wave per track, 1500
@@ -506,7 +555,7 @@ Klt::Klt(int device) : device_(device) {
     (void)hipSetDevice(device_);
     hipDeviceProp_t prop;
     n_simds_ = hipGetDeviceProperties(&prop, device_) == hipSuccess ? 4 * std::max(1, prop.multiProcessorCount) : 1024;
-    if (const char *e = std::getenv("PVIO_HIP_LK_UNITS")) lk_units_ = std::atoi(e) != 0;
+    if (const char *e = std::getenv("PVIO_HIP_LK_FORM")) lk_form_ = std::min(3, std::max(0, std::atoi(e)));
     if (const char *e = std::getenv("PVIO_HIP_LK_BLOCKS")) lk_blocks_ = std::max(0, std::atoi(e));
     (void)hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking);
     (void)hipEventCreate(&ev0_);
@@ -738,9 +787,14 @@ int Klt::track(const Image *prev, const Image *next, int n, const float *prev_xy
     bool ok = hipMemcpyAsync(d_prev, hp, (size_t)n * 16, hipMemcpyHostToDevice, stream_) == hipSuccess;
     // more tracks than SIMDs: (track, level) units from a queue in LDS, a block of eight waves per CU (see k_lk_track_units); otherwise a wave per track
     const int blocks = lk_blocks_ > 0 ? lk_blocks_ : n_simds_ / 4;
-    const bool units = (lk_units_ >= 0 ? lk_units_ != 0 : n > n_simds_) && (n + blocks - 1) / blocks <= kLkMaxOwned;
+    const bool units = lk_form_ == 2 && (n + blocks - 1) / blocks <= kLkMaxOwned;
+    // default: a workgroup per track and a wave per level while all of them are resident at once (seven waves of 72 VGPRs per SIMD), a wave per
+    // track beyond that -- same-box A/B of the mean of 50 launches, profiles/r6_klt_levels_ab.txt: 150 tracks 20.6 -> 17.4 us, 1500 tracks 31.1 ->
+    // 30.6, 2048 tracks 31.0 -> 35.7 (the levels form needs a second round there)
+    const bool levels = lk_form_ == 0 ? (long)n * kLevels <= 7L * n_simds_ : lk_form_ == 3;
     (void)hipEventRecord(ev0_, stream_);
     if (units) hipLaunchKernelGGL(k_lk_track_units, dim3(std::min(blocks, n)), dim3(64 * kLkUnitWaves), 0, stream_, a);
+    else if (levels) hipLaunchKernelGGL(k_lk_track_levels, dim3(n), dim3(64 * kLevels), 0, stream_, a);
     else hipLaunchKernelGGL(k_lk_track, dim3((n + 3) / 4), dim3(256), 0, stream_, a);
     (void)hipEventRecord(ev1_, stream_);
     ok = ok && hipMemcpyAsync(hp + (size_t)n * 8, d_next, (size_t)n * 9, hipMemcpyDeviceToHost, stream_) == hipSuccess;

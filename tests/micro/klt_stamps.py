@@ -67,7 +67,7 @@ def child(mode, n, truth_guess):
     import numpy as np
     from pvio_amd import synth, capi
     from pvio_amd.solver import HipContext, HipImage, klt_track
-    os.environ["PVIO_HIP_LK_UNITS"] = "0"  # the stamped kernel is the one with a wave per track
+    os.environ["PVIO_HIP_LK_FORM"] = "1"  # the stamped kernel is the one with a wave per track
     ctx = HipContext(lib=capi.load(os.path.join(OUT, "klt_stamps_%s.so" % mode)), device=0)
     img0, img1, p, truth, init = synth.make_image_pair(512, 512, 6000)
     A, B = HipImage(ctx, img0), HipImage(ctx, img1)

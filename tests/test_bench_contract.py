@@ -52,3 +52,39 @@ def test_traffic_comes_from_counter_passes_of_the_run_or_is_null(monkeypatch):
 def test_dense_roofline_flops():
     # P^3 / 3 + 2 P^2 at P = 150: 1.17 Mflop per factoring launch; the FP64 peak quoted is the MI355X figure
     assert abs((150 ** 3 / 3.0 + 2.0 * 150 ** 2) - 1.17e6) < 1e4 and bench.FP64_PEAK_TFLOPS == 78.6
+
+
+def test_bare_multi_gpu_invocation_becomes_a_one_rank_per_gpu_launch(monkeypatch):
+    """`python bench.py --gpus 8` without a launcher ran on one GPU and printed "n_gpus": 8.  A bare --gpus N > 1 now re-executes
+    itself under torch.distributed.run with N ranks (rendezvous on 127.0.0.1); a launcher's WORLD_SIZE that disagrees with the flag is an error;
+    the printed n_gpus is the world size, not the flag."""
+    import inspect
+    import pytest
+    calls = []
+
+    class Stop(Exception):
+        pass
+
+    def fake_execv(exe, argv):
+        calls.append((exe, argv))
+        raise Stop()
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(os, "execv", fake_execv)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7", "--warmup", "2"])
+    with pytest.raises(Stop):
+        bench.main()
+    exe, argv = calls[0]
+    assert exe == sys.executable and argv[1:3] == ["-m", "torch.distributed.run"]
+    assert argv[argv.index("--nproc-per-node") + 1] == "4" and argv[argv.index("--master-addr") + 1] == "127.0.0.1"
+    assert argv[-6:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"] and argv[-7] == os.path.join(ROOT, "bench.py")
+    # a launcher's world that disagrees with the flag: refused before anything touches a GPU
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "does not match WORLD_SIZE" in str(e.value)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "1"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "does not match WORLD_SIZE" in str(e.value)
+    src = inspect.getsource(bench.main)
+    assert '"n_gpus": world' in src and '"n_gpus": args.gpus' not in src

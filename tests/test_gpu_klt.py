@@ -168,27 +168,32 @@ def test_gpu_lk_border_corner_starts_are_bit_identical(gpu_ctx, oracle):
     B.release()
 
 
-def test_gpu_lk_unit_queue_is_bit_identical_to_a_wave_per_track(oracle, monkeypatch):
-    """k_lk_track_units ((track, level) units from a queue in LDS, eight waves per CU: the default for more tracks than SIMDs) against
-    k_lk_track (a wave per track) and the oracle, both forced by PVIO_HIP_LK_UNITS in contexts of their own: status bytes identical,
-    positions bit-identical, for track counts on both sides of the default's threshold (blocks that own 1, 6, 24 tracks; fewer tracks
-    than blocks).  The first build of the unit kernel hung the GPU (profiles/r5_ab_klt_units_hang.txt: the compiler threaded the two
-    `lane == 0` branches across the loop's back edge); the per-test time limit bounds this test should that ever come back."""
+def test_gpu_lk_forms_are_bit_identical(oracle, monkeypatch):
+    """The three launch forms of the LK search, each forced by PVIO_HIP_LK_FORM in a context of its own -- k_lk_track_levels (a workgroup per track,
+    a wave per pyramid level, hardware barriers between the levels' searches: the default since round 6), k_lk_track (a wave per track),
+    k_lk_track_units ((track, level) units from a queue in LDS, eight waves per CU) -- and the oracle: status bytes identical, positions
+    bit-identical, for track counts from fewer than CUs to six per SIMD.  The first build of the unit kernel hung the GPU
+    (profiles/r5_ab_klt_units_hang.txt: the compiler threaded the two `lane == 0` branches across the loop's back edge); the per-test time limit
+    bounds this test should that ever come back."""
     from pvio_amd import synth
     from pvio_amd.solver import HipContext, HipImage, klt_track
-    monkeypatch.setenv("PVIO_HIP_LK_UNITS", "0")
+    monkeypatch.setenv("PVIO_HIP_LK_FORM", "1")
     per_track = HipContext(device=0)
-    monkeypatch.setenv("PVIO_HIP_LK_UNITS", "1")
+    monkeypatch.setenv("PVIO_HIP_LK_FORM", "2")
     units = HipContext(device=0)
+    monkeypatch.setenv("PVIO_HIP_LK_FORM", "3")
+    levels = HipContext(device=0)
     img0, img1, p, truth, init = synth.make_image_pair(512, 512, 6000)
     P0, P1 = oracle.build_pyramid(oracle.clahe(img0)), oracle.build_pyramid(oracle.clahe(img1))
-    imgs = [(HipImage(c, img0), HipImage(c, img1)) for c in (per_track, units)]
+    imgs = [(HipImage(c, img0), HipImage(c, img1)) for c in (per_track, units, levels)]
     for n in (64, 5, 1500, 1025, 6000, 257):
         qa, sa, _ = klt_track(per_track, imgs[0][0], imgs[0][1], p[:n], init[:n])
         qb, sb, _ = klt_track(units, imgs[1][0], imgs[1][1], p[:n], init[:n])
+        qc, sc, _ = klt_track(levels, imgs[2][0], imgs[2][1], p[:n], init[:n])
         assert (sa == sb).all() and qa.tobytes() == qb.tobytes(), n
+        assert (sa == sc).all() and qa.tobytes() == qc.tobytes(), n
         if n <= 1500:
             q0, s0 = oracle.klt_track(P0, P1, p[:n], init[:n])
-            assert (s0 == sb).all() and np.abs(q0 - qb)[s0 > 0].max() == 0.0
-    for c in (per_track, units):
+            assert (s0 == sc).all() and np.abs(q0 - qc)[s0 > 0].max() == 0.0
+    for c in (per_track, units, levels):
         c.close()
