@@ -931,6 +931,8 @@ __device__ __forceinline__ void role_landmarks(const View &v, double *lds, const
     PV_STAMP(0, 8);
 }
 
+#include "ba_lin_tp.h" // role_landmarks_tp: the landmark role of large windows (Dims::lm_mm)
+
 // ---- plane-distance factors: one thread per factor, rows staged in LDS, same tile machinery (sign +) ----
 template <int T>
 __device__ __forceinline__ void role_planes(const View &v, double *lds, const Pro *pro, int wg, int n_wg, int part_row) {
@@ -1182,7 +1184,10 @@ __global__ void __launch_bounds__(kLinThreads) k_linearize(View v) {
     const int bx = blockIdx.x;
     const int b = bx < naux ? g1 + bx : (bx < naux + v.dm.G_plane ? g0 + (bx - naux) : bx - naux - v.dm.G_plane);
     if (v.dbg && v.dbg_sel < 0 && threadIdx.x == 0 && (b == g1 || b == g2)) v.dbg[b == g1 ? 10 : 12] = clock64(); // first IMU / prior workgroup (absolute)
-    if (b < g0) role_landmarks<T, MM, MM ? TilesPerWave<T>::value : 1>(v, lds, pro, b, g0);
+    if (b < g0) {
+        if constexpr (MM) role_landmarks_tp<TilesPerWave<T>::value, (T >= 9 ? 2 : 1)>(v, lds, pro, b, g0);
+        else role_landmarks<T, false, 1>(v, lds, pro, b, g0);
+    }
     else if (b < g1) {
         if (pro->mode != MODE_MARG) role_planes<T>(v, lds, pro, b - g0, v.dm.G_plane, b);
         else zero_partial_row(v, b);
@@ -3460,14 +3465,20 @@ __global__ void __launch_bounds__(256) k_prior_prep(const double *S, const doubl
 // ------------------------------------------------------------------------------------------------------
 // host-side launchers
 // ------------------------------------------------------------------------------------------------------
+// landmarks per chunk of the large-window role (ba_lin_tp.h): as many U rows as fit beside the factor rows in 150 KB of LDS, a multiple of
+// four (the K of one MFMA), at most 64
+int tp_landmark_slots(const Dims &dm) {
+    const size_t common = (size_t)(dm.N * 16 + dm.N * kFrameRec + 160 + 16), budget = 150 * 1024 / sizeof(double);
+    int s = 64;
+    while (s > 4 && common + tp_lds_doubles(dm.N, dm.P6, s, dm.n_tasks) > budget) s -= 4;
+    return s;
+}
+
 size_t linearize_lds_bytes(const Dims &dm) {
     const int N = dm.N;
     size_t common = (size_t)(N * 16 + N * kFrameRec + 160 + 16);
-    const size_t slots = dm.lm_mm ? (size_t)((dm.lm_slots + 3) & ~3) : (size_t)dm.lm_slots;
-    size_t lm = slots * (40 * N + 46) + slots + 2 * ((slots + 1) / 2) + 4;
-    if (dm.lm_mm && dm.P6 <= 64) lm += 4 * 64 * 6 + 4 * 36; // the four waves' (target, anchor) rows / anchor blocks at an anchor flush
-    if (dm.lm_mm && lm < (size_t)dm.n_tasks * 5) lm = (size_t)dm.n_tasks * 5; // staging of the final flush
-    if (dm.lm_mm && dm.P6 <= 64 && lm < 4 * 64 * 16) lm = 4 * 64 * 16;          // ... and the four waves' sets in front of it
+    const size_t slots = (size_t)dm.lm_slots;
+    size_t lm = dm.lm_mm ? tp_lds_doubles(N, dm.P6, (dm.lm_slots + 3) & ~3, dm.n_tasks) : slots * (40 * N + 46) + slots + 2 * ((slots + 1) / 2) + 4;
     size_t pl = (size_t)dm.plane_slots * (dm.P6 + 2);
     size_t pre = 16 + 450 + 450 + 16 + 225;
     size_t pri = (size_t)dm.prior_n * (15 + 9) + 40;

@@ -228,7 +228,10 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st, bool ma
     // fewer rows for k_reduce to sum (PVIO_HIP_LM_WGS=n caps the count; profiles/r5_ab_partials.txt): the traffic falls with the count and the
     // iteration rate with it, because a workgroup's chain grows with the landmarks it holds (the per-landmark sums and the tile accumulation walk
     // them one after another): 48 rows = 12 161 against 14 112 iterations/s, k_linearize 18.4 -> 29.2 us for 0.4 us less in k_reduce.
-    static const int lm_wgs_cap = std::getenv("PVIO_HIP_LM_WGS") ? std::atoi(std::getenv("PVIO_HIP_LM_WGS")) : 0;
+    // (an experiment switch, unsupported: read once per process, clamped to [1, 4 x CUs] -- the partial-row buffers are sized from the resulting grid below,
+    // so any value in the range is safe; anything else is ignored)
+    static const int lm_wgs_env = std::getenv("PVIO_HIP_LM_WGS") ? std::atoi(std::getenv("PVIO_HIP_LM_WGS")) : 0;
+    const int lm_wgs_cap = lm_wgs_env >= 1 ? std::min(lm_wgs_env, 4 * cus) : 0;
     int lm_cus = std::max(1, cus - dm.G_plane - dm.G_pre - dm.G_prior);
     if (lm_wgs_cap > 0) lm_cus = lm_wgs_cap; // (may exceed the free CUs: more than one workgroup per CU where registers and LDS allow)
     const int slots_lds = (int)std::max<size_t>(1, std::min<size_t>(lds_budget / 8 / (40 * N + 46), (size_t)kLinThreads));
@@ -252,6 +255,41 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st, bool ma
     dm.G_lm = std::max(1, std::min(dm.n_chunks, lm_cus));
     // A workgroup that walks many chunks spends its time in the Schur outer products: those go to the matrix cores then
     dm.lm_mm = lin_mode_ == 2 || (lin_mode_ == 0 && dm.n_chunks > 2 * dm.G_lm);
+    // Large windows (ba_lin_tp.h): chunks of <= 256 factors whose landmarks share ONE anchor frame (a chunk is cut where the anchor changes: the
+    // reference's block order is anchor-sorted, any other order only makes more chunks), as many landmarks as the LDS holds U rows for; every
+    // chunk's factors sorted by target frame (the direct part of J^T J is accumulated per target)
+    std::vector<int32_t> chunk_tptr;
+    std::vector<uint8_t> chunk_perm;
+    if (dm.lm_mm) {
+        dm.lm_slots = tp_landmark_slots(dm);
+        chunk_lm.assign(1, 0);
+        int cnt = 0, fac = 0, anchor = -1;
+        for (int l = 0; l < M; ++l) {
+            const int k = pb->lm_obs_ptr[l + 1] - pb->lm_obs_ptr[l];
+            if (cnt > 0 && (cnt + 1 > dm.lm_slots || fac + k > kLinThreads || pb->lm_anchor_frame[l] != anchor)) {
+                chunk_lm.push_back(l);
+                cnt = 0, fac = 0;
+            }
+            anchor = pb->lm_anchor_frame[l];
+            ++cnt, fac += k;
+        }
+        if (M > 0) chunk_lm.push_back(M);
+        dm.n_chunks = (int)chunk_lm.size() - 1;
+        dm.G_lm = std::max(1, std::min(dm.n_chunks, lm_cus));
+        chunk_tptr.assign((size_t)dm.n_chunks * (N + 1), 0);
+        chunk_perm.assign((size_t)std::max(F, 1), 0);
+        for (int c = 0; c < dm.n_chunks; ++c) {
+            const int o0 = pb->lm_obs_ptr[chunk_lm[c]], o1 = pb->lm_obs_ptr[chunk_lm[c + 1]];
+            int32_t *tp = chunk_tptr.data() + (size_t)c * (N + 1);
+            for (int o = o0; o < o1; ++o) ++tp[pb->obs_frame[o] + 1];
+            for (int t = 0; t < N; ++t) tp[t + 1] += tp[t];
+            int fill[kMaxFrames] = {0};
+            for (int o = o0; o < o1; ++o) { // counting sort, stable: a target's factors in landmark order
+                const int t = pb->obs_frame[o];
+                chunk_perm[(size_t)o0 + tp[t] + fill[t]++] = (uint8_t)(o - o0);
+            }
+        }
+    }
     // pvio_hip_opts::reuse_identical_candidates.  Not on landmark shards: their k_reduce feeds an all-reduce that sums IN PLACE, a skipped slot
     // would add the last slot's sums to themselves.
     dm.reuse_cand = (reuse_cand_ && !sharded_) ? 1 : 0;
@@ -307,6 +345,8 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st, bool ma
     stage.add(pb->obs_z, (size_t)F * 2, &v.obs_z);
     stage.add(obs_lm.data(), (size_t)F, &v.obs_lm);
     stage.add(chunk_lm.data(), chunk_lm.size(), &v.chunk_lm);
+    stage.add(chunk_tptr.empty() ? (const int32_t *)nullptr : chunk_tptr.data(), chunk_tptr.size(), &v.chunk_tptr);
+    stage.add(chunk_perm.empty() ? (const uint8_t *)nullptr : chunk_perm.data(), chunk_perm.size(), &v.chunk_perm);
     stage.add(task_desc.data(), task_desc.size(), &v.task_desc);
     stage.add(pre_valid.data(), Ns, &v.pre_valid);
     stage.add(dm.use_inertial ? pb->preint_delta : nullptr, Ns * 11, &v.pre_delta);

@@ -121,6 +121,10 @@ struct View { // passed by value to every kernel
     const double *lm_zref, *obs_z;
     const double *lm_mult; // [M] multiplicity of the landmark's residual blocks as a double, or null (every block once)
     const int32_t *chunk_lm;      // [n_chunks+1] landmark ranges
+    // Dims::lm_mm (large windows, ba_lin_tp.h): every chunk's factors sorted by target frame -- chunk_perm[o] = chunk-relative factor index of the
+    // o-th entry of the chunk's sorted list, chunk_tptr[chunk][t] = where target t's entries start in it
+    const int32_t *chunk_tptr;    // [n_chunks][N + 1]
+    const uint8_t *chunk_perm;    // [F]
     const int32_t *task_desc;     // [n_tasks] packed fi | fj<<8 | si<<16 | sj<<17
     const uint8_t *pre_valid;     // [N]
     const double *pre_delta, *pre_U, *pre_jac;

@@ -28,9 +28,14 @@
 
 #include "pv_math.h" // PV_HD
 
+// (clang: the pragma is scoped to each function body below -- PV_FM_NO_CONTRACT, like pv_math.h's q_mul -- so that including this header does not change
+// how the rest of a translation unit is compiled; GCC: push / pop around the header)
 #if defined(__clang__)
-#pragma clang fp contract(off) // (file scope: holds for everything below in the translation unit; klt.hip's own float kernels say the same per function)
-#elif defined(__GNUC__)
+#define PV_FM_NO_CONTRACT _Pragma("clang fp contract(off)")
+#else
+#define PV_FM_NO_CONTRACT
+#endif
+#if !defined(__clang__) && defined(__GNUC__)
 #pragma GCC push_options
 #pragma GCC optimize("fp-contract=off") // g++ contracts by default (-ffp-contract=fast) unless the build says otherwise: the functions below must not
 #endif
@@ -39,6 +44,7 @@ namespace pvfm {
 
 // x^(1/3), x > 0: Newton on y^3 = x from a power of two within a factor of two of the root, a fixed number of steps (each: y <- (2 y + x / y^2) / 3)
 PV_HD double fm_cbrt(double x) {
+    PV_FM_NO_CONTRACT
     if (!(x > 0)) return 0.0;
     int e;
     (void)frexp(x, &e); // x = m 2^e, m in [1/2, 1): exact
@@ -49,11 +55,13 @@ PV_HD double fm_cbrt(double x) {
 }
 
 PV_HD double fm_det3(const double *m) {
+    PV_FM_NO_CONTRACT
     return m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
 }
 
 // real roots of c[0] x^3 + c[1] x^2 + c[2] x + c[3] = 0 in the order of the closed form (three cosines, or the single real root)
 PV_HD int fm_solve_cubic(const double c[4], double x[3]) {
+    PV_FM_NO_CONTRACT
     const double a0 = c[0];
     if (a0 == 0) {
         if (c[1] == 0) {
@@ -100,6 +108,7 @@ PV_HD int fm_solve_cubic(const double c[4], double x[3]) {
 
 // up to three 3 x 3 matrices (row-major) with q^T F p = 0 for the seven correspondences
 PV_HD int fm_seven_point(const float p[14], const float q[14], double F[27]) {
+    PV_FM_NO_CONTRACT
     // rows (x2 x1, x2 y1, x2, y2 x1, y2 y1, y2, x1, y1, 1) . f = 0 ; f1, f2 = a basis of the null space.  The null space comes from a
     // Householder QR of A^T (9 x 7): the last two columns of Q are orthogonal to all seven rows.  (The eigenvectors of A^T A would
     // square the condition number -- pixel coordinates are not normalized here, as in OpenCV's 7-point routine.)
@@ -173,6 +182,7 @@ PV_HD int fm_seven_point(const float p[14], const float q[14], double F[27]) {
 
 // max of the two squared point-to-epipolar-line distances of (x1, y1) <-> (x2, y2) under F, rounded to float like OpenCV's error vector
 PV_HD float fm_error(const double *F, double x1, double y1, double x2, double y2) {
+    PV_FM_NO_CONTRACT
     double a = F[0] * x1 + F[1] * y1 + F[2], b = F[3] * x1 + F[4] * y1 + F[5], c = F[6] * x1 + F[7] * y1 + F[8];
     const double s2 = 1. / (a * a + b * b), d2 = x2 * a + y2 * b + c;
     a = F[0] * x2 + F[3] * y2 + F[6], b = F[1] * x2 + F[4] * y2 + F[7], c = F[2] * x2 + F[5] * y2 + F[8];
@@ -193,6 +203,7 @@ struct FmRng { // cv::RNG
 };
 
 inline bool fm_last_point_collinear(const float *m, int count) { // the count-th point against every pair of earlier ones
+    PV_FM_NO_CONTRACT
     const int i = count - 1;
     for (int j = 0; j < i; ++j) {
         const double dx1 = m[2 * j] - m[2 * i], dy1 = m[2 * j + 1] - m[2 * i + 1];
@@ -227,6 +238,7 @@ inline bool fm_draw_sample(FmRng &rng, int n, const float *p, const float *q, fl
 }
 
 inline int fm_update_iterations(double p, double ep, int model_points, int max_iters) {
+    PV_FM_NO_CONTRACT
     p = p < 0. ? 0. : (p > 1. ? 1. : p), ep = ep < 0. ? 0. : (ep > 1. ? 1. : ep);
     double num = 1. - p > DBL_MIN ? 1. - p : DBL_MIN, denom = 1. - pow(1. - ep, model_points);
     if (denom < DBL_MIN) return 0;

@@ -15,7 +15,7 @@ class DatasetConfig : public Config {
     static std::shared_ptr<DatasetConfig> tum_vi();  // config/tum-vi.yaml
     // constants of a rig given by the caller (tests: rendered sequences), noise parameters as in euroc.yaml
     static std::shared_ptr<DatasetConfig> make(const double K4[4], const double q_bc_xyzw[4], const double p_bc[3], double cov_gyr, double cov_acc,
-                                               double cov_bias_gyr, double cov_bias_acc);
+                                               double cov_bias_gyr, double cov_bias_acc, bool normalize_q = true);
     matrix<3> camera_intrinsic() const override { return K; }
     quaternion camera_to_body_rotation() const override { return q_bc; }
     vector<3> camera_to_body_translation() const override { return p_bc; }

@@ -378,3 +378,26 @@ def make_undistort_maps(width=512, height=512, k1=-0.28, k2=0.07):
     xy = np.stack([iu >> 5, iv >> 5], axis=-1).astype(np.int16)
     frac = ((iv & 31) * 32 + (iu & 31)).astype(np.uint16)
     return xy, frac
+
+
+def permute_landmarks(pb, order):
+    """The same window with its landmarks listed in another order (tests: anchor frames that are NOT sorted; the reference's block order is)."""
+    import copy
+    pb._canon()
+    out = copy.copy(pb)
+    order = np.asarray(order, np.int64)
+    ptr = pb.lm_obs_ptr.astype(np.int64)
+    cnt = (ptr[1:] - ptr[:-1])[order]
+    out.lm_obs_ptr = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32)
+    idx = np.concatenate([np.arange(ptr[l], ptr[l + 1]) for l in order]) if len(order) else np.zeros(0, np.int64)
+    out.lm_anchor_frame = pb.lm_anchor_frame[order].copy()
+    out.lm_anchor_z = pb.lm_anchor_z[order].copy()
+    out.obs_frame = pb.obs_frame[idx].copy()
+    out.obs_z = pb.obs_z[idx].copy()
+    out.lm_inv_depth = pb.lm_inv_depth[order].copy()
+    if pb.lm_multiplicity is not None:
+        out.lm_multiplicity = pb.lm_multiplicity[order].copy()
+    if pb.truth_inv_depth is not None:
+        out.truth_inv_depth = pb.truth_inv_depth[order].copy()
+    out.frame_state = pb.frame_state.copy()
+    return out

@@ -200,6 +200,11 @@ MM_CASES = {
     # N <= 10: the direct part is dealt to the four waves (partial row sets added in wave order at anchor flushes and at the end)
     "vio_4x150_four_wave_direct_part": dict(n_frames=4, n_landmarks=150, use_inertial=True, visibility=3),
     "metric_10x1000_vio_four_wave_direct_part": dict(n_frames=10, n_landmarks=1000, use_inertial=True),
+    # round 6 (ba_lin_tp.h): duplicate residual blocks; 30 frames = two direct tasks per thread, twenty tiles per wave, 16 landmarks per chunk;
+    # a short-visibility window whose chunks hold the full 64 landmarks
+    "vio_duplicate_blocks": ba_compare.CASES["vio_duplicate_blocks"],
+    "vision_30x90_two_direct_tasks_per_thread": dict(n_frames=30, n_landmarks=90, visibility=11),
+    "vio_8x400_full_chunks": dict(n_frames=8, n_landmarks=400, use_inertial=True, visibility=3),
 }
 
 
@@ -214,6 +219,21 @@ def emu_ctx_mm(emu_ctx):
 def test_emulated_mfma_tile_linearization_matches_oracle(emu_ctx_mm, oracle, name):
     pb = ba_compare.make(oracle, **MM_CASES[name])
     ba_compare.check_against_oracle(emu_ctx_mm, oracle, pb)
+
+
+def test_emulated_large_window_role_with_unsorted_anchors_and_a_fixed_frame(emu_ctx_mm, oracle):
+    """ba_lin_tp.h cuts a chunk wherever the anchor frame changes and flushes the (target, anchor) blocks there: a window whose landmarks come in
+    RANDOM anchor order (every chunk a few landmarks, an anchor flush in front of most of them, the same anchor coming back) and one with a fixed
+    frame (constant blocks have no Jacobian) must give what the oracle gives."""
+    import numpy as np
+    from pvio_amd import synth
+    pb = ba_compare.make(oracle, n_frames=7, n_landmarks=150, use_inertial=True, visibility=3)
+    pb2 = synth.permute_landmarks(pb, np.random.default_rng(3).permutation(pb.n_landmarks))
+    assert (np.diff(pb2.lm_anchor_frame) != 0).sum() > 60
+    ba_compare.check_against_oracle(emu_ctx_mm, oracle, pb2)
+    pb3 = ba_compare.make(oracle, n_frames=6, n_landmarks=120, visibility=4)
+    pb3.frame_fixed[2] = 1
+    ba_compare.check_against_oracle(emu_ctx_mm, oracle, pb3)
 
 
 @pytest.mark.parametrize("victim", [0, 2, 5])

@@ -297,6 +297,9 @@ def test_gpu_random_windows_match_oracle(gpu_ctx, oracle, seed):
     print(kw, ba_compare.check_against_oracle(gpu_ctx, oracle, pb))
 
 
+_SWEEP = {"run": 0, "skipped": []}  # windows of the two spread-tolerance sweeps that were run / not compared (decision-boundary windows)
+
+
 @pytest.mark.parametrize("seed", list(range(60)))
 def test_gpu_window_sweep_within_oracle_spread(gpu_ctx, oracle, seed):
     """The 60-window sweep of profiles/r*_sweep_random_windows.txt as a bounded test: 2-32 frames, 10-1500 landmarks,
@@ -306,14 +309,30 @@ def test_gpu_window_sweep_within_oracle_spread(gpu_ctx, oracle, seed):
     kw, pb = ba_compare.sweep_window(oracle, seed)
     r = ba_compare.check_against_oracle_within_spread(gpu_ctx, oracle, pb)
     print(seed, kw, r)
-    assert "skipped" not in r or seed not in (15, 20, 37)  # (the three ill-conditioned windows are not decision-boundary cases)
+    _SWEEP["run"] += 1
+    if "skipped" in r:  # a window that is not compared shows as SKIPPED, is counted, and the count is bounded below
+        assert seed not in (15, 20, 37)  # (the three ill-conditioned windows are not decision-boundary cases)
+        _SWEEP["skipped"].append(("sweep", seed))
+        pytest.skip("window %d: %s" % (seed, r["skipped"]))
 
 
 @pytest.mark.parametrize("case", range(len(ba_compare.TWO_VIEW_CASES)))
 def test_gpu_many_frame_two_view_windows(gpu_ctx, oracle, case):
     """15-31 frames, every landmark seen by exactly two of them, vision only (no gauge): the class the sweep's three outliers belong to"""
     pb = ba_compare.make(oracle, **ba_compare.TWO_VIEW_CASES[case])
-    print(ba_compare.TWO_VIEW_CASES[case], ba_compare.check_against_oracle_within_spread(gpu_ctx, oracle, pb))
+    r = ba_compare.check_against_oracle_within_spread(gpu_ctx, oracle, pb)
+    print(ba_compare.TWO_VIEW_CASES[case], r)
+    _SWEEP["run"] += 1
+    if "skipped" in r:
+        _SWEEP["skipped"].append(("two_view", case))
+        pytest.skip("two-view window %d: %s" % (case, r["skipped"]))
+
+
+def test_gpu_window_sweep_compares_nearly_every_window():
+    """a window on which the oracle's own summation orders disagree about a step's acceptance is skipped, not compared; at most 2
+    of the 66 windows of the two sweeps above may go that way (none does at the time of writing: profiles/r6_pytest_gpu.txt)."""
+    print("windows run %d, skipped %s" % (_SWEEP["run"], _SWEEP["skipped"]))
+    assert len(_SWEEP["skipped"]) <= 2, _SWEEP["skipped"]
 
 
 @pytest.mark.parametrize("poison", [float("nan"), 1e300], ids=["nan", "1e300"])

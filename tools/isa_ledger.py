@@ -55,7 +55,7 @@ def kernel_bodies(source, defines=()):
                 if code.startswith(".Lfunc_end"):  # (a kernel may hold several s_endpgm: its end is the function's end label)
                     break
                 if code:
-                    body.append(code)
+                    body.append(re.sub(r"\.LBB\d+_", ".LBB_", code))  # block labels carry the function's ordinal in the file: a kernel added in front of this one is not a change of this one
                 i += 1
             res[name] = [hashlib.sha256("\n".join(body).encode()).hexdigest(), {"instructions": sum(1 for b in body if not b.endswith(":") and not b.startswith("."))}]
         i += 1
