@@ -9,7 +9,7 @@ size_t linearize_lds_bytes(const Dims &dm);
 size_t dense_lds_bytes(const Dims &dm, int *lds_matrix);
 size_t dense_tile_doubles(const Dims &dm);
 int tiles_per_thread(const Dims &dm);
-int tp_landmark_slots(const Dims &dm); // landmarks per chunk of the large-window landmark role (ba_lin_tp.h)
+int tp_landmark_slots(const Dims &dm, int want); // landmarks per chunk of the large-window landmark role (ba_lin_tp.h); want: the landmarks 256 factors belong to
 hipError_t launch_linearize(const View &v, hipStream_t st);
 hipError_t launch_reduce(const View &v, hipStream_t st, int phase = 0); // phase: see k_reduce
 hipError_t launch_dense(const View &v, hipStream_t st);

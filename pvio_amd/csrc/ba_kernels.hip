@@ -429,25 +429,17 @@ __device__ __forceinline__ void stage_put(double *stage, int n_tasks, int e_lo, 
     double *dst = stage + ((pe.el - e_lo) * n_tasks + pe.t);
     *dst = add ? *dst + val : val;
 }
-__device__ __forceinline__ void partial_add(double *p, double x) { unsafeAtomicAdd(p, x); } // global_atomic_add_f64, no return
 
-// MM = false: every thread keeps T 3x3 tiles of the pose system in registers and adds every landmark's direct and Schur
-//      terms to them (right when a workgroup has a handful of landmarks: no set-up, no flush beyond one store per entry).
-// MM = true:  for workgroups that walk many chunks.  The Schur part  - sum_l w_l u_l u_l^T  is a rank-(#landmarks) update
-//      of a dense P6 x P6 matrix: it runs on the matrix cores (v_mfma_f64_16x16x4_f64, four landmarks per instruction,
-//      the 16x16 tiles of the lower block triangle dealt round-robin to the four waves and kept in accumulator registers
-//      for the whole walk, TW per wave).  The direct part  J^T J  of a factor only touches the target's diagonal block and
-//      the (target, anchor) block: thread 6 f + i keeps row i of both 6x6 blocks for frame f; the (target, anchor) rows
-//      and the anchor's own block are flushed whenever the anchor frame changes (chunks are walked in landmark order,
-//      which the reference's block order makes anchor-sorted).  Everything lands in the same element-major 3x3-task
-//      partial the other mode writes, by no-return FP64 atomics on the workgroup's own zeroed row, in a fixed order.
-template <int T, bool MM, int TW>
+// The landmark role of small and medium windows: every thread keeps T 3x3 tiles of the pose system in registers and adds every landmark's direct
+// and Schur terms to them (right when a workgroup has a handful of landmarks: no set-up, no flush beyond one store per entry); chunks are dealt
+// round-robin to the workgroups.  Large windows (Dims::lm_mm: workgroups that walk many chunks) take role_landmarks_tp (ba_lin_tp.h) instead.
+template <int T>
 __device__ __forceinline__ void role_landmarks(const View &v, double *lds, const Pro *pro, int wg, int n_wg) {
     const int N = v.dm.N, M = v.dm.M, P6 = v.dm.P6, tid = threadIdx.x, n_tasks = v.dm.n_tasks;
     const double *frec = lds + N * 16;
     double *scratch = lds + N * 16 + N * kFrameRec;
     double *chunk = lds + common_lds_doubles(N);
-    const int rec = lm_rec_doubles(N), slots = MM ? (v.dm.lm_slots + 3) & ~3 : v.dm.lm_slots;
+    const int rec = lm_rec_doubles(N), slots = v.dm.lm_slots;
     double *rho_eval = chunk + (size_t)slots * rec; // [slots]
     int *anch = reinterpret_cast<int *>(rho_eval + slots);
     int *active = anch + slots + (slots & 1);
@@ -464,7 +456,7 @@ __device__ __forceinline__ void role_landmarks(const View &v, double *lds, const
 
     int tfi[T], tfj[T], tsi[T], tsj[T];
     double acc[T][9];
-    if constexpr (!MM) {
+    {
 #pragma unroll
         for (int k = 0; k < T; ++k) {
             const int t = k * kLinThreads + tid;
@@ -474,59 +466,16 @@ __device__ __forceinline__ void role_landmarks(const View &v, double *lds, const
             for (int e = 0; e < 9; ++e) acc[k][e] = 0.0;
         }
     }
-    // MM state: accumulator tiles of this wave, operand offsets, direct-term rows of thread 6 f + i
     double *pS = v.part_S + (size_t)wg * n_tasks * 9;
-    const int lane = tid & 63, wv = tid >> 6, lk = lane >> 4, lr = lane & 15;
-    const int nbt = (P6 + 15) >> 4, ntile = (nbt * (nbt + 1)) >> 1;
-    mfma_d4 tacc[TW];
-    int tile_bb[TW]; // bi << 8 | bj of this wave's tiles, -1 past the last tile
-    double Drow[6], Crow[6], aa = 0.0;
-    int cur_anchor = -1;
-    // Direct part (MM): thread `lt` = 6 f + i owns row i of frame f's two 6 x 6 blocks and the pose-vector entries.  P6 <= 64 (N <= 10):
-    // the four waves each hold the whole row set (lt = lane) and take every fourth landmark of a chunk -- one wave walking the landmarks
-    // one after another while three wait was half of the tile phase at 10 x 50 000 -- and the four partial sets are added in wave order
-    // (fixed) at every anchor flush and in front of the final flush.  Otherwise lt = tid as before.
-    const bool split4 = MM && P6 <= 64; // uniform
-    const int lt = split4 ? (tid & 63) : tid;
-    const int myf = lt / 6, myi = lt - 6 * myf;
-    double *xw = chunk + (size_t)slots * rec + slots + 2 * ((slots + 1) / 2) + 4; // [4][64][6] Crow, [4][36] aa (split4 only; linearize_lds_bytes)
-    if constexpr (MM) {
-#pragma unroll
-        for (int u = 0; u < TW; ++u) {
-            const int q = wv + 4 * u;
-            int bi = (int)((sqrtf(8.0f * q + 1.0f) - 1.0f) * 0.5f);
-            while (((bi + 1) * (bi + 2)) >> 1 <= q) ++bi;
-            while (((bi * (bi + 1)) >> 1) > q) --bi;
-            const int bj = q - ((bi * (bi + 1)) >> 1);
-            tile_bb[u] = q < ntile ? (bi << 8 | bj) : -1;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) tacc[u][r] = 0.0;
-        }
-#pragma unroll
-        for (int j = 0; j < 6; ++j) Drow[j] = 0.0, Crow[j] = 0.0;
-    }
-    // (target, anchor) rows and the anchor's own block of the landmarks seen since the last flush -> partial row
-    bool row_dirty = false; // an anchor flush has zeroed the partial row and added to it (uniform)
     double vg = 0, vrhs = 0, vdiag = 0;                         // vector tasks (tid < P6)
     double s_cost = 0, s_g2 = 0, s_step2 = 0, s_norm2 = 0, s_bad = 0, s_bmax = 0; // scalars
 
-    // MM: contiguous chunk range per workgroup; otherwise chunks are dealt round-robin
-    const int per_wg = (v.dm.n_chunks + n_wg - 1) / n_wg;
-    const int ck_begin = MM ? wg * per_wg : wg, ck_stop = ck_begin + per_wg < v.dm.n_chunks ? ck_begin + per_wg : v.dm.n_chunks;
-    const int ck_end = MM ? ck_stop : v.dm.n_chunks, ck_step = MM ? 1 : n_wg;
-    for (int ck = ck_begin; ck < ck_end; ck += ck_step) {
+    for (int ck = wg; ck < v.dm.n_chunks; ck += n_wg) { // chunks are dealt round-robin
         const int l0 = v.chunk_lm[ck], l1 = v.chunk_lm[ck + 1], ns = l1 - l0;
         const int o0 = v.lm_ptr[l0], nf = v.lm_ptr[l1] - o0;
         PV_STAMP(0, 2);
-        // ---- phase 0: clear the chunk records (MM: up to a multiple of four, the K of one MFMA), evaluation-point inverse depths ----
-        if constexpr (MM) { // 16 bytes per store (records are an even number of doubles, the chunk area is 16-byte aligned)
-            lds_d2 z;
-            z[0] = 0.0, z[1] = 0.0;
-            lds_d2 *c2 = reinterpret_cast<lds_d2 *>(chunk);
-            for (int e = tid; e < ((((ns + 3) & ~3) * rec) >> 1); e += kLinThreads) c2[e] = z;
-        } else {
-            for (int e = tid; e < ns * rec; e += kLinThreads) chunk[e] = 0.0;
-        }
+        // ---- phase 0: clear the chunk records, evaluation-point inverse depths ----
+        for (int e = tid; e < ns * rec; e += kLinThreads) chunk[e] = 0.0;
         if (tid < ns) {
             const int l = l0 + tid;
             double r = rho_cur[l];
@@ -595,46 +544,6 @@ __device__ __forceinline__ void role_landmarks(const View &v, double *lds, const
         // ---- phase 1b: per-landmark sums over its factors (50 outputs per landmark) ----
         // every output is sum_f Z[f][p] Z[f][q] + Z[f][p2] Z[f][q2] for an index quadruple that depends only on k:
         // branch-free, two independent accumulators so that the LDS reads of consecutive frames overlap
-        if constexpr (MM) {
-            // The same 50 sums are the Gram matrix of the landmark's factor rows X[(f, rho)] = (Jd, r, Jr[0..5]) of residual
-            // row rho: Hll = G00, bl = G01, Wa = G0,2.., GA = G1,2.., HAA = G2..,2...  One MFMA takes two frames (K = 4 rows)
-            // of TWO landmarks (rows / columns 0-7 and 8-15; the cross blocks are ignored), A and B are the same value.
-            const int c8 = lr & 7, sub = lr >> 3, rho = lk & 1, fo = lk >> 1;
-            const int zoff = 18 * N + (c8 == 0 ? rho : (c8 == 1 ? 2 + rho : 4 + 6 * rho + (c8 - 2)));
-            for (int pr = wv; 2 * pr < ns; pr += 4) {
-                const int so = 2 * pr + sub; // < the cleared slot count
-                const double *Zs = chunk + (size_t)so * rec + zoff;
-                mfma_d4 g, g2;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) g[r] = 0.0, g2[r] = 0.0;
-                for (int f0 = 0; f0 < N; f0 += 8) { // four independent loads, two accumulation chains
-                    double x[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) x[q] = f0 + 2 * q + fo < N ? Zs[16 * (f0 + 2 * q + fo)] : 0.0;
-                    g = __builtin_amdgcn_mfma_f64_16x16x4f64(x[0], x[0], g, 0, 0, 0);
-                    g2 = __builtin_amdgcn_mfma_f64_16x16x4f64(x[1], x[1], g2, 0, 0, 0);
-                    g = __builtin_amdgcn_mfma_f64_16x16x4f64(x[2], x[2], g, 0, 0, 0);
-                    g2 = __builtin_amdgcn_mfma_f64_16x16x4f64(x[3], x[3], g2, 0, 0, 0);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) g[r] += g2[r];
-                if (so < ns) {
-                    double *W = chunk + (size_t)so * rec + 40 * N; // HAA[36] GA[6] SC[4]
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int i = lk + 4 * r, ci = i & 7;
-                        if ((i >> 3) != sub) continue;
-                        if (ci == 0 && c8 == 0) W[42 + 3] = g[r];
-                        else if (ci == 0 && c8 == 1) W[42 + 1] = g[r];
-                        else if (ci == 0) {
-                            o_Wa[(size_t)(l0 + so) * 6 + (c8 - 2)] = g[r];
-                            chunk[(size_t)so * rec + 6 * anch[so] + (c8 - 2)] += g[r];
-                        } else if (ci == 1 && c8 >= 2) W[36 + (c8 - 2)] = g[r];
-                        else if (ci >= 2 && c8 >= 2) W[6 * (ci - 2) + (c8 - 2)] = g[r];
-                    }
-                }
-            }
-        } else
         for (int e = tid; e < ns * 50; e += kLinThreads) {
             const int s = e / 50, k = e - 50 * s;
             int p, q, p2, q2;
@@ -703,96 +612,6 @@ __device__ __forceinline__ void role_landmarks(const View &v, double *lds, const
         // direct-term operand offsets per task (relative to the landmark record); which pair applies depends on the
         // landmark's anchor only:  fi == fj      : Jt(fi)^T Jt(fi)  [+ HAA when the anchor is fi]
         //                          anchor == fj  : Jt(fi)^T Jr(fi)      anchor == fi : Jr(fj)^T Jt(fj)
-        if constexpr (MM) {
-            // Schur part: D_tile(bi, bj) -= sum_s (w_s U_s[16 bi + i]) U_s[16 bj + j], four landmarks per instruction.
-            // Lane l supplies A[l & 15][l >> 4] and B[l >> 4][l & 15]; rows past P6 read the next field of the record
-            // (finite, never flushed), slots past ns were cleared with the chunk.
-            for (int s0 = 0; s0 < ns; s0 += 4) {
-                const double *R = chunk + (size_t)(s0 + lk) * rec;
-                const double nw = -R[40 * N + 42];
-                const double *Rl = R + lr;
-                constexpr int kOps = TW < 6 ? TW : 6; // operands of a batch are all requested before its first MFMA
-#pragma unroll
-                for (int u0 = 0; u0 < TW; u0 += kOps) {
-                    double a_op[kOps], b_op[kOps];
-#pragma unroll
-                    for (int u = 0; u < kOps; ++u) {
-                        const int bb = u0 + u < TW ? tile_bb[u0 + u < TW ? u0 + u : 0] : -1;
-                        a_op[u] = Rl[bb >= 0 ? (bb >> 8) << 4 : 0], b_op[u] = Rl[bb >= 0 ? (bb & 255) << 4 : 0];
-                    }
-#pragma unroll
-                    for (int u = 0; u < kOps; ++u)
-                        if (u0 + u < TW && tile_bb[u0 + u < TW ? u0 + u : 0] >= 0) // wave-uniform
-                            tacc[u0 + u] = __builtin_amdgcn_mfma_f64_16x16x4f64(nw * a_op[u], b_op[u], tacc[u0 + u], 0, 0, 0);
-                }
-            }
-            // direct part + pose vectors, one landmark at a time (anchor changes are uniform across the workgroup)
-            for (int s = 0; s < ns; ++s) {
-                const double *R = chunk + (size_t)s * rec;
-                const double *HAA = R + 40 * N, *SC = HAA + 42;
-                const int a = anch[s];
-                if (a != cur_anchor) { // uniform
-                    if (cur_anchor >= 0) {
-                        // (target, anchor) rows and the anchor's own block of the landmarks seen since the last flush go
-                        // to the partial row by atomics: the first time the row is zeroed for them
-                        if (!row_dirty) {
-                            for (int e = tid; e < n_tasks * 9; e += kLinThreads) pS[e] = 0.0;
-                            // the workgroup's own stores, atomics and later loads of the row all meet in this XCD's L2: a
-                            // workgroup-scope fence (wait for the stores) orders them; __threadfence() would write the whole
-                            // L2 back (agent scope), tens of microseconds with the W rows of this launch in it
-                            __threadfence_block();
-                            __syncthreads();
-                            row_dirty = true;
-                        }
-                        if (split4) { // the four waves' (target, anchor) rows and anchor blocks -> wave 0, in wave order
-                            const int wq = tid >> 6, lq = tid & 63;
-#pragma unroll
-                            for (int j = 0; j < 6; ++j) xw[(wq * 64 + lq) * 6 + j] = Crow[j];
-                            if (lq < 36) xw[4 * 64 * 6 + wq * 36 + lq] = aa;
-                            __syncthreads();
-#pragma unroll
-                            for (int j = 0; j < 6; ++j)
-                                Crow[j] = wq == 0 ? ((xw[lq * 6 + j] + xw[(64 + lq) * 6 + j]) + xw[(128 + lq) * 6 + j]) + xw[(192 + lq) * 6 + j] : 0.0;
-                            aa = (wq == 0 && lq < 36) ? ((xw[4 * 64 * 6 + lq] + xw[4 * 64 * 6 + 36 + lq]) + xw[4 * 64 * 6 + 72 + lq]) + xw[4 * 64 * 6 + 108 + lq] : 0.0;
-                            __syncthreads();
-                        }
-                        if (tid < P6 && myf != cur_anchor) {
-#pragma unroll
-                            for (int j = 0; j < 6; ++j) {
-                                const PartialEntry pe = partial_entry(N, myf, myi, cur_anchor, j);
-                                if (Crow[j] != 0.0) partial_add(pS + pe.el * n_tasks + pe.t, Crow[j]);
-                                Crow[j] = 0.0;
-                            }
-                        }
-                        if (tid < 36) {
-                            const PartialEntry pe = partial_entry(N, cur_anchor, tid / 6, cur_anchor, tid % 6);
-                            partial_add(pS + pe.el * n_tasks + pe.t, aa);
-                            aa = 0.0;
-                        }
-                    }
-                    cur_anchor = a;
-                }
-                const bool mine = !split4 || (s & 3) == (tid >> 6);
-                if (lt < P6 && mine) {
-                    // (records, field offsets and 12 f / 16 f + 4 are even: 16-byte loads)
-                    const double *JTs = R + 6 * N + 12 * myf;
-                    const lds_d2 *JT2 = reinterpret_cast<const lds_d2 *>(JTs), *JR2 = reinterpret_cast<const lds_d2 *>(R + 18 * N + 16 * myf + 4);
-                    const double x0 = JTs[myi], x1 = JTs[6 + myi];
-                    lds_d2 t0[3], t1[3], q0[3], q1[3];
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) t0[j] = JT2[j], t1[j] = JT2[3 + j], q0[j] = JR2[j], q1[j] = JR2[3 + j];
-#pragma unroll
-                    for (int j = 0; j < 6; ++j) {
-                        Drow[j] += x0 * t0[j >> 1][j & 1] + x1 * t1[j >> 1][j & 1];
-                        Crow[j] += x0 * q0[j >> 1][j & 1] + x1 * q1[j >> 1][j & 1];
-                    }
-                    vg += R[34 * N + lt] + (a == myf ? HAA[36 + myi] : 0.0);
-                    vrhs += SC[0] * SC[1] * R[lt];
-                    vdiag += x0 * x0 + x1 * x1 + (a == myf ? HAA[7 * myi] : 0.0);
-                }
-                if (lt < 36 && mine) aa += HAA[lt];
-            }
-        } else
         for (int s = 0; s < ns; ++s) {
             const double *R = chunk + (size_t)s * rec;
             const double *U = R, *HAA = R + 40 * N, *SC = HAA + 42;
@@ -834,82 +653,7 @@ __device__ __forceinline__ void role_landmarks(const View &v, double *lds, const
         PV_STAMP(0, 7);
     }
     // ---- flush this WG's partial ----
-    if constexpr (MM) {
-        // The accumulators are laid out for the matrix cores, the partial row for the 3x3 tasks: the transposition goes
-        // through LDS (the chunk records are dead now), five of the nine task elements at a time, so that the row itself is
-        // written by coalesced sweeps.  The tiles only carry the lower triangle: the upper halves of the diagonal frame
-        // blocks hold the direct terms alone, no consumer reads them (the stage is cleared first for those entries).
-        // Fixed order per entry: tile entry (at most one per entry),
-        // then the diagonal / (target, anchor) rows (disjoint blocks), then the last anchor's own block, then what earlier
-        // anchor flushes (if any) left in the row.
-        double *stage = chunk;
-        if (split4) { // the four waves' row sets and pose-vector entries -> wave 0, in wave order (the chunk area is free)
-            const int wq = tid >> 6, lq = tid & 63;
-            double *xs = chunk + (size_t)(wq * 64 + lq) * 16;
-#pragma unroll
-            for (int j = 0; j < 6; ++j) xs[j] = Drow[j], xs[6 + j] = Crow[j];
-            xs[12] = vg, xs[13] = vrhs, xs[14] = vdiag, xs[15] = aa;
-            __syncthreads();
-            const double *x0s = chunk + (size_t)lq * 16, *x1s = x0s + 64 * 16, *x2s = x1s + 64 * 16, *x3s = x2s + 64 * 16;
-            if (wq == 0) {
-#pragma unroll
-                for (int j = 0; j < 6; ++j) Drow[j] = ((x0s[j] + x1s[j]) + x2s[j]) + x3s[j], Crow[j] = ((x0s[6 + j] + x1s[6 + j]) + x2s[6 + j]) + x3s[6 + j];
-                vg = ((x0s[12] + x1s[12]) + x2s[12]) + x3s[12], vrhs = ((x0s[13] + x1s[13]) + x2s[13]) + x3s[13];
-                vdiag = ((x0s[14] + x1s[14]) + x2s[14]) + x3s[14], aa = ((x0s[15] + x1s[15]) + x2s[15]) + x3s[15];
-            }
-            __syncthreads(); // (the stage is cleared next)
-        }
-        for (int h = 0; h < 2; ++h) {
-            const int e_lo = 5 * h, e_n = h == 0 ? 5 : 4;
-
-            __syncthreads();
-            for (int e = tid; e < e_n * n_tasks; e += kLinThreads) stage[e] = 0.0;
-            __syncthreads();
-#pragma unroll
-            for (int u = 0; u < TW; ++u) {
-                if (tile_bb[u] < 0) continue;
-                const int I0 = ((tile_bb[u] >> 8) << 4) + lk, J = ((tile_bb[u] & 255) << 4) + lr; // this lane owns rows I0 + 4 r of column J of the tile
-                const int fJ = J / 6, jJ = J - 6 * fJ;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int I = I0 + 4 * r;
-                    if (I >= P6 || J > I) continue;
-                    const int fI = I / 6, iI = I - 6 * fI;
-                    stage_put(stage, n_tasks, e_lo, e_n, partial_entry(N, fI, iI, fJ, jJ), tacc[u][r], false);
-                }
-            }
-            __syncthreads();
-            if (h == 0) PV_STAMP(0, 14);
-            if (tid < P6) {
-#pragma unroll
-                for (int j = 0; j < 6; ++j) {
-                    stage_put(stage, n_tasks, e_lo, e_n, partial_entry(N, myf, myi, myf, j), Drow[j], true);
-                    if (cur_anchor >= 0 && myf != cur_anchor) stage_put(stage, n_tasks, e_lo, e_n, partial_entry(N, myf, myi, cur_anchor, j), Crow[j], true);
-                }
-            }
-            __syncthreads();
-            if (tid < 36 && cur_anchor >= 0) stage_put(stage, n_tasks, e_lo, e_n, partial_entry(N, cur_anchor, tid / 6, cur_anchor, tid % 6), aa, true);
-            if (row_dirty) __threadfence_block(); // earlier anchor flushes have landed before the row is read
-            __syncthreads();
-            if (h == 0) PV_STAMP(0, 15);
-            double *dstrow = pS + (size_t)e_lo * n_tasks;
-            const int n_el = e_n * n_tasks;
-            if (!row_dirty) {
-                for (int e = tid; e < n_el; e += kLinThreads) dstrow[e] = stage[e];
-            } else {
-                for (int e0 = tid; e0 < n_el; e0 += 8 * kLinThreads) { // eight row values in flight per thread
-                    double old[8];
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) old[q] = e0 + q * kLinThreads < n_el ? dstrow[e0 + q * kLinThreads] : 0.0;
-#pragma unroll
-                    for (int q = 0; q < 8; ++q)
-                        if (e0 + q * kLinThreads < n_el) dstrow[e0 + q * kLinThreads] = old[q] + stage[e0 + q * kLinThreads];
-                }
-            }
-            if (h == 0) PV_STAMP(0, 16);
-        }
-        PV_STAMP(0, 17);
-    } else {
+    {
 #pragma unroll
         for (int k = 0; k < T; ++k) {
             const int t = k * kLinThreads + tid;
@@ -932,6 +676,12 @@ __device__ __forceinline__ void role_landmarks(const View &v, double *lds, const
 }
 
 #include "ba_lin_tp.h" // role_landmarks_tp: the landmark role of large windows (Dims::lm_mm)
+
+#if defined(__clang__)
+#define PV_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n, n))) // register budget of a kernel: 512 / n per wave
+#else
+#define PV_WAVES_PER_EU(n) // (the emulator's host compiler)
+#endif
 
 // ---- plane-distance factors: one thread per factor, rows staged in LDS, same tile machinery (sign +) ----
 template <int T>
@@ -1145,10 +895,14 @@ __device__ __forceinline__ void zero_partial_row(const View &v, int row) {
 }
 
 // MFMA accumulator tiles per wave for the window sizes a tile count T stands for (T = 1: N <= 10 ... T = 9: N <= 32)
-template <int T> struct TilesPerWave { static constexpr int value = T <= 1 ? 3 : (T <= 2 ? 6 : (T <= 4 ? 12 : (T <= 6 ? 17 : 20))); };
+// (large windows, ba_lin_tp.h: the tiles cover 6 N + 1 columns -- b_l rides along as column 6 N -- i.e. 13 block rows = 91 tiles at N = 32)
+template <int T> struct TilesPerWave { static constexpr int value = T <= 1 ? 3 : (T <= 2 ? 6 : (T <= 4 ? 12 : (T <= 6 ? 17 : 23))); };
 
-template <int T, bool MM>
-__global__ void __launch_bounds__(kLinThreads) k_linearize(View v) {
+// MM (large windows, Dims::lm_mm): the landmark workgroups run role_landmarks_tp (ba_lin_tp.h); up to 15 frames the kernel is held to 256 registers so
+// that two workgroups share a CU when their LDS allows it (tp_landmark_slots: 80 KB each) -- the phases of one overlap the latencies of the other
+// TW: accumulator tiles per wave of the large-window role (23 only for 32 frames: 91 tiles; 28 .. 31 frames need 66 .. 78)
+template <int T, bool MM, int TW = TilesPerWave<T>::value>
+__global__ void __launch_bounds__(kLinThreads) PV_WAVES_PER_EU((MM && T <= 2) ? 2 : 1) k_linearize(View v) {
     HIP_DYNAMIC_SHARED(double, lds)
     PV_STAMP_BEGIN(0);
     PV_STAMP(0, 0);
@@ -1185,8 +939,8 @@ __global__ void __launch_bounds__(kLinThreads) k_linearize(View v) {
     const int b = bx < naux ? g1 + bx : (bx < naux + v.dm.G_plane ? g0 + (bx - naux) : bx - naux - v.dm.G_plane);
     if (v.dbg && v.dbg_sel < 0 && threadIdx.x == 0 && (b == g1 || b == g2)) v.dbg[b == g1 ? 10 : 12] = clock64(); // first IMU / prior workgroup (absolute)
     if (b < g0) {
-        if constexpr (MM) role_landmarks_tp<TilesPerWave<T>::value, (T >= 9 ? 2 : 1)>(v, lds, pro, b, g0);
-        else role_landmarks<T, false, 1>(v, lds, pro, b, g0);
+        if constexpr (MM) role_landmarks_tp<TW, (T >= 6 ? 2 : 1)>(v, lds, pro, b, g0);
+        else role_landmarks<T>(v, lds, pro, b, g0);
     }
     else if (b < g1) {
         if (pro->mode != MODE_MARG) role_planes<T>(v, lds, pro, b - g0, v.dm.G_plane, b);
@@ -3465,12 +3219,17 @@ __global__ void __launch_bounds__(256) k_prior_prep(const double *S, const doubl
 // ------------------------------------------------------------------------------------------------------
 // host-side launchers
 // ------------------------------------------------------------------------------------------------------
-// landmarks per chunk of the large-window role (ba_lin_tp.h): as many U rows as fit beside the factor rows in 150 KB of LDS, a multiple of
-// four (the K of one MFMA), at most 64
-int tp_landmark_slots(const Dims &dm) {
-    const size_t common = (size_t)(dm.N * 16 + dm.N * kFrameRec + 160 + 16), budget = 150 * 1024 / sizeof(double);
+// landmarks per chunk of the large-window role (ba_lin_tp.h): a multiple of four (the K of one MFMA), at most 64.  Two workgroups per CU (80 KB of LDS
+// each: the phases of one overlap the latencies of the other) when that leaves room for the landmarks 256 factors belong to (`want`); else what fits in
+// 150 KB
+int tp_landmark_slots(const Dims &dm, int want) {
+    const size_t common = (size_t)(dm.N * 16 + dm.N * kFrameRec + 160 + 16);
+    auto fits = [&](int s, size_t bytes) { return (common + tp_lds_doubles(dm.N, dm.P6, s, dm.n_tasks)) * sizeof(double) <= bytes; };
+    const int up = std::min(64, std::max(4, (want + 3) & ~3)), down = std::min(64, std::max(4, want & ~3));
+    if (fits(up, 80 * 1024)) return up;
+    if (fits(down, 80 * 1024)) return down; // (10 frames seen by all: 28 landmarks = 252 factors per chunk)
     int s = 64;
-    while (s > 4 && common + tp_lds_doubles(dm.N, dm.P6, s, dm.n_tasks) > budget) s -= 4;
+    while (s > 4 && !fits(s, 150 * 1024)) s -= 4;
     return s;
 }
 
@@ -3479,9 +3238,9 @@ size_t linearize_lds_bytes(const Dims &dm) {
     size_t common = (size_t)(N * 16 + N * kFrameRec + 160 + 16);
     const size_t slots = (size_t)dm.lm_slots;
     size_t lm = dm.lm_mm ? tp_lds_doubles(N, dm.P6, (dm.lm_slots + 3) & ~3, dm.n_tasks) : slots * (40 * N + 46) + slots + 2 * ((slots + 1) / 2) + 4;
-    size_t pl = (size_t)dm.plane_slots * (dm.P6 + 2);
-    size_t pre = 16 + 450 + 450 + 16 + 225;
-    size_t pri = (size_t)dm.prior_n * (15 + 9) + 40;
+    size_t pl = dm.n_plane > 0 ? (size_t)dm.plane_slots * (dm.P6 + 2) : 0; // (a role without workgroups needs no room)
+    size_t pre = dm.use_inertial ? 16 + 450 + 450 + 16 + 225 : 0;
+    size_t pri = dm.prior_n > 0 ? (size_t)dm.prior_n * (15 + 9) + 40 : 0;
     size_t role = lm;
     if (pl > role) role = pl;
     if (pre > role) role = pre;
@@ -3491,22 +3250,27 @@ size_t linearize_lds_bytes(const Dims &dm) {
 
 int tiles_per_thread(const Dims &dm) { return (dm.n_tasks + kLinThreads - 1) / kLinThreads; }
 
-template <int T, bool MM>
+template <int T, bool MM, int TW = TilesPerWave<T>::value>
 static hipError_t launch_lin_TM(const View &v, hipStream_t st) {
     const int grid = v.dm.G_lm + v.dm.G_plane + v.dm.G_pre + v.dm.G_prior;
     const size_t lds = linearize_lds_bytes(v.dm);
     static size_t configured = 0;
     if (lds > configured) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_linearize<T, MM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_linearize<T, MM, TW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         configured = lds;
     }
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_linearize<T, MM>), dim3(grid), dim3(kLinThreads), lds, st, v);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_linearize<T, MM, TW>), dim3(grid), dim3(kLinThreads), lds, st, v);
     return hipGetLastError();
 }
 template <int T>
 static hipError_t launch_lin_T(const View &v, hipStream_t st) {
-    return v.dm.lm_mm ? launch_lin_TM<T, true>(v, st) : launch_lin_TM<T, false>(v, st);
+    if (!v.dm.lm_mm) return launch_lin_TM<T, false>(v, st);
+    if (tp_tiles(v.dm.P6) > 4 * TilesPerWave<T>::value) return hipErrorInvalidValue; // (cannot happen: see TilesPerWave)
+    if constexpr (T == 9) {
+        if (tp_tiles(v.dm.P6) <= 80) return launch_lin_TM<9, true, 20>(v, st); // 28 .. 31 frames
+    }
+    return launch_lin_TM<T, true>(v, st);
 }
 
 hipError_t launch_linearize(const View &v, hipStream_t st) {

@@ -7,38 +7,26 @@
 //
 //   E  evaluate     one thread per factor (reprojection_error_cost.h:40-120 through pv_factors.h): the factor's row X = [Jt | Jr | r | Jd] goes to LDS as 14
 //                   (row 0, row 1) pairs, its Schur row W_t = Jd^T Jt to the landmark's dense U row (LDS) and to HBM (k_backsub reads it)
-//   D  direct part  J^T J of a factor only touches the target's diagonal block, the (target, anchor) block and the target's gradient: 9 N thread tasks
-//                   (target t, 3 x 3 block b), each walking the chunk's factors of ITS target in a fixed order (a per-chunk permutation by target, built by
-//                   the host at upload) with the 9 sums in registers for the WHOLE chunk range of the workgroup; small N: several threads per task
-//   L  per landmark H_ll, b_l, W_a, Jr^T r, Jr^T Jr are the Gram matrix of the landmark's factor rows [Jd r Jr]: v_mfma_f64_16x16x4_f64, two landmarks per
-//                   instruction, two factors per K step (contiguous rows: no per-frame slots, nothing to clear)
-//   P  scalars      Jacobi scale, dogleg diagonal, Schur weight; W_a completes the U row; the per-landmark outputs k_backsub needs
+//   D  direct part  J^T J of a factor only touches the target's diagonal block, the (target, anchor) block, the anchor's own block and the two gradients.
+//                   Thread tasks (target t, 3 x 3 block b) walk the chunk's factors of THEIR target in a fixed order (a per-chunk permutation by target, built
+//                   by the host at upload), tasks (anchor block b) walk all of the chunk's factors; the 9 sums of a task stay in registers for the WHOLE chunk
+//                   range of the workgroup; the threads left over split every task into subs
+//   L  per landmark H_ll, b_l, W_a = Jd^T [Jd r Jr] over the landmark's (contiguous) factor rows: thread = (landmark, column)
+//   P  scalars      Jacobi scale, dogleg diagonal, Schur weight; W_a and b_l complete the U row; the per-landmark outputs k_backsub needs
 //   S  Schur        - sum_l w_l u_l u_l^T as a SYRK on the matrix cores, 16 x 16 tiles of the lower block triangle in accumulator registers for the whole
-//                   walk (as before); the anchor's own block and the right-hand side by a few threads beside it; the NEXT chunk's landmark inputs are
-//                   fetched and the other U buffer is cleared here, so a chunk passes four barriers
-//   flush           once per workgroup (and at an anchor change): accumulators -> the element-major 3 x 3-task partial row the other form writes
+//                   walk; b_l rides along as column 6 N of the U row, so the row 6 N of the product is the Schur right-hand side
+//   A chunk passes four barriers; the inputs of chunk k + 1 (factor and landmark arrays: two dependent trips to HBM) are requested while chunk k is in D .. S.
+//   flush           once per workgroup (and at an anchor change): accumulators -> the element-major 3 x 3-task partial row the other form writes, through a
+//                   scatter table of the tile entries built at upload
 //
 // Sums are taken in fixed orders (no floating-point atomics): re-solves are bit-identical.
 //
-// LDS after the common part (doubles):  X [256][28] | U [2][S][US] | LMR [S][50] | DS (direct sums at a flush) | small per-chunk tables
+// LDS after the common part (doubles):  X [256][28] | U [2][S][US] | LMR [S][8] | small per-chunk tables; a flush reuses X .. LMR as its stage
 #pragma once
 
-constexpr int kTpXCols = 14;   // (row 0, row 1) pairs of a factor row: 0-5 Jt, 6-11 Jr, 12 r, 13 Jd
-constexpr int kTpLmr = 50;     // per-landmark results: HAA[36] GA[6] | 42 w  43 bl  44..49 Wa
-constexpr int kTpDirTasks = 9; // per target: TT00 TT01 TT11 | TR00 TR01 TR10 TR11 | g[0:3] g[3:6]
+// (the LDS geometry -- kTpXCols, tp_u_stride, tp_lds_doubles ... -- is in ba_types.h: the host sizes chunks and the launch with it)
 
-__host__ __device__ inline int tp_u_stride(int P6) { return ((P6 + 15) >> 4) << 4; }
-// doubles of LDS the role needs behind the common part
-__host__ __device__ inline size_t tp_lds_doubles(int N, int P6, int slots, int n_tasks) {
-    const size_t S = (size_t)slots, US = (size_t)tp_u_stride(P6);
-    size_t work = (size_t)kLinThreads * 2 * kTpXCols + 2 * S * US + S * kTpLmr;
-    const size_t stage = (size_t)n_tasks * 5 + (size_t)kTpDirTasks * N * 9 + 64; // the final flush reuses the work area: stage halves + direct sums
-    if (work < stage) work = stage;
-    // tables: rho_eval[2][S] | accumulators vg_acc[P6] vdiag_acc[P6] | ints: active[2][S], fptr[2][S + 1], tptr[kMaxFrames + 1], perm[256]
-    return work + 2 * S + 2 * (size_t)P6 + (2 * S + 2 * (S + 1) + (kMaxFrames + 1) + kLinThreads + 8) / 2 + 8;
-}
-
-template <int TW, int NDT> // TW: accumulator tiles per wave; NDT: direct tasks per thread (2 when 9 N > 256)
+template <int TW, int NDT> // TW: accumulator tiles per wave; NDT: direct tasks per thread
 __device__ __forceinline__ void role_landmarks_tp(const View &v, double *lds, const Pro *pro, int wg, int n_wg) {
     const int N = v.dm.N, M = v.dm.M, P6 = v.dm.P6, tid = threadIdx.x, n_tasks = v.dm.n_tasks;
     const int lane = tid & 63, wv = tid >> 6, lk = lane >> 4, lr = lane & 15;
@@ -48,19 +36,17 @@ __device__ __forceinline__ void role_landmarks_tp(const View &v, double *lds, co
     // ---- LDS carve ----
     double *work = lds + common_lds_doubles(N);
     lds_d2 *X2 = reinterpret_cast<lds_d2 *>(work);               // [256][14]
-    double *Ubuf = work + (size_t)kLinThreads * 2 * kTpXCols;    // [2][S][US]
-    double *LMR = Ubuf + 2 * (size_t)S * US;                     // [S][50]
-    size_t work_sz = (size_t)kLinThreads * 2 * kTpXCols + 2 * (size_t)S * US + (size_t)S * kTpLmr;
-    {
-        const size_t stage_sz = (size_t)n_tasks * 5 + (size_t)kTpDirTasks * N * 9 + 64;
-        if (work_sz < stage_sz) work_sz = stage_sz;
-    }
-    double *rho_eval = work + work_sz;                           // [2][S]
-    double *vg_acc = rho_eval + 2 * S, *vdiag_acc = vg_acc + P6; // [P6] each: what anchor flushes have taken out of the registers
-    int *active = reinterpret_cast<int *>(vdiag_acc + P6);       // [2][S]
-    int *fptr = active + 2 * S;                                  // [2][S + 1] first factor (chunk-relative) of every slot
-    int *tptr = fptr + 2 * (S + 1);                              // [N + 1] chunk-relative offsets of the by-target permutation
-    int *perm = tptr + kMaxFrames + 1;                           // [256] factor slots sorted by target
+    double *U = work + (size_t)kLinThreads * 2 * kTpXCols;       // [S][US]: every cell of a chunk's rows is written by E / P, nothing is cleared per chunk
+    double *LMR = U + (size_t)S * US;                            // [S][8]
+    const size_t work_sz = tp_work_doubles(N, P6, S, n_tasks);
+    double *rho_e = work + work_sz;                              // [S]
+    double *cl_tab = rho_e + S;                                  // [S]
+    double *vg_acc = cl_tab + S, *vdiag_acc = vg_acc + P6;       // [P6] each: what anchor flushes have taken out of the registers
+    int *act_e = reinterpret_cast<int *>(vdiag_acc + P6);        // [S]
+    int *seen_e = act_e + S;                                     // [S] frames the landmark is observed in
+    int *fp = seen_e + S;                                        // [S + 1] first factor (chunk-relative) of every slot
+    int *tptr = fp + S + 1;                                      // [N + 1] chunk-relative offsets of the by-target permutation
+    uint8_t *perm = reinterpret_cast<uint8_t *>(tptr + kMaxFrames + 1); // [256] factor slots sorted by target
 
     const int mode = pro->mode, cur = pro->cur, lin = pro->lin, oset = pro->out_set;
     const bool marg = mode == MODE_MARG;
@@ -74,8 +60,8 @@ __device__ __forceinline__ void role_landmarks_tp(const View &v, double *lds, co
     double *rho_cand = v.rho + (1 - cur) * Ms;
     double *pS = v.part_S + (size_t)wg * n_tasks * 9;
 
-    // ---- Schur tiles of this wave (lower block triangle, dealt round-robin to the four waves) ----
-    const int nbt = (P6 + 15) >> 4, ntile = (nbt * (nbt + 1)) >> 1;
+    // ---- Schur tiles of this wave (lower block triangle of the (6 N + 1)-column system, dealt round-robin to the four waves) ----
+    const int nbt = US >> 4, ntile = (nbt * (nbt + 1)) >> 1;
     mfma_d4 tacc[TW];
     int tile_bb[TW]; // bi << 8 | bj, -1 past the last tile
 #pragma unroll
@@ -89,27 +75,37 @@ __device__ __forceinline__ void role_landmarks_tp(const View &v, double *lds, co
 #pragma unroll
         for (int r = 0; r < 4; ++r) tacc[u][r] = 0.0;
     }
-    // ---- direct tasks of this thread: (target, block) x sub; task index = block * N + target (threads of a wave mostly share the block) ----
+    // ---- direct tasks: unified list [target tasks x nsub | anchor tasks x nsubA], thread tid owns entries tid + 256 q ----
     const int n_dir = kTpDirTasks * N;
-    const int nsub = NDT > 1 ? 1 : (kLinThreads / n_dir > 0 ? kLinThreads / n_dir : 1);
-    int d_t[NDT], d_a[NDT], d_b[NDT], d_bs[NDT], d_blk[NDT]; // target, first A column, first B column, B column step, block
-    const int d_sub = tid % nsub;
+    const int nsub = (NDT * kLinThreads - 4 * kTpAnchTasks) / n_dir > 0 ? (NDT * kLinThreads - 4 * kTpAnchTasks) / n_dir : 1;
+    const int nsubA = (NDT * kLinThreads - n_dir * nsub) / kTpAnchTasks; // >= 4 for N <= 32 (9 N + 20 <= 512)
+    int d_kind[NDT], d_t[NDT], d_a[NDT], d_b[NDT], d_bs[NDT], d_blk[NDT], d_sub[NDT]; // -1 idle / 0 target / 1 anchor; target; first A column, first B column, its step; block; sub
     double dacc[NDT][9];
 #pragma unroll
     for (int q = 0; q < NDT; ++q) {
-        const int task = tid / nsub + q * kLinThreads;
-        const bool on = task < n_dir;
-        const int b = on ? task / N : 0;
-        d_t[q] = on ? task - b * N : -1, d_blk[q] = b;
-        // TT00 TT01 TT11 TR00 TR01 TR10 TR11 g0 g1
-        d_a[q] = (b == 0 || b == 1 || b == 3 || b == 4 || b == 7) ? 0 : 3;
-        d_b[q] = b == 0 ? 0 : (b == 1 || b == 2) ? 3 : (b == 3 || b == 5) ? 6 : (b == 4 || b == 6) ? 9 : 12;
-        d_bs[q] = b >= 7 ? 0 : 1;
+        const int u = tid + q * kLinThreads, ua = u - n_dir * nsub;
+        int b;
+        if (u < n_dir * nsub) {
+            const int task = u / nsub;
+            b = task / N;
+            d_kind[q] = 0, d_t[q] = task - b * N, d_blk[q] = b, d_sub[q] = u - task * nsub;
+            // TT00 TT01 TT11 TR00 TR01 TR10 TR11 g0 g1
+            d_a[q] = (b == 0 || b == 1 || b == 3 || b == 4 || b == 7) ? 0 : 3;
+            d_b[q] = b == 0 ? 0 : (b == 1 || b == 2) ? 3 : (b == 3 || b == 5) ? 6 : (b == 4 || b == 6) ? 9 : 12;
+            d_bs[q] = b >= 7 ? 0 : 1;
+        } else if (ua < kTpAnchTasks * nsubA) {
+            b = ua / nsubA;
+            d_kind[q] = 1, d_t[q] = -1, d_blk[q] = b, d_sub[q] = ua - b * nsubA;
+            // RR00 RR01 RR11 gR0 gR1
+            d_a[q] = (b == 0 || b == 1 || b == 3) ? 6 : 9;
+            d_b[q] = b == 0 ? 6 : (b == 1 || b == 2) ? 9 : 12;
+            d_bs[q] = b >= 3 ? 0 : 1;
+        } else {
+            d_kind[q] = -1, d_t[q] = -1, d_blk[q] = 0, d_sub[q] = 0, d_a[q] = 0, d_b[q] = 0, d_bs[q] = 0;
+        }
 #pragma unroll
         for (int e = 0; e < 9; ++e) dacc[q][e] = 0.0;
     }
-    double aa = 0.0;                       // tid in [64, 64 + 42): the anchor's own block HAA (36) and Jr^T r (6) of the landmarks since the last flush
-    double vrhs = 0.0;                     // tid < P6
     double s_cost = 0, s_g2 = 0, s_step2 = 0, s_norm2 = 0, s_bad = 0, s_bmax = 0;
     int cur_anchor = -1;
     bool row_dirty = false;
@@ -118,38 +114,95 @@ __device__ __forceinline__ void role_landmarks_tp(const View &v, double *lds, co
     const int per_wg = (v.dm.n_chunks + n_wg - 1) / n_wg;
     const int ck_begin = wg * per_wg, ck_end = ck_begin + per_wg < v.dm.n_chunks ? ck_begin + per_wg : v.dm.n_chunks;
 
-    // landmark inputs of chunk ck -> tables of parity (ck & 1); candidate inverse depths, |step|^2, |x|^2 (threads tid < ns)
-    auto prep = [&](int ck) {
-        const int l0 = v.chunk_lm[ck], ns = v.chunk_lm[ck + 1] - l0, par = ck & 1;
+    // ---- inputs of a chunk, requested one chunk ahead: factor arrays (thread = factor) and landmark arrays (thread = landmark) ----
+    int f_l = 0, f_t = 0, f_perm = 0;
+    double f_z0 = 0, f_z1 = 0, f_zr0 = 0, f_zr1 = 0;
+    double p_rho = 0, p_cl = 1, p_gh = 0, p_gn = 0, p_D = 1;
+    int p_p0 = 0, p_p1 = 0, p_anchor = 0;
+    uint32_t p_seen = 0;
+    auto request = [&](int ck) { // independent loads
+        const int l0 = v.chunk_lm[ck], ns = v.chunk_lm[ck + 1] - l0;
+        const int o0 = v.lm_ptr[l0], nf = v.lm_ptr[l0 + ns] - o0;
+        if (tid < nf) {
+            const size_t o = (size_t)o0 + tid;
+            f_l = v.obs_lm[o], f_t = v.obs_frame[o], f_perm = v.chunk_perm[o], f_z0 = v.obs_z[2 * o], f_z1 = v.obs_z[2 * o + 1];
+        }
         if (tid < ns) {
             const int l = l0 + tid;
-            double r = rho_cur[l];
-            const int p0 = v.lm_ptr[l], p1 = v.lm_ptr[l + 1];
-            const bool used = p1 > p0;
+            p_rho = rho_cur[l], p_p0 = v.lm_ptr[l], p_p1 = v.lm_ptr[l + 1], p_seen = v.lm_seen[l];
+            if (mode != MODE_INIT && !marg) p_cl = v.cl[l];
+            if (mode == MODE_CANDIDATE) p_gh = i_ghl[l], p_gn = i_gnl[l], p_D = i_Dl[l];
+            if (marg) p_anchor = v.lm_anchor[l];
+        }
+    };
+    auto request2 = [&](int ck) { // loads that depend on the first ones
+        const int l0 = v.chunk_lm[ck], ns = v.chunk_lm[ck + 1] - l0;
+        const int nf = v.lm_ptr[l0 + ns] - v.lm_ptr[l0];
+        if (tid < nf) f_zr0 = v.lm_zref[2 * (size_t)f_l], f_zr1 = v.lm_zref[2 * (size_t)f_l + 1];
+    };
+    // landmark inputs of chunk ck -> the tables (single-buffered: written in phase S of the chunk before, when nothing reads them any more);
+    // candidate inverse depths, |step|^2, |x|^2 (threads tid < ns)
+    auto prep = [&](int ck) {
+        const int l0 = v.chunk_lm[ck], ns = v.chunk_lm[ck + 1] - l0;
+        if (tid < ns) {
+            const int l = l0 + tid;
+            double r = p_rho;
+            const bool used = p_p1 > p_p0;
             if (mode == MODE_CANDIDATE && used) {
-                const double dl = v.cl[l] * (ca * i_ghl[l] + cb * i_gnl[l]) / i_Dl[l];
+                const double dl = p_cl * (ca * p_gh + cb * p_gn) / p_D;
                 const double rc = r + dl;
                 s_step2 += (rc - r) * (rc - r);
                 r = rc;
             }
             if (mode == MODE_CANDIDATE) rho_cand[l] = r;
             if (used) s_norm2 += r * r;
-            rho_eval[par * S + tid] = r;
+            rho_e[tid] = r;
+            cl_tab[tid] = p_cl;
             int act = 1;
             if (marg) { // bundle_adjustor.cpp:455-461: only tracks the victim frame observes
-                act = v.lm_anchor[l] == victim;
-                for (int o = p0; o < p1; ++o) act |= v.obs_frame[o] == victim;
+                act = p_anchor == victim;
+                for (int o = p_p0; o < p_p1; ++o) act |= v.obs_frame[o] == victim;
             }
-            active[par * S + tid] = act;
-            fptr[par * (S + 1) + tid] = p0 - v.lm_ptr[l0];
-            if (tid == ns - 1) fptr[par * (S + 1) + ns] = p1 - v.lm_ptr[l0];
+            act_e[tid] = act;
+            seen_e[tid] = (int)p_seen;
+            fp[tid] = p_p0 - v.lm_ptr[l0];
+            if (tid == ns - 1) fp[ns] = p_p1 - v.lm_ptr[l0];
         }
     };
-    auto clear_u = [&](int par) {
-        lds_d2 z;
-        z[0] = 0.0, z[1] = 0.0;
-        lds_d2 *u2 = reinterpret_cast<lds_d2 *>(Ubuf + (size_t)par * S * US);
-        for (int e = tid; e < ((S * US) >> 1); e += kLinThreads) u2[e] = z;
+    // sums of a task's subs -> every thread of the task, through LDS (work area: X is free between chunks), in sub order
+    auto sum_subs = [&](bool only_anchor_bound) {
+        double *DS = work; // [NDT * 256][9]
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < NDT; ++q)
+            if (d_kind[q] >= 0) {
+                double *dst = DS + (size_t)(tid + q * kLinThreads) * 9;
+#pragma unroll
+                for (int e = 0; e < 9; ++e) dst[e] = dacc[q][e];
+            }
+        __syncthreads();
+        if (!only_anchor_bound) PV_STAMP(0, 20);
+#pragma unroll
+        for (int q = 0; q < NDT; ++q) {
+            const bool bound = d_kind[q] == 1 || (d_kind[q] == 0 && d_blk[q] >= 3 && d_blk[q] <= 6); // the sums that belong to the current anchor
+            if (d_kind[q] >= 0 && d_sub[q] == 0 && (bound || !only_anchor_bound)) {
+                const int step = d_kind[q] == 0 ? nsub : nsubA;
+                const double *src = DS + (size_t)(tid + q * kLinThreads) * 9;
+                double sum[9]; // (sub by sub, the nine loads of a sub in flight together: element by element is `step` dependent LDS round trips each)
+#pragma unroll
+                for (int e = 0; e < 9; ++e) sum[e] = src[e];
+                for (int u = 1; u < step; ++u) {
+#pragma unroll
+                    for (int e = 0; e < 9; ++e) sum[e] += src[u * 9 + e];
+                }
+#pragma unroll
+                for (int e = 0; e < 9; ++e) dacc[q][e] = sum[e];
+            } else if (d_kind[q] >= 0 && (bound || !only_anchor_bound)) {
+#pragma unroll
+                for (int e = 0; e < 9; ++e) dacc[q][e] = 0.0;
+            }
+        }
+        __syncthreads();
     };
     // The (target, anchor) blocks and the anchor's own block belong to ONE anchor: when it changes they leave the registers.  The workgroup's partial
     // row is zeroed the first time (row_dirty) and every entry has one writer per flush (the subs of a task are summed through LDS first): plain
@@ -160,56 +213,60 @@ __device__ __forceinline__ void role_landmarks_tp(const View &v, double *lds, co
             __threadfence_block();
             row_dirty = true;
         }
-        double *DS = work; // [n_dir][nsub][9] -- X is free between chunks
-        __syncthreads();
+        sum_subs(true);
+        const int A = cur_anchor;
 #pragma unroll
-        for (int q = 0; q < NDT; ++q)
-            if (d_t[q] >= 0 && d_blk[q] >= 3 && d_blk[q] <= 6) {
-                double *dst = DS + ((size_t)(d_blk[q] * N + d_t[q]) * nsub + d_sub) * 9;
-#pragma unroll
-                for (int e = 0; e < 9; ++e) dst[e] = dacc[q][e], dacc[q][e] = 0.0;
-            }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < NDT; ++q)
-            if (d_t[q] >= 0 && d_blk[q] >= 3 && d_blk[q] <= 6 && d_sub == 0 && d_t[q] != cur_anchor) {
-                const double *src = DS + (size_t)(d_blk[q] * N + d_t[q]) * nsub * 9;
+        for (int q = 0; q < NDT; ++q) {
+            if (d_kind[q] == 0 && d_blk[q] >= 3 && d_blk[q] <= 6 && d_sub[q] == 0 && d_t[q] != A) {
                 const int bi = (d_blk[q] - 3) >> 1, bj = (d_blk[q] - 3) & 1;
 #pragma unroll
                 for (int e = 0; e < 9; ++e) {
-                    double sum = src[e];
-                    for (int u = 1; u < nsub; ++u) sum += src[u * 9 + e];
-                    const PartialEntry pe = partial_entry(N, d_t[q], 3 * bi + e / 3, cur_anchor, 3 * bj + e % 3);
-                    if (sum != 0.0) pS[pe.el * n_tasks + pe.t] += sum;
+                    const PartialEntry pe = partial_entry(N, d_t[q], 3 * bi + e / 3, A, 3 * bj + e % 3);
+                    if (dacc[q][e] != 0.0) pS[pe.el * n_tasks + pe.t] += dacc[q][e];
                 }
             }
-        if (tid >= 64 && tid < 64 + 36) {
-            const int e = tid - 64;
-            const PartialEntry pe = partial_entry(N, cur_anchor, e / 6, cur_anchor, e % 6);
-            pS[pe.el * n_tasks + pe.t] += aa;
-            if (e / 6 == e % 6) vdiag_acc[6 * cur_anchor + e / 6] += aa;
-            aa = 0.0;
-        } else if (tid >= 64 + 36 && tid < 64 + 42) {
-            vg_acc[6 * cur_anchor + (tid - 64 - 36)] += aa;
-            aa = 0.0;
+            if (d_kind[q] == 1 && d_sub[q] == 0) {
+                const int b = d_blk[q];
+#pragma unroll
+                for (int e = 0; e < 9; ++e) {
+                    const int i = e / 3, j = e % 3;
+                    const double val = dacc[q][e];
+                    if (b == 0 || b == 2) {
+                        const int o3 = b == 0 ? 0 : 3;
+                        const PartialEntry pe = partial_entry(N, A, o3 + i, A, o3 + j);
+                        pS[pe.el * n_tasks + pe.t] += val;
+                        if (i == j) vdiag_acc[6 * A + o3 + i] += val;
+                    } else if (b == 1) {
+                        const PartialEntry pe = partial_entry(N, A, i, A, 3 + j), pt = partial_entry(N, A, 3 + j, A, i);
+                        pS[pe.el * n_tasks + pe.t] += val, pS[pt.el * n_tasks + pt.t] += val;
+                    } else if (j == 0) vg_acc[6 * A + 3 * (b - 3) + i] += val;
+                }
+            }
+            if (d_kind[q] == 1 || (d_kind[q] == 0 && d_blk[q] >= 3 && d_blk[q] <= 6)) {
+#pragma unroll
+                for (int e = 0; e < 9; ++e) dacc[q][e] = 0.0;
+            }
         }
         __threadfence_block();
         __syncthreads();
     };
 
     if (ck_begin < ck_end) {
+        request(ck_begin);
+        request2(ck_begin);
         prep(ck_begin);
-        clear_u(ck_begin & 1);
+    }
+    {   // the U rows once: the columns behind 6 N + 1 stay zero for the whole walk
+        lds_d2 z;
+        z[0] = 0.0, z[1] = 0.0;
+        lds_d2 *u2 = reinterpret_cast<lds_d2 *>(U);
+        for (int e = tid; e < ((S * US) >> 1); e += kLinThreads) u2[e] = z;
     }
     __syncthreads();
     for (int ck = ck_begin; ck < ck_end; ++ck) {
-        const int par = ck & 1;
         const int l0 = v.chunk_lm[ck], ns = v.chunk_lm[ck + 1] - l0;
         const int o0 = v.lm_ptr[l0], nf = v.lm_ptr[l0 + ns] - o0;
         const int a = v.lm_anchor[l0]; // the chunk's anchor (the host cuts chunks at anchor changes)
-        double *U = Ubuf + (size_t)par * S * US;
-        const double *rho_e = rho_eval + par * S;
-        const int *act_e = active + par * S, *fp = fptr + par * (S + 1);
         if (a != cur_anchor) { // uniform
             if (cur_anchor >= 0) anchor_flush();
             cur_anchor = a;
@@ -218,11 +275,10 @@ __device__ __forceinline__ void role_landmarks_tp(const View &v, double *lds, co
         // ---- E: one thread per factor ----
         if (tid <= N) tptr[tid] = v.chunk_tptr[(size_t)ck * (N + 1) + tid];
         if (tid < nf) {
-            const int o = o0 + tid, l = v.obs_lm[o], s = l - l0, t = v.obs_frame[o];
-            perm[tid] = v.chunk_perm[o];
+            const int o = o0 + tid, l = f_l, s = l - l0, t = f_t;
+            perm[tid] = (uint8_t)f_perm;
             double r[2], Jt[12], Jr[12], Jd[2];
-            reproj_eval<true>(frec + t * kFrameRec, frec + a * kFrameRec, rho_e[s], v.lm_zref[2 * l], v.lm_zref[2 * l + 1],
-                              v.obs_z[2 * (size_t)o], v.obs_z[2 * (size_t)o + 1], r, Jt, Jr, Jd);
+            reproj_eval<true>(frec + t * kFrameRec, frec + a * kFrameRec, rho_e[s], f_zr0, f_zr1, f_z0, f_z1, r, Jt, Jr, Jd);
             const bool act = act_e[s] != 0;
             const double sq = r[0] * r[0] + r[1] * r[1];
             // duplicate residual blocks (bundle_adjustor.cpp:165-179): m copies of the block, each robustified on its own, summed by
@@ -265,16 +321,31 @@ __device__ __forceinline__ void role_landmarks_tp(const View &v, double *lds, co
                 o_Wt[(size_t)o * 6 + k] = wt;
             }
         }
+        if (ck + 1 < ck_end) request(ck + 1); // (in flight through D .. P)
         __syncthreads();
         PV_STAMP(0, 3);
-        // ---- D: direct part, thread = (target, 3 x 3 block, sub) ----
+        // ---- D: direct part, thread = (target or anchor task, sub); two factors per pass so that their loads are in flight together ----
 #pragma unroll
         for (int q = 0; q < NDT; ++q)
-            if (d_t[q] >= 0) {
-                const int e0 = tptr[d_t[q]], e1 = tptr[d_t[q] + 1];
+            if (d_kind[q] >= 0) {
+                const bool tgt = d_kind[q] == 0;
+                const int e0 = tgt ? tptr[d_t[q]] : 0, e1 = tgt ? tptr[d_t[q] + 1] : nf, step = tgt ? nsub : nsubA;
                 const int ao = d_a[q], bo = d_b[q], bs = d_bs[q];
-                for (int i = e0 + d_sub; i < e1; i += nsub) {
-                    const lds_d2 *x = X2 + (size_t)perm[i] * kTpXCols;
+                int i = e0 + d_sub[q];
+                for (; i + step < e1; i += 2 * step) {
+                    const int fA = tgt ? perm[i] : i, fB = tgt ? perm[i + step] : i + step;
+                    const lds_d2 *x = X2 + (size_t)fA * kTpXCols, *y = X2 + (size_t)fB * kTpXCols;
+                    const lds_d2 a0 = x[ao], a1 = x[ao + 1], a2 = x[ao + 2], b0 = x[bo], b1 = x[bo + bs], b2 = x[bo + 2 * bs];
+                    const lds_d2 c0 = y[ao], c1 = y[ao + 1], c2 = y[ao + 2], d0 = y[bo], d1 = y[bo + bs], d2 = y[bo + 2 * bs];
+                    dacc[q][0] += a0[0] * b0[0] + a0[1] * b0[1], dacc[q][1] += a0[0] * b1[0] + a0[1] * b1[1], dacc[q][2] += a0[0] * b2[0] + a0[1] * b2[1];
+                    dacc[q][3] += a1[0] * b0[0] + a1[1] * b0[1], dacc[q][4] += a1[0] * b1[0] + a1[1] * b1[1], dacc[q][5] += a1[0] * b2[0] + a1[1] * b2[1];
+                    dacc[q][6] += a2[0] * b0[0] + a2[1] * b0[1], dacc[q][7] += a2[0] * b1[0] + a2[1] * b1[1], dacc[q][8] += a2[0] * b2[0] + a2[1] * b2[1];
+                    dacc[q][0] += c0[0] * d0[0] + c0[1] * d0[1], dacc[q][1] += c0[0] * d1[0] + c0[1] * d1[1], dacc[q][2] += c0[0] * d2[0] + c0[1] * d2[1];
+                    dacc[q][3] += c1[0] * d0[0] + c1[1] * d0[1], dacc[q][4] += c1[0] * d1[0] + c1[1] * d1[1], dacc[q][5] += c1[0] * d2[0] + c1[1] * d2[1];
+                    dacc[q][6] += c2[0] * d0[0] + c2[1] * d0[1], dacc[q][7] += c2[0] * d1[0] + c2[1] * d1[1], dacc[q][8] += c2[0] * d2[0] + c2[1] * d2[1];
+                }
+                if (i < e1) {
+                    const lds_d2 *x = X2 + (size_t)(tgt ? perm[i] : i) * kTpXCols;
                     const lds_d2 a0 = x[ao], a1 = x[ao + 1], a2 = x[ao + 2], b0 = x[bo], b1 = x[bo + bs], b2 = x[bo + 2 * bs];
                     dacc[q][0] += a0[0] * b0[0] + a0[1] * b0[1], dacc[q][1] += a0[0] * b1[0] + a0[1] * b1[1], dacc[q][2] += a0[0] * b2[0] + a0[1] * b2[1];
                     dacc[q][3] += a1[0] * b0[0] + a1[1] * b0[1], dacc[q][4] += a1[0] * b1[0] + a1[1] * b1[1], dacc[q][5] += a1[0] * b2[0] + a1[1] * b2[1];
@@ -282,50 +353,31 @@ __device__ __forceinline__ void role_landmarks_tp(const View &v, double *lds, co
                 }
             }
         PV_STAMP(0, 4);
-        // ---- L: per-landmark Gram matrix of the factor rows [Jd r Jr0..5] (two residual rows each) on the matrix cores ----
-        {
-            // lane (c8 = lr & 7, sub = lr >> 3, k = lk): column c8 of landmark 2 pr + sub, residual row k & 1 of the factor 2 step + (k >> 1)
-            const int c8 = lr & 7, sub = lr >> 3, rho = lk & 1, fo = lk >> 1;
-            const int col = c8 == 0 ? 13 : (c8 == 1 ? 12 : 4 + c8);
-            for (int pr = wv; 2 * pr < ns; pr += 4) {
-                const int so = 2 * pr + sub;
-                const int f0 = so < ns ? fp[so] : 0, cnt = so < ns ? fp[so + 1] - f0 : 0;
-                const int sA = 2 * pr, cntA = fp[sA + 1] - fp[sA], cntB = sA + 1 < ns ? fp[sA + 2] - fp[sA + 1] : 0;
-                const int cmax = cntA > cntB ? cntA : cntB; // uniform
-                const double *xs = reinterpret_cast<const double *>(X2 + (size_t)f0 * kTpXCols + col) + rho;
-                mfma_d4 g, g2;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) g[r] = 0.0, g2[r] = 0.0;
-                for (int kf = 0; kf < cmax; kf += 4) { // two independent accumulation chains
-                    const double x0 = kf + fo < cnt ? xs[(size_t)(kf + fo) * 2 * kTpXCols] : 0.0;
-                    const double x1 = kf + 2 + fo < cnt ? xs[(size_t)(kf + 2 + fo) * 2 * kTpXCols] : 0.0;
-                    g = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, g, 0, 0, 0);
-                    g2 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x1, g2, 0, 0, 0);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) g[r] += g2[r];
-                if (so < ns) {
-                    double *W = LMR + (size_t)so * kTpLmr;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int i = lk + 4 * r, ci = i & 7;
-                        if ((i >> 3) != sub) continue;
-                        if (ci == 0 && c8 == 0) W[42] = g[r];                       // Hll (the scalar phase turns it into the Schur weight)
-                        else if (ci == 0 && c8 == 1) W[43] = g[r];                  // bl
-                        else if (ci == 0) W[44 + (c8 - 2)] = g[r];                  // Wa
-                        else if (ci == 1 && c8 >= 2) W[36 + (c8 - 2)] = g[r];       // GA = Jr^T r
-                        else if (ci >= 2 && c8 >= 2) W[6 * (ci - 2) + (c8 - 2)] = g[r]; // HAA
-                    }
-                }
+        // ---- L: H_ll, b_l, W_a = Jd^T [Jd r Jr] over the landmark's factor rows; thread = (slot, column) ----
+        for (int s = tid >> 3; s < ns; s += kLinThreads >> 3) {
+            const int c = tid & 7, col = c == 0 ? 13 : (c == 1 ? 12 : 4 + c);
+            const int f0 = fp[s], f1 = fp[s + 1];
+            double s0 = 0.0, s1 = 0.0;
+            int f = f0;
+            for (; f + 1 < f1; f += 2) {
+                const lds_d2 *x = X2 + (size_t)f * kTpXCols;
+                const lds_d2 jd0 = x[13], y0 = x[col], jd1 = x[kTpXCols + 13], y1 = x[kTpXCols + col];
+                s0 += jd0[0] * y0[0] + jd0[1] * y0[1], s1 += jd1[0] * y1[0] + jd1[1] * y1[1];
             }
+            if (f < f1) {
+                const lds_d2 *x = X2 + (size_t)f * kTpXCols;
+                const lds_d2 jd0 = x[13], y0 = x[col];
+                s0 += jd0[0] * y0[0] + jd0[1] * y0[1];
+            }
+            LMR[(size_t)s * kTpLmr + c] = s0 + s1;
         }
         __syncthreads();
         PV_STAMP(0, 5);
-        // ---- P: per-landmark scalars: Jacobi scale, dogleg diagonal, Schur weight; W_a completes the U row ----
+        // ---- P: per-landmark scalars: Jacobi scale, dogleg diagonal, Schur weight; W_a and b_l complete the U row ----
         if (tid < ns) {
             const int l = l0 + tid;
             double *W = LMR + (size_t)tid * kTpLmr;
-            const double Hll = W[42], b = W[43];
+            const double Hll = W[0], b = W[1];
             const bool used = fp[tid + 1] > fp[tid];
             double cl;
             if (marg) {
@@ -334,7 +386,7 @@ __device__ __forceinline__ void role_landmarks_tp(const View &v, double *lds, co
                 cl = used ? 1.0 / (1.0 + sqrt(Hll)) : 1.0; // jacobi_scaling, computed once (iteration 0)
                 v.cl[l] = cl;
             } else {
-                cl = v.cl[l];
+                cl = cl_tab[tid];
             }
             const double d2 = cl * cl * Hll;
             const double Dl = sqrt(fmin(fmax(d2, 1e-6), 1e32)); // DoglegStrategy diagonal (min/max_lm_diagonal)
@@ -345,26 +397,38 @@ __device__ __forceinline__ void role_landmarks_tp(const View &v, double *lds, co
                 const double inv = 1.0 / Hll;
                 w = (act_e[tid] && isfinite(inv)) ? inv : 0.0;
             }
-            W[42] = w;
+            W[0] = w;
             o_Hll[l] = Hll, o_bl[l] = b, o_Dl[l] = Dl, o_ghl[l] = used ? gh : 0.0;
             if (used) {
                 s_g2 += gh * gh;
                 s_bmax = fmax(s_bmax, fabs(b));
             }
-            double *Us = U + (size_t)tid * US + 6 * a;
+            double *Us = U + (size_t)tid * US;
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
-                const double wa = W[44 + k];
-                Us[k] = wa; // the anchor is never a target of its own landmark
+                const double wa = W[2 + k];
+                Us[6 * a + k] = wa; // the anchor is never a target of its own landmark
                 o_Wa[(size_t)l * 6 + k] = wa;
             }
+            Us[P6] = b; // row 6 N of the SYRK below: - sum_l w_l b_l u_l = - the Schur right-hand side
+            // the blocks of the frames that do not see the landmark: whatever the last chunk left there
+            const unsigned unseen = ~((unsigned)seen_e[tid] | (1u << a));
+            for (int f = 0; f < N; ++f)
+                if ((unseen >> f) & 1u) {
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) Us[6 * f + k] = 0.0;
+                }
+        } else if (tid < ((ns + 3) & ~3)) { // rows that pad the chunk to the K of an MFMA: zero (their weight is read as 0, but 0 x NaN is not 0)
+            double *Us = U + (size_t)tid * US;
+            for (int k = 0; k <= P6; ++k) Us[k] = 0.0;
         }
+        if (ck + 1 < ck_end) request2(ck + 1);
         __syncthreads();
         PV_STAMP(0, 6);
-        // ---- S: Schur complement on the matrix cores; beside it the right-hand side, the anchor's own block, the next chunk's inputs ----
+        // ---- S: Schur complement on the matrix cores; beside it the next chunk's landmark tables and the other U buffer's clear ----
         for (int s0 = 0; s0 < ns; s0 += 4) {
-            const int row = s0 + lk; // rows past ns are zero (the buffer was cleared), their weight is read as 0
-            const double nw = row < ns ? -LMR[(size_t)row * kTpLmr + 42] : 0.0;
+            const int row = s0 + lk; // rows past ns are zero (phase P), their weight is read as 0
+            const double nw = row < ns ? -LMR[(size_t)row * kTpLmr] : 0.0;
             const double *Rl = U + (size_t)row * US + lr;
             constexpr int kOps = TW < 6 ? TW : 6; // operands of a batch are all requested before its first MFMA
 #pragma unroll
@@ -381,22 +445,7 @@ __device__ __forceinline__ void role_landmarks_tp(const View &v, double *lds, co
                         tacc[u0 + u] = __builtin_amdgcn_mfma_f64_16x16x4f64(nw * a_op[u], b_op[u], tacc[u0 + u], 0, 0, 0);
             }
         }
-        if (tid < P6) {
-            double sum = 0.0;
-            for (int s = 0; s < ns; ++s) {
-                const double *W = LMR + (size_t)s * kTpLmr;
-                sum += W[42] * W[43] * U[(size_t)s * US + tid];
-            }
-            vrhs += sum;
-        }
-        if (tid >= 64 && tid < 64 + 42) {
-            const int e = tid - 64;
-            double sum = 0.0;
-            for (int s = 0; s < ns; ++s) sum += LMR[(size_t)s * kTpLmr + e];
-            aa += sum;
-        }
         if (ck + 1 < ck_end) prep(ck + 1);
-        clear_u(1 - par);
         __syncthreads();
         PV_STAMP(0, 7);
     }
@@ -404,87 +453,107 @@ __device__ __forceinline__ void role_landmarks_tp(const View &v, double *lds, co
     // ---- flush: accumulators -> the workgroup's partial row (element-major 3 x 3 tasks), pose vectors, scalars ----
     // order per entry: tile entry (set), then the direct blocks (disjoint entries), then the last anchor's own block, then what earlier anchor
     // flushes left in the row
-    double *stage = work;                                   // [5][n_tasks]
-    double *DS = work + (size_t)n_tasks * 5;                // [n_dir][9] direct sums (subs added in order)
-    {
-        // subs of a task -> sub 0, through DS laid out [task][sub][9] in the stage area first (free: the chunk walk is over)
-        double *tmp = work;
-        __syncthreads();
+    // (the scatter table of this wave's tiles is requested first: it comes from HBM)
+    int tdst[TW][4];
 #pragma unroll
-        for (int q = 0; q < NDT; ++q)
-            if (d_t[q] >= 0) {
-                double *dst = tmp + ((size_t)(d_blk[q] * N + d_t[q]) * nsub + d_sub) * 9;
+    for (int u = 0; u < TW; ++u) {
+        const int32_t *dp = v.tp_tile_dst + ((size_t)(wv + 4 * u < ntile ? wv + 4 * u : 0) * 64 + lane) * 4;
 #pragma unroll
-                for (int e = 0; e < 9; ++e) dst[e] = dacc[q][e];
-            }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < NDT; ++q)
-            if (d_t[q] >= 0 && d_sub == 0) {
-                const double *src = tmp + (size_t)(d_blk[q] * N + d_t[q]) * nsub * 9;
-#pragma unroll
-                for (int e = 0; e < 9; ++e) {
-                    double sum = src[e];
-                    for (int u = 1; u < nsub; ++u) sum += src[u * 9 + e];
-                    dacc[q][e] = sum;
-                }
-            }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < NDT; ++q)
-            if (d_t[q] >= 0 && d_sub == 0) {
-                double *dst = DS + (size_t)(d_blk[q] * N + d_t[q]) * 9;
-#pragma unroll
-                for (int e = 0; e < 9; ++e) dst[e] = dacc[q][e];
-            }
-        __syncthreads();
+        for (int r = 0; r < 4; ++r) tdst[u][r] = tile_bb[u] >= 0 ? dp[r] : -1;
     }
-    // pose vectors: g_dir = Jt^T r of the targets + Jr^T r of the anchors; rhs_schur; diag of the direct H
-    double aa_keep = aa; // (threads 64 .. 64 + 41)
-    if (tid >= 64 + 36 && tid < 64 + 42 && cur_anchor >= 0) vg_acc[6 * cur_anchor + (tid - 64 - 36)] += aa;
-    if (tid >= 64 && tid < 64 + 36 && cur_anchor >= 0 && (tid - 64) / 6 == (tid - 64) % 6) vdiag_acc[6 * cur_anchor + (tid - 64) / 6] += aa;
+    PV_STAMP(0, 18);
+    sum_subs(false); // every task's sums in its sub 0
+    PV_STAMP(0, 19);
+    double *DS = work;                                      // [NDT * 256][9] sums of the tasks (sub 0 entries are read)
+#pragma unroll
+    for (int q = 0; q < NDT; ++q)
+        if (d_kind[q] >= 0 && d_sub[q] == 0) {
+            double *dst = DS + (size_t)(tid + q * kLinThreads) * 9;
+#pragma unroll
+            for (int e = 0; e < 9; ++e) dst[e] = dacc[q][e];
+        }
     __syncthreads();
+    PV_STAMP(0, 14);
+    // where the sums of target task (t, b) / anchor task b sit in DS
+    auto ds_target = [&](int t, int b) { return DS + (size_t)((b * N + t) * nsub) * 9; };
+    auto ds_anchor = [&](int b) { return DS + (size_t)(n_dir * nsub + b * nsubA) * 9; };
+    // the last anchor's gradient and diagonal join what the anchor flushes collected
+    if (cur_anchor >= 0 && tid < 6) {
+        vg_acc[6 * cur_anchor + tid] += ds_anchor(3 + tid / 3)[3 * (tid % 3)];
+        vdiag_acc[6 * cur_anchor + tid] += ds_anchor(tid < 3 ? 0 : 2)[4 * (tid % 3)];
+    }
+    __syncthreads();
+    double *pv = v.part_vec + (size_t)wg * kNumPoseVec * P6;
     if (tid < P6) {
         const int t = tid / 6, i = tid - 6 * t;
-        const double g_t = DS[(size_t)((7 + i / 3) * N + t) * 9 + 3 * (i % 3)];
-        const double d_tt = DS[(size_t)((i < 3 ? 0 : 2) * N + t) * 9 + 4 * (i % 3)];
-        double *pv = v.part_vec + (size_t)wg * kNumPoseVec * P6;
-        pv[tid] = g_t + vg_acc[tid], pv[P6 + tid] = vrhs, pv[2 * P6 + tid] = d_tt + vdiag_acc[tid];
+        const double g_t = ds_target(t, 7 + i / 3)[3 * (i % 3)];
+        const double d_tt = ds_target(t, i < 3 ? 0 : 2)[4 * (i % 3)];
+        pv[tid] = g_t + vg_acc[tid], pv[2 * P6 + tid] = d_tt + vdiag_acc[tid];
     }
-    for (int h = 0; h < 2; ++h) {
-        const int e_lo = 5 * h, e_n = h == 0 ? 5 : 4;
+    // the Schur right-hand side: row 6 N of the tiles of the last block row
+#pragma unroll
+    for (int u = 0; u < TW; ++u) {
+        if (tile_bb[u] < 0 || (tile_bb[u] >> 8) != nbt - 1) continue;
+        const int I0 = ((tile_bb[u] >> 8) << 4) + lk, J = ((tile_bb[u] & 255) << 4) + lr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (I0 + 4 * r == P6 && J < P6) pv[P6 + J] = -tacc[u][r];
+    }
+    double *stage = work + (size_t)NDT * kLinThreads * 9;   // [els][n_tasks]: as many elements of the partial row per pass as fit
+    const int cap = (int)((work_sz - (size_t)NDT * kLinThreads * 9) / (size_t)n_tasks);
+    const int els = cap >= 9 ? 9 : cap; // >= 2 (tp_work_doubles)
+    for (int e_lo = 0; e_lo < 9; e_lo += els) {
+        const int e_n = e_lo + els <= 9 ? els : 9 - e_lo;
         __syncthreads();
         for (int e = tid; e < e_n * n_tasks; e += kLinThreads) stage[e] = 0.0;
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < TW; ++u) {
             if (tile_bb[u] < 0) continue;
-            const int I0 = ((tile_bb[u] >> 8) << 4) + lk, J = ((tile_bb[u] & 255) << 4) + lr; // this lane owns rows I0 + 4 r of column J of the tile
-            const int fJ = J / 6, jJ = J - 6 * fJ;
+            // scatter table of the tile's entries (built at upload): el << 24 | task, -1 for entries nothing reads
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int I = I0 + 4 * r;
-                if (I >= P6 || J > I) continue;
-                const int fI = I / 6, iI = I - 6 * fI;
-                stage_put(stage, n_tasks, e_lo, e_n, partial_entry(N, fI, iI, fJ, jJ), tacc[u][r], false);
+                const int el = tdst[u][r] >> 24, t = tdst[u][r] & 0xffffff;
+                if (tdst[u][r] >= 0 && el >= e_lo && el < e_lo + e_n) stage[(el - e_lo) * n_tasks + t] = tacc[u][r];
             }
         }
         __syncthreads();
-        // direct blocks: one thread per (task, element); the entries of different tasks are disjoint
-        for (int e = tid; e < n_dir * 9; e += kLinThreads) {
-            const int task = e / 9, el = e - 9 * task, b = task / N, t = task - b * N, i = el / 3, j = el - 3 * i;
-            const double val = DS[e];
-            if (b == 0) stage_put(stage, n_tasks, e_lo, e_n, partial_entry(N, t, i, t, j), val, true);
-            else if (b == 1) {
-                stage_put(stage, n_tasks, e_lo, e_n, partial_entry(N, t, i, t, 3 + j), val, true);
-                stage_put(stage, n_tasks, e_lo, e_n, partial_entry(N, t, 3 + j, t, i), val, true);
-            } else if (b == 2) stage_put(stage, n_tasks, e_lo, e_n, partial_entry(N, t, 3 + i, t, 3 + j), val, true);
-            else if (b <= 6) {
-                if (cur_anchor >= 0 && t != cur_anchor) stage_put(stage, n_tasks, e_lo, e_n, partial_entry(N, t, 3 * ((b - 3) >> 1) + i, cur_anchor, 3 * ((b - 3) & 1) + j), val, true);
+        if (e_lo == 0) PV_STAMP(0, 15);
+        // direct blocks, from the registers of every target task's sub 0 (the entries of different tasks are disjoint): a 3 x 3 block is ONE task of the
+        // partial row (its nine elements lie n_tasks apart), stored as it is or transposed
+#pragma unroll
+        for (int q = 0; q < NDT; ++q)
+            if (d_kind[q] == 0 && d_sub[q] == 0 && d_blk[q] < 7) {
+                const int b = d_blk[q], t = d_t[q], A = cur_anchor;
+                int tA, tB = -1;
+                bool trA = false;
+                if (b <= 2) { // the target's own block: (0, 0) / (0, 1) and its mirror (1, 0) / (1, 1)
+                    tA = task_index(N, t, t, b == 2, b >= 1);
+                    if (b == 1) tB = task_index(N, t, t, 1, 0);
+                } else { // (target, anchor): filed under the smaller frame
+                    const int bi = (b - 3) >> 1, bj = (b - 3) & 1;
+                    trA = t > A;
+                    tA = (A < 0 || t == A) ? -1 : (trA ? task_index(N, A, t, bj, bi) : task_index(N, t, A, bi, bj));
+                }
+#pragma unroll
+                for (int e = 0; e < 9; ++e) {
+                    const int eT = 3 * (e % 3) + e / 3, elA = trA ? eT : e;
+                    if (tA >= 0 && elA >= e_lo && elA < e_lo + e_n) stage[(elA - e_lo) * n_tasks + tA] += dacc[q][e];
+                    if (tB >= 0 && eT >= e_lo && eT < e_lo + e_n) stage[(eT - e_lo) * n_tasks + tB] += dacc[q][e];
+                }
+            }
+        __syncthreads();
+        if (e_lo == 0) PV_STAMP(0, 16);
+        if (tid < 27 && cur_anchor >= 0) { // the last anchor's own block
+            const int b = tid / 9, el = tid - 9 * b, i = el / 3, j = el - 3 * i, A = cur_anchor;
+            const double val = ds_anchor(b)[el];
+            if (b == 0) stage_put(stage, n_tasks, e_lo, e_n, partial_entry(N, A, i, A, j), val, true);
+            else if (b == 2) stage_put(stage, n_tasks, e_lo, e_n, partial_entry(N, A, 3 + i, A, 3 + j), val, true);
+            else {
+                stage_put(stage, n_tasks, e_lo, e_n, partial_entry(N, A, i, A, 3 + j), val, true);
+                stage_put(stage, n_tasks, e_lo, e_n, partial_entry(N, A, 3 + j, A, i), val, true);
             }
         }
-        __syncthreads();
-        if (tid >= 64 && tid < 64 + 36 && cur_anchor >= 0) stage_put(stage, n_tasks, e_lo, e_n, partial_entry(N, cur_anchor, (tid - 64) / 6, cur_anchor, (tid - 64) % 6), aa_keep, true);
         if (row_dirty) __threadfence_block(); // earlier anchor flushes have landed before the row is read
         __syncthreads();
         double *dstrow = pS + (size_t)e_lo * n_tasks;
@@ -501,6 +570,7 @@ __device__ __forceinline__ void role_landmarks_tp(const View &v, double *lds, co
                     if (e0 + q * kLinThreads < n_el) dstrow[e0 + q * kLinThreads] = old[q] + stage[e0 + q * kLinThreads];
             }
         }
+        if (e_lo == 0) PV_STAMP(0, 17);
     }
     double sc[6] = {s_cost, s_g2, s_step2, s_norm2, s_bad, s_bmax};
     block_sum<6, true>(sc, scratch);

@@ -149,6 +149,7 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st, bool ma
     // ---- block usage (Ceres removes constant and unreferenced parameter blocks from the reduced program) ----
     std::vector<uint8_t> pose_used(N, 0), motion_used(N, 0), pose_active(N, 0), motion_active(N, 0), pre_valid(N, 0);
     std::vector<int32_t> obs_lm(F, 0);
+    std::vector<uint32_t> lm_seen((size_t)std::max(M, 1), 0u); // bit f: the landmark is observed in frame f
     int maxK = 1;
     for (int l = 0; l < M; ++l) {
         const int b = pb->lm_obs_ptr[l], e = pb->lm_obs_ptr[l + 1];
@@ -166,6 +167,7 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st, bool ma
             obs_lm[o] = l;
             pose_used[t] = 1;
         }
+        lm_seen[(size_t)l] = seen;
     }
     if (maxK > kLinThreads) return fail(PVIO_ERR_UNSUPPORTED, "too many observations per landmark");
     if (dm.use_inertial && pb->preint_valid)
@@ -258,10 +260,31 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st, bool ma
     // Large windows (ba_lin_tp.h): chunks of <= 256 factors whose landmarks share ONE anchor frame (a chunk is cut where the anchor changes: the
     // reference's block order is anchor-sorted, any other order only makes more chunks), as many landmarks as the LDS holds U rows for; every
     // chunk's factors sorted by target frame (the direct part of J^T J is accumulated per target)
-    std::vector<int32_t> chunk_tptr;
+    std::vector<int32_t> chunk_tptr, tp_tile_dst;
     std::vector<uint8_t> chunk_perm;
     if (dm.lm_mm) {
-        dm.lm_slots = tp_landmark_slots(dm);
+        // scatter table of the Schur tiles' accumulator entries into the element-major 3 x 3-task partial row (the flush of ba_lin_tp.h): entry r of
+        // lane l of tile (bi, bj) is element (16 bi + (l >> 4) + 4 r, 16 bj + (l & 15)) of the lower triangle
+        const int nbt = tp_u_stride(dm.P6) >> 4;
+        auto task_index = [&](int fi, int fj, int si, int sj) { return 4 * (fi * N - ((fi * (fi - 1)) >> 1) + (fj - fi)) + 2 * si + sj; };
+        for (int bi = 0; bi < nbt; ++bi)
+            for (int bj = 0; bj <= bi; ++bj)
+                for (int l = 0; l < 64; ++l)
+                    for (int r = 0; r < 4; ++r) {
+                        const int I = 16 * bi + (l >> 4) + 4 * r, J = 16 * bj + (l & 15);
+                        int32_t dst = -1;
+                        if (I < dm.P6 && J <= I) {
+                            const int fI = I / 6, iI = I % 6, fJ = J / 6, jJ = J % 6; // fJ <= fI
+                            // partial_entry(N, fI, iI, fJ, jJ) of ba_kernels.hip: off-diagonal blocks once (smaller frame = row of the task)
+                            const int el = fI == fJ ? 3 * (iI % 3) + (jJ % 3) : 3 * (jJ % 3) + (iI % 3);
+                            const int t = fI == fJ ? task_index(fI, fI, iI / 3, jJ / 3) : task_index(fJ, fI, jJ / 3, iI / 3);
+                            dst = (el << 24) | t;
+                        }
+                        tp_tile_dst.push_back(dst);
+                    }
+    }
+    if (dm.lm_mm) {
+        dm.lm_slots = tp_landmark_slots(dm, F > 0 ? (int)(((long long)kLinThreads * M + F - 1) / F) : 64);
         chunk_lm.assign(1, 0);
         int cnt = 0, fac = 0, anchor = -1;
         for (int l = 0; l < M; ++l) {
@@ -275,7 +298,10 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st, bool ma
         }
         if (M > 0) chunk_lm.push_back(M);
         dm.n_chunks = (int)chunk_lm.size() - 1;
-        dm.G_lm = std::max(1, std::min(dm.n_chunks, lm_cus));
+        // two workgroups per CU where their LDS allows (tp_landmark_slots) and the kernel is held to 256 registers (k_linearize<T <= 2, true>)
+        dm.lm_mm = 1;
+        const int per_cu = (linearize_lds_bytes(dm) <= 80 * 1024 && tiles_per_thread(dm) <= 2) ? 2 : 1;
+        dm.G_lm = std::max(1, std::min(dm.n_chunks, lm_wgs_cap > 0 ? lm_wgs_cap : per_cu * cus - (dm.G_plane + dm.G_pre + dm.G_prior)));
         chunk_tptr.assign((size_t)dm.n_chunks * (N + 1), 0);
         chunk_perm.assign((size_t)std::max(F, 1), 0);
         for (int c = 0; c < dm.n_chunks; ++c) {
@@ -344,9 +370,11 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st, bool ma
     stage.add(pb->obs_frame, (size_t)F, &v.obs_frame);
     stage.add(pb->obs_z, (size_t)F * 2, &v.obs_z);
     stage.add(obs_lm.data(), (size_t)F, &v.obs_lm);
+    stage.add(lm_seen.data(), (size_t)M, &v.lm_seen);
     stage.add(chunk_lm.data(), chunk_lm.size(), &v.chunk_lm);
     stage.add(chunk_tptr.empty() ? (const int32_t *)nullptr : chunk_tptr.data(), chunk_tptr.size(), &v.chunk_tptr);
     stage.add(chunk_perm.empty() ? (const uint8_t *)nullptr : chunk_perm.data(), chunk_perm.size(), &v.chunk_perm);
+    stage.add(tp_tile_dst.empty() ? (const int32_t *)nullptr : tp_tile_dst.data(), tp_tile_dst.size(), &v.tp_tile_dst);
     stage.add(task_desc.data(), task_desc.size(), &v.task_desc);
     stage.add(pre_valid.data(), Ns, &v.pre_valid);
     stage.add(dm.use_inertial ? pb->preint_delta : nullptr, Ns * 11, &v.pre_delta);

@@ -10,6 +10,7 @@
 //   partials   one row per workgroup of k_linearize: S tiles, 3 pose vectors, 8 scalars; summed by k_reduce
 //   dense      Smat[(dN)^2], vectors of length dN  (d = 6 vision-only, 15 with IMU / prior)
 #pragma once
+#include <stddef.h>
 #include <stdint.h>
 
 namespace pvba {
@@ -125,6 +126,8 @@ struct View { // passed by value to every kernel
     // o-th entry of the chunk's sorted list, chunk_tptr[chunk][t] = where target t's entries start in it
     const int32_t *chunk_tptr;    // [n_chunks][N + 1]
     const uint8_t *chunk_perm;    // [F]
+    const uint32_t *lm_seen;      // [M] bit f: the landmark is observed in frame f (large windows: the U row's zero blocks)
+    const int32_t *tp_tile_dst;   // [tiles][64 lanes][4]: where entry r of lane's accumulator of a Schur tile goes in the partial row: el << 24 | task, -1: nowhere
     const int32_t *task_desc;     // [n_tasks] packed fi | fj<<8 | si<<16 | sj<<17
     const uint8_t *pre_valid;     // [N]
     const double *pre_delta, *pre_U, *pre_jac;
@@ -179,5 +182,32 @@ struct View { // passed by value to every kernel
 };
 
 inline int lin_set_stride_M() { return 1; }
+
+// ---- LDS geometry of the large-window landmark role (ba_lin_tp.h), shared by the kernel, the chunker of upload() and the launch ----
+#if defined(__HIPCC__)
+#define PVBA_HD __host__ __device__
+#else
+#define PVBA_HD
+#endif
+constexpr int kTpXCols = 14;   // (row 0, row 1) pairs of a factor row: 0-5 Jt, 6-11 Jr, 12 r, 13 Jd
+constexpr int kTpLmr = 8;      // per-landmark results: 0 H_ll (then the Schur weight w)  1 b_l  2..7 W_a
+constexpr int kTpDirTasks = 9; // per target: TT00 TT01 TT11 | TR00 TR01 TR10 TR11 | g[0:3] g[3:6]
+constexpr int kTpAnchTasks = 5; // per anchor: RR00 RR01 RR11 | gR[0:3] gR[3:6]
+
+// U rows: 6 N pose columns, then b_l in column 6 N (the row 6 N of the SYRK is then the Schur right-hand side), padded to whole 16 x 16 tiles
+PVBA_HD inline int tp_u_stride(int P6) { return ((P6 + 1 + 15) >> 4) << 4; }
+PVBA_HD inline int tp_tiles(int P6) { const int nbt = tp_u_stride(P6) >> 4; return (nbt * (nbt + 1)) >> 1; }
+// doubles of LDS the role needs behind the common part: X [256][14 pairs] | U [S][US] | LMR [S][8]; a flush reuses them as its stage
+PVBA_HD inline size_t tp_work_doubles(int N, int P6, int slots, int n_tasks) {
+    const size_t S = (size_t)slots, US = (size_t)tp_u_stride(P6);
+    size_t work = (size_t)kLinThreads * 2 * kTpXCols + S * US + S * kTpLmr;
+    const size_t flush = (size_t)2 * n_tasks + 2 * (size_t)kLinThreads * 9 + 64; // a flush: >= two elements of the partial row per pass + the tasks' sums
+    return work < flush ? flush : work;
+}
+PVBA_HD inline size_t tp_lds_doubles(int N, int P6, int slots, int n_tasks) {
+    const size_t S = (size_t)slots;
+    // tables: rho_eval[S] cl_tab[S] | vg_acc[P6] vdiag_acc[P6] | ints: active[S], seen[S], fptr[S + 1], tptr[kMaxFrames + 1] | bytes: perm[256]
+    return tp_work_doubles(N, P6, slots, n_tasks) + 2 * S + 2 * (size_t)P6 + (3 * S + 1 + (kMaxFrames + 1) + 1) / 2 + kLinThreads / 8 + 8;
+}
 
 } // namespace pvba
