@@ -678,9 +678,9 @@ __device__ __forceinline__ void role_landmarks(const View &v, double *lds, const
 #include "ba_lin_tp.h" // role_landmarks_tp: the landmark role of large windows (Dims::lm_mm)
 
 #if defined(__clang__)
-#define PV_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n, n))) // register budget of a kernel: 512 / n per wave
+#define PV_MIN_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n, 8))) // register budget of a kernel: at most 512 / n per wave ((1, 8) is the compiler's default range)
 #else
-#define PV_WAVES_PER_EU(n) // (the emulator's host compiler)
+#define PV_MIN_WAVES_PER_EU(n) // (the emulator's host compiler)
 #endif
 
 // ---- plane-distance factors: one thread per factor, rows staged in LDS, same tile machinery (sign +) ----
@@ -902,7 +902,7 @@ template <int T> struct TilesPerWave { static constexpr int value = T <= 1 ? 3 :
 // that two workgroups share a CU when their LDS allows it (tp_landmark_slots: 80 KB each) -- the phases of one overlap the latencies of the other
 // TW: accumulator tiles per wave of the large-window role (23 only for 32 frames: 91 tiles; 28 .. 31 frames need 66 .. 78)
 template <int T, bool MM, int TW = TilesPerWave<T>::value>
-__global__ void __launch_bounds__(kLinThreads) PV_WAVES_PER_EU((MM && T <= 2) ? 2 : 1) k_linearize(View v) {
+__global__ void __launch_bounds__(kLinThreads) PV_MIN_WAVES_PER_EU((MM && T <= 2) ? 2 : 1) k_linearize(View v) {
     HIP_DYNAMIC_SHARED(double, lds)
     PV_STAMP_BEGIN(0);
     PV_STAMP(0, 0);

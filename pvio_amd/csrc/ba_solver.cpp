@@ -755,6 +755,7 @@ int BASolver::solve(pvio_ba_summary *sum, pvio_ba_kernel_times *prof, pvio_ba_st
             rc = run_slots(n_slots);
         }
         if (rc != PVIO_OK) return rc;
+        const auto t_enq = std::chrono::steady_clock::now();
         if (check(hipMemcpyAsync(h_ctrl_, v_.ctrl, sizeof(Ctrl), hipMemcpyDeviceToHost, stream_), "ctrl D2H")) return PVIO_ERR_HIP;
         if (check(hipEventRecord(ev1_, stream_), "event")) return PVIO_ERR_HIP;
         if (read_back) { // speculative: all but never is the state machine still running after one replay (then this is repeated)
@@ -763,6 +764,13 @@ int BASolver::solve(pvio_ba_summary *sum, pvio_ba_kernel_times *prof, pvio_ba_st
         }
         if (check(hipStreamSynchronize(stream_), "solve sync")) return PVIO_ERR_HIP;
         stage_in_flight_ = false;
+        {   // PVIO_HIP_TIMING=1: where the host's time of a solve goes (enqueueing the slots against waiting for them)
+            static const bool timing = std::getenv("PVIO_HIP_TIMING") != nullptr;
+            if (timing)
+                std::fprintf(stderr, "[pvio-hip] solve host: reset + %d slots enqueued after %.0f us (%s), stream drained after %.0f us\n", n_slots,
+                             std::chrono::duration<double, std::micro>(t_enq - t0).count(), graph_exec_ && graph_slots_ == n_slots ? "graph" : "plain launches",
+                             std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+        }
         if (h_ctrl_->done || ++rounds > (time_limited ? 16 * (dm.max_iter + 1) : 16)) break;
         // max_solver_time_in_seconds (solver_options.h:30): the state machine runs on the device, so the wall clock is looked at
         // between replays of the slot graph only (one replay covers every iteration of an ordinary solve): NO_CONVERGENCE at
