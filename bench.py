@@ -207,15 +207,15 @@ def bench_klt(ctx, args, width=512, height=512, n_points=1500, reps=50):
         r_good, _, _, r_hyp = fundamental_ransac(ctx, rp, rq)
     ransac_ms = 1e3 * (time.perf_counter() - t0) / 20
     alg_bytes = 11616 * n_points  # 4 levels x (22^2 u8 template + 22^2 x 2 int16 derivatives + 22^2 u8 target)
-    # the launch form (klt.hip, Klt::track): k_lk_track_levels (a workgroup per track, a wave per pyramid level) while every track is resident at once
-    # (4 n <= 7 waves x SIMDs), k_lk_track (a wave per track) beyond; PVIO_HIP_LK_FORM forces one
+    # the launch form (klt.hip, Klt::track): k_lk_track_levels (a workgroup per track, a wave per pyramid level) up to three tracks per CU
+    # (the tracker's own regime: 150 keypoints), k_lk_track (a wave per track) beyond -- bench.py's 1500 tracks; PVIO_HIP_LK_FORM forces one
     try:
         import torch
         n_simds = 4 * torch.cuda.get_device_properties(0).multi_processor_count
     except Exception:
         n_simds = 1024  # MI355X: 256 CUs
     form = os.environ.get("PVIO_HIP_LK_FORM", "0")
-    lk_kernel = {"1": "k_lk_track", "2": "k_lk_track_units", "3": "k_lk_track_levels"}.get(form, "k_lk_track_levels" if 4 * n_points <= 7 * n_simds else "k_lk_track")
+    lk_kernel = {"1": "k_lk_track", "2": "k_lk_track_units", "3": "k_lk_track_levels"}.get(form, "k_lk_track_levels" if 4 * n_points <= 3 * n_simds else "k_lk_track")
     out = {"metric": "KLT tracks/ms", "value": n_points / dev_ms, "unit": "tracks/ms", "value_incl_h2d_d2h": n_points / wall_ms,
            "workload": "%dx%d u8 pair, %d tracks, win 21x21, 4 levels, <=30 iterations, initial flow given" % (width, height, n_points),
            "tracked": int(st.sum()), "preprocess_ms_per_image": prep_ms, "preprocess_undistorted_ms_per_image": prep_ud_ms, "detect_ms_per_image": detect_ms, "detected_corners": int(len(corners)),

@@ -42,7 +42,7 @@ class Klt {
     size_t pts_cap_ = 0;
     void *h_pts_ = nullptr; // pinned mirror of d_pts_
     int n_simds_ = 0;    // 4 x CUs
-    int lk_form_ = 0;    // PVIO_HIP_LK_FORM (experiments and tests): 0 (default) k_lk_track_levels (a workgroup per track, a wave per level) while every track is resident at once, k_lk_track (a wave per track) beyond; 1 always k_lk_track; 2 the unit queue (k_lk_track_units); 3 always k_lk_track_levels
+    int lk_form_ = 0;    // PVIO_HIP_LK_FORM (experiments and tests): 0 (default) k_lk_track_levels (a workgroup per track, a wave per level) up to three tracks per CU, k_lk_track (a wave per track) beyond; 1 always k_lk_track; 2 the unit queue (k_lk_track_units); 3 always k_lk_track_levels
     int lk_blocks_ = 0;  // PVIO_HIP_LK_BLOCKS: blocks of the unit queue (default one per CU)
     void *d_fm_ = nullptr, *h_fm_ = nullptr; // fundamental_ransac: points, samples, counts, models, mask words (+ pinned mirror)
     size_t fm_cap_ = 0;

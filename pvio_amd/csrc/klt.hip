@@ -788,10 +788,10 @@ int Klt::track(const Image *prev, const Image *next, int n, const float *prev_xy
     // more tracks than SIMDs: (track, level) units from a queue in LDS, a block of eight waves per CU (see k_lk_track_units); otherwise a wave per track
     const int blocks = lk_blocks_ > 0 ? lk_blocks_ : n_simds_ / 4;
     const bool units = lk_form_ == 2 && (n + blocks - 1) / blocks <= kLkMaxOwned;
-    // default: a workgroup per track and a wave per level while all of them are resident at once (seven waves of 72 VGPRs per SIMD), a wave per
-    // track beyond that -- same-box A/B of the mean of 50 launches, profiles/r6_klt_levels_ab.txt: 150 tracks 20.6 -> 17.4 us, 1500 tracks 31.1 ->
-    // 30.6, 2048 tracks 31.0 -> 35.7 (the levels form needs a second round there)
-    const bool levels = lk_form_ == 0 ? (long)n * kLevels <= 7L * n_simds_ : lk_form_ == 3;
+    // default: a workgroup per track and a wave per level up to three tracks per CU, a wave per track beyond -- same-box A/Bs of the mean of 50 launches
+    // (profiles/r6_klt_bench_ab.txt, bench.py's own point set): 150 tracks 22.2 -> 19.2 us, 300 tracks 25.5 -> 22.4 us; 600 tracks 23.3 -> 24.0,
+    // 1500 tracks 35.3 -> 36.2 (with five or six chains per CU the level waves of different tracks meet on the same SIMDs: nothing is gained)
+    const bool levels = lk_form_ == 0 ? (long)n * 4 <= 3L * n_simds_ : lk_form_ == 3;
     (void)hipEventRecord(ev0_, stream_);
     if (units) hipLaunchKernelGGL(k_lk_track_units, dim3(std::min(blocks, n)), dim3(64 * kLkUnitWaves), 0, stream_, a);
     else if (levels) hipLaunchKernelGGL(k_lk_track_levels, dim3(n), dim3(64 * kLevels), 0, stream_, a);

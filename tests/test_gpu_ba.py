@@ -157,6 +157,79 @@ def test_gpu_mfma_tiles_forced_on_small_windows(oracle, name):
     ctx.close()
 
 
+# ---- round 6: the large-window landmark role (csrc/ba_lin_tp.h), forced on windows the oracle finishes in seconds ----
+@pytest.fixture(scope="module")
+def gpu_ctx_tp():
+    from pvio_amd.solver import HipContext
+    ctx = HipContext(device=0, linearize_mode=2)
+    yield ctx
+    ctx.close()
+
+
+@pytest.mark.parametrize("name", ["vio_duplicate_blocks", "vision_30x90_two_direct_tasks_per_thread", "vio_8x400_full_chunks", "vio_10x200_anchor_changes",
+                                  "vision_16x120_twelve_tiles_per_wave", "vio_4x150"])
+def test_gpu_large_window_role_matches_oracle(gpu_ctx_tp, oracle, name):
+    """the emulator's cases of tests/test_emu_ba.py (duplicate blocks; 30 frames: two direct tasks per thread, twenty tiles per wave; chunks of 64
+    landmarks; anchor flushes; ...) on the GPU, per iteration against the oracle"""
+    kw = {"vio_duplicate_blocks": ba_compare.CASES["vio_duplicate_blocks"], "vision_30x90_two_direct_tasks_per_thread": dict(n_frames=30, n_landmarks=90, visibility=11),
+          "vio_8x400_full_chunks": dict(n_frames=8, n_landmarks=400, use_inertial=True, visibility=3),
+          "vio_10x200_anchor_changes": dict(n_frames=10, n_landmarks=200, use_inertial=True, visibility=5),
+          "vision_16x120_twelve_tiles_per_wave": dict(n_frames=16, n_landmarks=120, visibility=9), "vio_4x150": dict(n_frames=4, n_landmarks=150, use_inertial=True, visibility=3)}[name]
+    print(name, ba_compare.check_against_oracle(gpu_ctx_tp, oracle, ba_compare.make(oracle, **kw)))
+
+
+def test_gpu_large_window_role_unsorted_anchors_fixed_frame_and_marginalization(gpu_ctx_tp, oracle):
+    """landmarks in RANDOM anchor order (a chunk per few landmarks, an anchor flush in front of most, anchors coming back), a fixed frame, and
+    marginalize_frame through the same role (un-robustified blocks of the victim's tracks only)"""
+    import marg_compare
+    from pvio_amd import synth
+    pb = ba_compare.make(oracle, n_frames=7, n_landmarks=150, use_inertial=True, visibility=3)
+    pb2 = synth.permute_landmarks(pb, np.random.default_rng(3).permutation(pb.n_landmarks))
+    assert (np.diff(pb2.lm_anchor_frame) != 0).sum() > 60
+    ba_compare.check_against_oracle(gpu_ctx_tp, oracle, pb2)
+    pb3 = ba_compare.make(oracle, n_frames=6, n_landmarks=120, visibility=4)
+    pb3.frame_fixed[2] = 1
+    ba_compare.check_against_oracle(gpu_ctx_tp, oracle, pb3)
+    for victim in (0, 3):
+        marg_compare.check_marginalize(gpu_ctx_tp, oracle, victim, n_frames=8, n_landmarks=500, use_inertial=True, visibility=5)
+
+
+@pytest.mark.parametrize("seed", list(range(0, 60, 5)))
+def test_gpu_large_window_role_on_the_random_sweep(gpu_ctx_tp, oracle, seed):
+    """every fifth window of the random-shape sweep (2-32 frames, planes, IMU or not, fixed frames) through the large-window role"""
+    kw, pb = ba_compare.sweep_window(oracle, seed)
+    r = ba_compare.check_against_oracle_within_spread(gpu_ctx_tp, oracle, pb)
+    print(seed, kw, r)
+    if "skipped" in r:
+        pytest.skip("window %d: %s" % (seed, r["skipped"]))
+
+
+def test_gpu_large_window_role_is_deterministic_and_reads_nothing_stale(gpu_ctx_tp, oracle):
+    """a 10 x 5000 window (two workgroups per CU, several chunks per workgroup): twenty resident re-solves bit-identical, also with every CU's LDS and
+    registers left full of NaN / 1e300 by another kernel in between (the role clears nothing per chunk: every U cell it reads must have been written)"""
+    import struct
+    L, R = _poison_libs()
+    pb = ba_compare.make(oracle, n_frames=10, n_landmarks=5000, use_inertial=True, visibility=7)
+    gpu_ctx_tp.upload(pb)
+    ref = None
+    for k in range(20):
+        if k % 5 == 4:
+            pat = struct.unpack("<Q", struct.pack("<d", float("nan") if k % 10 == 4 else 1e300))[0]
+            assert L.lds_poison(pat) == 0 and R.reg_poison(pat) == 0
+        sm = BASummary(pb, trace=False)
+        gpu_ctx_tp.solve_resident(sm)
+        st = BAState(pb)
+        gpu_ctx_tp.download(st)
+        cur = (st.frame_state.copy(), st.lm_inv_depth.copy(), sm.final_cost, sm.num_iterations)
+        ref = ref or cur
+        assert (cur[0] == ref[0]).all() and (cur[1] == ref[1]).all() and cur[2:] == ref[2:], k
+    st0, sm0 = BAState(pb), BASummary(pb)
+    oracle.solve(pb, st0, sm0)
+    assert sm0.num_iterations == ref[3]
+    np.testing.assert_allclose(ref[0], st0.frame_state, rtol=0, atol=1e-6)
+    np.testing.assert_allclose(ref[1], st0.lm_inv_depth, rtol=0, atol=1e-6)
+
+
 def test_gpu_both_linearize_modes_agree_on_a_large_window(oracle):
     from pvio_amd.solver import HipContext
     pb = ba_compare.make(oracle, n_frames=24, n_landmarks=8000, use_inertial=True, visibility=9)
