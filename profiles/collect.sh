@@ -1,9 +1,9 @@
 #!/bin/bash
 # Collects the round's evidence on the GPU box: run from the repo root through gpurun, e.g.
-#   gpurun --timeout 2400 -- 'bash profiles/collect.sh r5'
+#   gpurun --timeout 3300 -- 'bash profiles/collect.sh r6'
 # Everything lands in gpurun_out/<tag>_*; copy what should be judged into profiles/.
 set -u
-TAG=${1:-r5}
+TAG=${1:-r6}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 mkdir -p $OUT
@@ -20,6 +20,14 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_pro
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_prof_large_write -- $LARGE > $OUT/${TAG}_prof_large_write.log 2>&1
 python $R/profiles/summarize_pmc.py $OUT/${TAG}_prof_large_fetch $OUT/${TAG}_prof_large_write $OUT/${TAG}_pmc_hbm_30x50000_vio.json > /dev/null
 find $OUT/${TAG}_prof_large_stats -name '*kernel_stats.csv' -exec cp {} $OUT/${TAG}_kernel_stats_bench_30x50000_vio.csv \;
+# the same three passes for the 10 KF x 50k VIO window (the one north_star states the scaling target on; round 6: k_linearize in its two-workgroups-per-CU form)
+MID="python $R/bench.py --workload 10x50000_vio --steps 8 --warmup 2 --no-klt --no-cpu-baseline --no-pmc"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_mid_stats -- $MID > $OUT/${TAG}_prof_mid_stats.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_prof_mid_fetch -- $MID > $OUT/${TAG}_prof_mid_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_prof_mid_write -- $MID > $OUT/${TAG}_prof_mid_write.log 2>&1
+python $R/profiles/summarize_pmc.py $OUT/${TAG}_prof_mid_fetch $OUT/${TAG}_prof_mid_write $OUT/${TAG}_pmc_hbm_10x50000_vio.json > /dev/null
+find $OUT/${TAG}_prof_mid_stats -name '*kernel_stats.csv' -exec cp {} $OUT/${TAG}_kernel_stats_bench_10x50000_vio.csv \;
+rm -rf $OUT/${TAG}_prof_mid_fetch $OUT/${TAG}_prof_mid_write $OUT/${TAG}_prof_mid_stats 2>/dev/null
 rm -rf $OUT/${TAG}_prof_large_fetch/*/*kernel_trace.csv $OUT/${TAG}_prof_large_write/*/*kernel_trace.csv $OUT/${TAG}_prof_large_stats/*/*kernel_trace.csv 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_stats -- python $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-scaling-window > $OUT/${TAG}_prof_stats.log 2>&1
 # counters in their own passes, kernel trace only (no sys / runtime traces)
@@ -36,12 +44,14 @@ python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.
 # end to end: rendered sequence -> front end -> PnP -> sliding-window BA (tests/test_host_headless.py prints the trajectory error)
 (cd $R && python -m pytest tests/test_host_headless.py -m gpu -q -s 2>&1 | grep "^headless") > $OUT/${TAG}_headless.txt
 # complete keyframe solves (upload + solve + download), LK launch time against the batch size, dense kernel of large windows
-(cd $R && python tests/prof_sequence_solves.py) > $OUT/${TAG}_prof_sequence_solves.txt 2>&1
+(cd $R && python tests/prof_sequence_solves.py full full_relief) > $OUT/${TAG}_prof_sequence_solves_60.txt 2>&1  # (the 360-frame sequences: tools/gpu/r6_call12.sh, ~12 min)
 (cd $R && python tests/sweep_random_dropin.py gpu 24 2>&1 | tail -26) > $OUT/${TAG}_sweep_random_dropin_gpu.txt
 (cd $R && python tests/prof_upload.py) > $OUT/${TAG}_prof_upload.txt 2>&1
 (cd $R && python tests/prof_klt.py) > $OUT/${TAG}_prof_klt.txt 2>&1
 (cd $R && python tests/prof_dense_large.py) > $OUT/${TAG}_prof_dense_large.txt 2>&1
 (cd $R && python tests/prof_phases.py) > $OUT/${TAG}_prof_phases.txt 2>&1
+(cd $R && python tests/prof_large_tp.py 2>&1 | grep -v amdgpu.ids) > $OUT/${TAG}_prof_large_tp.txt
+(cd $R && timeout -s KILL 400 python tests/micro/klt_bench_ab.py 2>&1 | grep -v amdgpu.ids) > $OUT/${TAG}_klt_bench_ab_final.txt
 # the raw traces are large: keep the summaries only
 rm -rf $OUT/${TAG}_prof_fetch/*/*kernel_trace.csv $OUT/${TAG}_prof_write/*/*kernel_trace.csv 2>/dev/null
 ls -la $OUT | head -40

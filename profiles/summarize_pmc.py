@@ -8,7 +8,7 @@ narrow access patterns); WRITE_SIZE is taken as is."""
 import csv, glob, json, os, re, sys
 from collections import defaultdict
 
-KERNELS = ["k_linearize", "k_reduce", "k_dense", "k_backsub", "k_lk_track_units", "k_lk_track", "k_scharr", "k_pyr_down", "k_clahe_apply", "k_remap"]
+KERNELS = ["k_linearize", "k_reduce", "k_dense", "k_backsub", "k_lk_track_levels", "k_lk_track_units", "k_lk_track", "k_scharr", "k_pyr_down", "k_clahe_apply", "k_remap"]
 
 
 def per_kernel(directory, counter):

@@ -120,9 +120,17 @@ __device__ __forceinline__ void role_landmarks_tp(const View &v, double *lds, co
     double p_rho = 0, p_cl = 1, p_gh = 0, p_gn = 0, p_D = 1;
     int p_p0 = 0, p_p1 = 0, p_anchor = 0;
     uint32_t p_seen = 0;
-    auto request = [&](int ck) { // independent loads
-        const int l0 = v.chunk_lm[ck], ns = v.chunk_lm[ck + 1] - l0;
-        const int o0 = v.lm_ptr[l0], nf = v.lm_ptr[l0 + ns] - o0;
+    // geometry of a chunk: first landmark, landmarks, first factor, factors, anchor frame -- one 32-byte record per chunk (built at upload): deriving it from
+    // chunk_lm -> lm_ptr -> lm_anchor is a chain of dependent scalar loads, repeated by every step below it was 3-4 k cycles of a chunk's ~25 k
+    struct Geo {
+        int l0, ns, o0, nf, a;
+    };
+    auto load_geo = [&](int ck) {
+        const int32_t *g = v.chunk_geo + 8 * (size_t)ck;
+        return Geo{g[0], g[1], g[2], g[3], g[4]};
+    };
+    auto request = [&](const Geo &G) { // independent loads
+        const int l0 = G.l0, ns = G.ns, o0 = G.o0, nf = G.nf;
         if (tid < nf) {
             const size_t o = (size_t)o0 + tid;
             f_l = v.obs_lm[o], f_t = v.obs_frame[o], f_perm = v.chunk_perm[o], f_z0 = v.obs_z[2 * o], f_z1 = v.obs_z[2 * o + 1];
@@ -135,15 +143,13 @@ __device__ __forceinline__ void role_landmarks_tp(const View &v, double *lds, co
             if (marg) p_anchor = v.lm_anchor[l];
         }
     };
-    auto request2 = [&](int ck) { // loads that depend on the first ones
-        const int l0 = v.chunk_lm[ck], ns = v.chunk_lm[ck + 1] - l0;
-        const int nf = v.lm_ptr[l0 + ns] - v.lm_ptr[l0];
-        if (tid < nf) f_zr0 = v.lm_zref[2 * (size_t)f_l], f_zr1 = v.lm_zref[2 * (size_t)f_l + 1];
+    auto request2 = [&](const Geo &G) { // loads that depend on the first ones
+        if (tid < G.nf) f_zr0 = v.lm_zref[2 * (size_t)f_l], f_zr1 = v.lm_zref[2 * (size_t)f_l + 1];
     };
     // landmark inputs of chunk ck -> the tables (single-buffered: written in phase S of the chunk before, when nothing reads them any more);
     // candidate inverse depths, |step|^2, |x|^2 (threads tid < ns)
-    auto prep = [&](int ck) {
-        const int l0 = v.chunk_lm[ck], ns = v.chunk_lm[ck + 1] - l0;
+    auto prep = [&](const Geo &G) {
+        const int l0 = G.l0, ns = G.ns;
         if (tid < ns) {
             const int l = l0 + tid;
             double r = p_rho;
@@ -165,8 +171,8 @@ __device__ __forceinline__ void role_landmarks_tp(const View &v, double *lds, co
             }
             act_e[tid] = act;
             seen_e[tid] = (int)p_seen;
-            fp[tid] = p_p0 - v.lm_ptr[l0];
-            if (tid == ns - 1) fp[ns] = p_p1 - v.lm_ptr[l0];
+            fp[tid] = p_p0 - G.o0;
+            if (tid == ns - 1) fp[ns] = p_p1 - G.o0;
         }
     };
     // sums of a task's subs -> every thread of the task, through LDS (work area: X is free between chunks), in sub order
@@ -182,16 +188,32 @@ __device__ __forceinline__ void role_landmarks_tp(const View &v, double *lds, co
             }
         __syncthreads();
         if (!only_anchor_bound) PV_STAMP(0, 20);
+        // the anchor tasks have many subs (15 at N = 10, 48 at N = 30): 45 (task, element) sums dealt to four lanes each, joined by DPP (fixed order)
+        double *RES = DS + (size_t)NDT * kLinThreads * 9; // [5][9]
+        {
+            const int g = tid & 3, te = tid >> 2, b = te / 9, e = te - 9 * b;
+            double sum = 0.0;
+            if (te < 9 * kTpAnchTasks) {
+                const int per = (nsubA + 3) >> 2, u0 = g * per, u1 = u0 + per < nsubA ? u0 + per : nsubA;
+                const double *src = DS + (size_t)(n_dir * nsub + b * nsubA) * 9 + e;
+                for (int u = u0; u < u1; ++u) sum += src[(size_t)u * 9];
+            }
+            sum += dpp_f64(sum, 0), sum += dpp_f64(sum, 1); // (whole waves: 180 lanes = 45 quads)
+            if (te < 9 * kTpAnchTasks && g == 0) RES[te] = sum;
+        }
+        __syncthreads();
 #pragma unroll
         for (int q = 0; q < NDT; ++q) {
             const bool bound = d_kind[q] == 1 || (d_kind[q] == 0 && d_blk[q] >= 3 && d_blk[q] <= 6); // the sums that belong to the current anchor
-            if (d_kind[q] >= 0 && d_sub[q] == 0 && (bound || !only_anchor_bound)) {
-                const int step = d_kind[q] == 0 ? nsub : nsubA;
+            if (d_kind[q] == 1 && d_sub[q] == 0) {
+#pragma unroll
+                for (int e = 0; e < 9; ++e) dacc[q][e] = RES[9 * d_blk[q] + e];
+            } else if (d_kind[q] == 0 && d_sub[q] == 0 && (bound || !only_anchor_bound)) {
                 const double *src = DS + (size_t)(tid + q * kLinThreads) * 9;
-                double sum[9]; // (sub by sub, the nine loads of a sub in flight together: element by element is `step` dependent LDS round trips each)
+                double sum[9]; // (sub by sub, the nine loads of a sub in flight together)
 #pragma unroll
                 for (int e = 0; e < 9; ++e) sum[e] = src[e];
-                for (int u = 1; u < step; ++u) {
+                for (int u = 1; u < nsub; ++u) {
 #pragma unroll
                     for (int e = 0; e < 9; ++e) sum[e] += src[u * 9 + e];
                 }
@@ -251,10 +273,12 @@ __device__ __forceinline__ void role_landmarks_tp(const View &v, double *lds, co
         __syncthreads();
     };
 
+    Geo cg{0, 0, 0, 0, 0}, ng{0, 0, 0, 0, 0}; // this chunk's / the next chunk's geometry
     if (ck_begin < ck_end) {
-        request(ck_begin);
-        request2(ck_begin);
-        prep(ck_begin);
+        cg = load_geo(ck_begin);
+        request(cg);
+        request2(cg);
+        prep(cg);
     }
     {   // the U rows once: the columns behind 6 N + 1 stay zero for the whole walk
         lds_d2 z;
@@ -264,9 +288,9 @@ __device__ __forceinline__ void role_landmarks_tp(const View &v, double *lds, co
     }
     __syncthreads();
     for (int ck = ck_begin; ck < ck_end; ++ck) {
-        const int l0 = v.chunk_lm[ck], ns = v.chunk_lm[ck + 1] - l0;
-        const int o0 = v.lm_ptr[l0], nf = v.lm_ptr[l0 + ns] - o0;
-        const int a = v.lm_anchor[l0]; // the chunk's anchor (the host cuts chunks at anchor changes)
+        const int l0 = cg.l0, ns = cg.ns, o0 = cg.o0, nf = cg.nf;
+        const int a = cg.a; // the chunk's anchor (the host cuts chunks at anchor changes)
+        if (ck + 1 < ck_end) ng = load_geo(ck + 1); // (back long before phase E ends)
         if (a != cur_anchor) { // uniform
             if (cur_anchor >= 0) anchor_flush();
             cur_anchor = a;
@@ -321,7 +345,7 @@ __device__ __forceinline__ void role_landmarks_tp(const View &v, double *lds, co
                 o_Wt[(size_t)o * 6 + k] = wt;
             }
         }
-        if (ck + 1 < ck_end) request(ck + 1); // (in flight through D .. P)
+        if (ck + 1 < ck_end) request(ng); // (in flight through D .. P)
         __syncthreads();
         PV_STAMP(0, 3);
         // ---- D: direct part, thread = (target or anchor task, sub); two factors per pass so that their loads are in flight together ----
@@ -353,23 +377,33 @@ __device__ __forceinline__ void role_landmarks_tp(const View &v, double *lds, co
                 }
             }
         PV_STAMP(0, 4);
-        // ---- L: H_ll, b_l, W_a = Jd^T [Jd r Jr] over the landmark's factor rows; thread = (slot, column) ----
-        for (int s = tid >> 3; s < ns; s += kLinThreads >> 3) {
-            const int c = tid & 7, col = c == 0 ? 13 : (c == 1 ? 12 : 4 + c);
-            const int f0 = fp[s], f1 = fp[s + 1];
-            double s0 = 0.0, s1 = 0.0;
-            int f = f0;
-            for (; f + 1 < f1; f += 2) {
-                const lds_d2 *x = X2 + (size_t)f * kTpXCols;
-                const lds_d2 jd0 = x[13], y0 = x[col], jd1 = x[kTpXCols + 13], y1 = x[kTpXCols + col];
-                s0 += jd0[0] * y0[0] + jd0[1] * y0[1], s1 += jd1[0] * y1[0] + jd1[1] * y1[1];
+        // ---- L: H_ll, b_l, W_a = Jd^T [Jd r Jr] over the landmark's factor rows; thread = (slot, column, part): a chunk of few landmarks (many frames)
+        // deals a landmark's factors to 2 or 4 adjacent lanes, whose partial sums meet by DPP (fixed order) ----
+        {
+            const int split = ns <= 8 ? 4 : (ns <= 16 ? 2 : 1); // uniform
+            const int q = tid & (split - 1), sc = tid / split, c = sc & 7, col = c == 0 ? 13 : (c == 1 ? 12 : 4 + c);
+            for (int sb = 0; sb < ns; sb += kLinThreads / (8 * split)) { // (uniform trip count: the DPP exchange below is executed by whole waves)
+                const int s = sb + (sc >> 3);
+                double s0 = 0.0, s1 = 0.0;
+                if (s < ns) {
+                    const int f0 = fp[s], f1 = fp[s + 1];
+                    int f = f0 + q;
+                    for (; f + split < f1; f += 2 * split) {
+                        const lds_d2 *x = X2 + (size_t)f * kTpXCols, *y = x + (size_t)split * kTpXCols;
+                        const lds_d2 jd0 = x[13], y0 = x[col], jd1 = y[13], y1 = y[col];
+                        s0 += jd0[0] * y0[0] + jd0[1] * y0[1], s1 += jd1[0] * y1[0] + jd1[1] * y1[1];
+                    }
+                    if (f < f1) {
+                        const lds_d2 *x = X2 + (size_t)f * kTpXCols;
+                        const lds_d2 jd0 = x[13], y0 = x[col];
+                        s0 += jd0[0] * y0[0] + jd0[1] * y0[1];
+                    }
+                }
+                double sum = s0 + s1;
+                if (split >= 2) sum += dpp_f64(sum, 0); // lane ^ 1
+                if (split >= 4) sum += dpp_f64(sum, 1); // lane ^ 2
+                if (s < ns && q == 0) LMR[(size_t)s * kTpLmr + c] = sum;
             }
-            if (f < f1) {
-                const lds_d2 *x = X2 + (size_t)f * kTpXCols;
-                const lds_d2 jd0 = x[13], y0 = x[col];
-                s0 += jd0[0] * y0[0] + jd0[1] * y0[1];
-            }
-            LMR[(size_t)s * kTpLmr + c] = s0 + s1;
         }
         __syncthreads();
         PV_STAMP(0, 5);
@@ -412,8 +446,8 @@ __device__ __forceinline__ void role_landmarks_tp(const View &v, double *lds, co
             }
             Us[P6] = b; // row 6 N of the SYRK below: - sum_l w_l b_l u_l = - the Schur right-hand side
             // the blocks of the frames that do not see the landmark: whatever the last chunk left there
-            const unsigned unseen = ~((unsigned)seen_e[tid] | (1u << a));
-            for (int f = 0; f < N; ++f)
+            const unsigned unseen = ~((unsigned)seen_e[tid] | (1u << a)) & (N >= 32 ? 0xffffffffu : (1u << N) - 1u);
+            for (int f = 0; unseen >> f; ++f) // (nothing to do for a landmark every frame sees)
                 if ((unseen >> f) & 1u) {
 #pragma unroll
                     for (int k = 0; k < 6; ++k) Us[6 * f + k] = 0.0;
@@ -422,7 +456,7 @@ __device__ __forceinline__ void role_landmarks_tp(const View &v, double *lds, co
             double *Us = U + (size_t)tid * US;
             for (int k = 0; k <= P6; ++k) Us[k] = 0.0;
         }
-        if (ck + 1 < ck_end) request2(ck + 1);
+        if (ck + 1 < ck_end) request2(ng);
         __syncthreads();
         PV_STAMP(0, 6);
         // ---- S: Schur complement on the matrix cores; beside it the next chunk's landmark tables and the other U buffer's clear ----
@@ -445,7 +479,8 @@ __device__ __forceinline__ void role_landmarks_tp(const View &v, double *lds, co
                         tacc[u0 + u] = __builtin_amdgcn_mfma_f64_16x16x4f64(nw * a_op[u], b_op[u], tacc[u0 + u], 0, 0, 0);
             }
         }
-        if (ck + 1 < ck_end) prep(ck + 1);
+        if (ck + 1 < ck_end) prep(ng);
+        cg = ng;
         __syncthreads();
         PV_STAMP(0, 7);
     }
@@ -500,9 +535,74 @@ __device__ __forceinline__ void role_landmarks_tp(const View &v, double *lds, co
             if (I0 + 4 * r == P6 && J < P6) pv[P6 + J] = -tacc[u][r];
     }
     double *stage = work + (size_t)NDT * kLinThreads * 9;   // [els][n_tasks]: as many elements of the partial row per pass as fit
-    const int cap = (int)((work_sz - (size_t)NDT * kLinThreads * 9) / (size_t)n_tasks);
-    const int els = cap >= 9 ? 9 : cap; // >= 2 (tp_work_doubles)
-    for (int e_lo = 0; e_lo < 9; e_lo += els) {
+    const int cap = (int)((unsigned)(work_sz - (size_t)NDT * kLinThreads * 9) / (unsigned)n_tasks);
+    int els = cap >= 9 ? 9 : cap; // >= 2 (tp_work_doubles)
+    if (els < 9) {
+        // Many frames (the row does not fit the LDS at once: 134 KB at N = 30): straight to the workgroup's row in HBM instead of three staged passes
+        // (94 k cycles at 30 x 50 000).  Every entry has ONE writer per step -- tile entries are distinct, the tasks' blocks are disjoint, the anchor's own
+        // block comes last -- and the steps are separated by barriers: plain read-modify-writes of the workgroup's own row, in the same order per entry as
+        // the staged form (tile, direct block, anchor block; what earlier anchor flushes left is already in the row).
+        if (!row_dirty) {
+            for (int e = tid; e < n_tasks * 9; e += kLinThreads) pS[e] = 0.0;
+            __threadfence_block();
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < TW; ++u) {
+            if (tile_bb[u] < 0) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (tdst[u][r] >= 0) {
+                    double *dst = pS + (size_t)(tdst[u][r] >> 24) * n_tasks + (tdst[u][r] & 0xffffff);
+                    *dst = row_dirty ? *dst + tacc[u][r] : tacc[u][r];
+                }
+        }
+        __threadfence_block();
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < NDT; ++q)
+            if (d_kind[q] == 0 && d_sub[q] == 0 && d_blk[q] < 7) {
+                const int b = d_blk[q], t = d_t[q], A = cur_anchor;
+                int tA, tB = -1;
+                bool trA = false;
+                if (b <= 2) {
+                    tA = task_index(N, t, t, b == 2, b >= 1);
+                    if (b == 1) tB = task_index(N, t, t, 1, 0);
+                } else {
+                    const int bi = (b - 3) >> 1, bj = (b - 3) & 1;
+                    trA = t > A;
+                    tA = (A < 0 || t == A) ? -1 : (trA ? task_index(N, A, t, bj, bi) : task_index(N, t, A, bi, bj));
+                }
+                // (all loads of the task first: a chain of read-modify-writes the compiler must keep in order is eighteen trips to L2)
+                double oa[9], ob[9];
+#pragma unroll
+                for (int e = 0; e < 9; ++e) {
+                    const int eT = 3 * (e % 3) + e / 3, elA = trA ? eT : e;
+                    oa[e] = tA >= 0 ? pS[(size_t)elA * n_tasks + tA] : 0.0, ob[e] = tB >= 0 ? pS[(size_t)eT * n_tasks + tB] : 0.0;
+                }
+#pragma unroll
+                for (int e = 0; e < 9; ++e) {
+                    const int eT = 3 * (e % 3) + e / 3, elA = trA ? eT : e;
+                    if (tA >= 0) pS[(size_t)elA * n_tasks + tA] = oa[e] + dacc[q][e];
+                    if (tB >= 0) pS[(size_t)eT * n_tasks + tB] = ob[e] + dacc[q][e];
+                }
+            }
+        __threadfence_block();
+        __syncthreads();
+        if (tid < 27 && cur_anchor >= 0) { // the last anchor's own block
+            const int b = tid / 9, el = tid - 9 * b, i = el / 3, j = el - 3 * i, A = cur_anchor;
+            const double val = ds_anchor(b)[el];
+            if (b != 1) {
+                const PartialEntry pe = partial_entry(N, A, (b == 0 ? 0 : 3) + i, A, (b == 0 ? 0 : 3) + j);
+                pS[(size_t)pe.el * n_tasks + pe.t] += val;
+            } else {
+                const PartialEntry pe = partial_entry(N, A, i, A, 3 + j), pt = partial_entry(N, A, 3 + j, A, i);
+                pS[(size_t)pe.el * n_tasks + pe.t] += val, pS[(size_t)pt.el * n_tasks + pt.t] += val;
+            }
+        }
+        els = 9; // (skips the staged passes below)
+    }
+    for (int e_lo = els < 9 ? 0 : (cap >= 9 ? 0 : 9); e_lo < 9; e_lo += els) {
         const int e_n = e_lo + els <= 9 ? els : 9 - e_lo;
         __syncthreads();
         for (int e = tid; e < e_n * n_tasks; e += kLinThreads) stage[e] = 0.0;

@@ -260,7 +260,7 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st, bool ma
     // Large windows (ba_lin_tp.h): chunks of <= 256 factors whose landmarks share ONE anchor frame (a chunk is cut where the anchor changes: the
     // reference's block order is anchor-sorted, any other order only makes more chunks), as many landmarks as the LDS holds U rows for; every
     // chunk's factors sorted by target frame (the direct part of J^T J is accumulated per target)
-    std::vector<int32_t> chunk_tptr, tp_tile_dst;
+    std::vector<int32_t> chunk_tptr, chunk_geo, tp_tile_dst;
     std::vector<uint8_t> chunk_perm;
     if (dm.lm_mm) {
         // scatter table of the Schur tiles' accumulator entries into the element-major 3 x 3-task partial row (the flush of ba_lin_tp.h): entry r of
@@ -302,6 +302,12 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st, bool ma
         dm.lm_mm = 1;
         const int per_cu = (linearize_lds_bytes(dm) <= 80 * 1024 && tiles_per_thread(dm) <= 2) ? 2 : 1;
         dm.G_lm = std::max(1, std::min(dm.n_chunks, lm_wgs_cap > 0 ? lm_wgs_cap : per_cu * cus - (dm.G_plane + dm.G_pre + dm.G_prior)));
+        chunk_geo.assign((size_t)dm.n_chunks * 8, 0);
+        for (int c = 0; c < dm.n_chunks; ++c) {
+            int32_t *g = chunk_geo.data() + (size_t)c * 8;
+            g[0] = chunk_lm[c], g[1] = chunk_lm[c + 1] - chunk_lm[c], g[2] = pb->lm_obs_ptr[chunk_lm[c]], g[3] = pb->lm_obs_ptr[chunk_lm[c + 1]] - g[2];
+            g[4] = pb->lm_anchor_frame[chunk_lm[c]];
+        }
         chunk_tptr.assign((size_t)dm.n_chunks * (N + 1), 0);
         chunk_perm.assign((size_t)std::max(F, 1), 0);
         for (int c = 0; c < dm.n_chunks; ++c) {
@@ -373,6 +379,7 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st, bool ma
     stage.add(lm_seen.data(), (size_t)M, &v.lm_seen);
     stage.add(chunk_lm.data(), chunk_lm.size(), &v.chunk_lm);
     stage.add(chunk_tptr.empty() ? (const int32_t *)nullptr : chunk_tptr.data(), chunk_tptr.size(), &v.chunk_tptr);
+    stage.add(chunk_geo.empty() ? (const int32_t *)nullptr : chunk_geo.data(), chunk_geo.size(), &v.chunk_geo);
     stage.add(chunk_perm.empty() ? (const uint8_t *)nullptr : chunk_perm.data(), chunk_perm.size(), &v.chunk_perm);
     stage.add(tp_tile_dst.empty() ? (const int32_t *)nullptr : tp_tile_dst.data(), tp_tile_dst.size(), &v.tp_tile_dst);
     stage.add(task_desc.data(), task_desc.size(), &v.task_desc);

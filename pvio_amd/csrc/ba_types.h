@@ -124,6 +124,7 @@ struct View { // passed by value to every kernel
     const int32_t *chunk_lm;      // [n_chunks+1] landmark ranges
     // Dims::lm_mm (large windows, ba_lin_tp.h): every chunk's factors sorted by target frame -- chunk_perm[o] = chunk-relative factor index of the
     // o-th entry of the chunk's sorted list, chunk_tptr[chunk][t] = where target t's entries start in it
+    const int32_t *chunk_geo;     // [n_chunks][8]: first landmark, landmarks, first factor, factors, anchor frame, 0, 0, 0
     const int32_t *chunk_tptr;    // [n_chunks][N + 1]
     const uint8_t *chunk_perm;    // [F]
     const uint32_t *lm_seen;      // [M] bit f: the landmark is observed in frame f (large windows: the U row's zero blocks)

@@ -1,4 +1,6 @@
-"""k_lk_track_levels with 2..6 blocks per CU (fewer blocks than tracks: the rest is claimed from the queue) against k_lk_track and the unit queue on bench.py's
+"""RECORD OF A DROPPED EXPERIMENT (profiles/r6_klt_persist_ab.txt): the queue-claiming form of k_lk_track_levels and its PVIO_HIP_LK_LEVEL_BLOCKS switch are not in
+the tree any more (30 % slower at every setting); with today's library every "levels" variant below is the same kernel.
+k_lk_track_levels with 2..6 blocks per CU (fewer blocks than tracks: the rest is claimed from the queue) against k_lk_track and the unit queue on bench.py's
 KLT workload (make_image_pair(512, 512, 1500)) and at 3000 / 6000 tracks: mean of 50 launches, interleaved rounds on one box."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
