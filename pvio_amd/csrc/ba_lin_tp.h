@@ -115,7 +115,7 @@ __device__ __forceinline__ void role_landmarks_tp(const View &v, double *lds, co
     const int ck_begin = wg * per_wg, ck_end = ck_begin + per_wg < v.dm.n_chunks ? ck_begin + per_wg : v.dm.n_chunks;
 
     // ---- inputs of a chunk, requested one chunk ahead: factor arrays (thread = factor) and landmark arrays (thread = landmark) ----
-    int f_l = 0, f_t = 0, f_perm = 0;
+    int f_l = 0, f_t = 0, f_perm = 0, f_tptr = 0;
     double f_z0 = 0, f_z1 = 0, f_zr0 = 0, f_zr1 = 0;
     double p_rho = 0, p_cl = 1, p_gh = 0, p_gn = 0, p_D = 1;
     int p_p0 = 0, p_p1 = 0, p_anchor = 0;
@@ -123,14 +123,15 @@ __device__ __forceinline__ void role_landmarks_tp(const View &v, double *lds, co
     // geometry of a chunk: first landmark, landmarks, first factor, factors, anchor frame -- one 32-byte record per chunk (built at upload): deriving it from
     // chunk_lm -> lm_ptr -> lm_anchor is a chain of dependent scalar loads, repeated by every step below it was 3-4 k cycles of a chunk's ~25 k
     struct Geo {
-        int l0, ns, o0, nf, a;
+        int l0, ns, o0, nf, a, ck;
     };
     auto load_geo = [&](int ck) {
         const int32_t *g = v.chunk_geo + 8 * (size_t)ck;
-        return Geo{g[0], g[1], g[2], g[3], g[4]};
+        return Geo{g[0], g[1], g[2], g[3], g[4], ck};
     };
     auto request = [&](const Geo &G) { // independent loads
         const int l0 = G.l0, ns = G.ns, o0 = G.o0, nf = G.nf;
+        if (tid <= N) f_tptr = v.chunk_tptr[(size_t)G.ck * (N + 1) + tid];
         if (tid < nf) {
             const size_t o = (size_t)o0 + tid;
             f_l = v.obs_lm[o], f_t = v.obs_frame[o], f_perm = v.chunk_perm[o], f_z0 = v.obs_z[2 * o], f_z1 = v.obs_z[2 * o + 1];
@@ -273,7 +274,7 @@ __device__ __forceinline__ void role_landmarks_tp(const View &v, double *lds, co
         __syncthreads();
     };
 
-    Geo cg{0, 0, 0, 0, 0}, ng{0, 0, 0, 0, 0}; // this chunk's / the next chunk's geometry
+    Geo cg{0, 0, 0, 0, 0, 0}, ng{0, 0, 0, 0, 0, 0}; // this chunk's / the next chunk's geometry
     if (ck_begin < ck_end) {
         cg = load_geo(ck_begin);
         request(cg);
@@ -297,7 +298,7 @@ __device__ __forceinline__ void role_landmarks_tp(const View &v, double *lds, co
         }
         PV_STAMP(0, 2);
         // ---- E: one thread per factor ----
-        if (tid <= N) tptr[tid] = v.chunk_tptr[(size_t)ck * (N + 1) + tid];
+        if (tid <= N) tptr[tid] = f_tptr; // (requested with the chunk's other inputs, a chunk ahead)
         if (tid < nf) {
             const int o = o0 + tid, l = f_l, s = l - l0, t = f_t;
             perm[tid] = (uint8_t)f_perm;
@@ -547,6 +548,7 @@ __device__ __forceinline__ void role_landmarks_tp(const View &v, double *lds, co
             __threadfence_block();
         }
         __syncthreads();
+        PV_STAMP(0, 21);
 #pragma unroll
         for (int u = 0; u < TW; ++u) {
             if (tile_bb[u] < 0) continue;
@@ -559,6 +561,7 @@ __device__ __forceinline__ void role_landmarks_tp(const View &v, double *lds, co
         }
         __threadfence_block();
         __syncthreads();
+        PV_STAMP(0, 22);
 #pragma unroll
         for (int q = 0; q < NDT; ++q)
             if (d_kind[q] == 0 && d_sub[q] == 0 && d_blk[q] < 7) {
@@ -589,6 +592,7 @@ __device__ __forceinline__ void role_landmarks_tp(const View &v, double *lds, co
             }
         __threadfence_block();
         __syncthreads();
+        PV_STAMP(0, 23);
         if (tid < 27 && cur_anchor >= 0) { // the last anchor's own block
             const int b = tid / 9, el = tid - 9 * b, i = el / 3, j = el - 3 * i, A = cur_anchor;
             const double val = ds_anchor(b)[el];

@@ -255,8 +255,11 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st, bool ma
     }
     dm.n_chunks = (int)chunk_lm.size() - 1;
     dm.G_lm = std::max(1, std::min(dm.n_chunks, lm_cus));
-    // A workgroup that walks many chunks spends its time in the Schur outer products: those go to the matrix cores then
-    dm.lm_mm = lin_mode_ == 2 || (lin_mode_ == 0 && dm.n_chunks > 2 * dm.G_lm);
+    // Large windows take the throughput role (ba_lin_tp.h: chunks of 256 factors walked by workgroups that keep their accumulators, Schur complement on the
+    // matrix cores); its prologue + flush + first chunk cost ~30 us whatever the window, the register-tile role's time grows with the landmarks per workgroup:
+    // same-box A/B over 6 .. 24 frames (profiles/r6_lin_mode_ab.txt): they cross at ~40 000 factors (10 x 5000: 35.7 -> 32.4 us, 10 x 10 000: 66.7 -> 40.2 us,
+    // 16 x 3000: 48.4 -> 41.0 us; 10 x 3000: 28.1 against 31.3 us, 6 x 3000: 24.5 against 34.5 us)
+    dm.lm_mm = lin_mode_ == 2 || (lin_mode_ == 0 && F >= 40000);
     // Large windows (ba_lin_tp.h): chunks of <= 256 factors whose landmarks share ONE anchor frame (a chunk is cut where the anchor changes: the
     // reference's block order is anchor-sorted, any other order only makes more chunks), as many landmarks as the LDS holds U rows for; every
     // chunk's factors sorted by target frame (the direct part of J^T J is accumulated per target)

@@ -19,5 +19,7 @@ for n, m in cfgs:
         t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8], t[9], wall_us, t[9] / wall_us if wall_us > 0 else 0), flush=True)
     print('  last chunk: E %d  D %d  L %d  P %d  S %d ticks;  chunks of workgroup 0: (start of last chunk - prologue) / chunk = ?' % (t[3] - t[2], t[4] - t[3], t[5] - t[4], t[6] - t[5], t[7] - t[6]))
     print('  flush detail: table requested %d  sums stored in LDS (2 barriers) %d  subs added %d  DS written %d' % (t[18] - t[7], t[20] - t[18], t[19] - t[20], t[14] - t[19]))
+    if t[21]:
+        print('  flush straight to the row (many frames): vectors + row zeroed %d  tiles scattered %d  direct blocks %d  anchor block + scalars %d' % (t[21] - t[14], t[22] - t[21], t[23] - t[22], t[8] - t[23]))
     print('  flush: task sums in LDS %d | first pass: tiles scattered %d  direct blocks added %d  row written %d | flushed %d' % (t[14] - t[7], t[15] - t[14], t[16] - t[15], t[17] - t[16], t[8] - t[7]))
     ctx.close()
