@@ -11,17 +11,20 @@
 //                   Thread tasks (target t, 3 x 3 block b) walk the chunk's factors of THEIR target in a fixed order (a per-chunk permutation by target, built
 //                   by the host at upload), tasks (anchor block b) walk all of the chunk's factors; the 9 sums of a task stay in registers for the WHOLE chunk
 //                   range of the workgroup; the threads left over split every task into subs
-//   L  per landmark H_ll, b_l, W_a = Jd^T [Jd r Jr] over the landmark's (contiguous) factor rows: thread = (landmark, column)
+//   L  per landmark H_ll, b_l, W_a = Jd^T [Jd r Jr] over the landmark's (contiguous) factor rows: thread = (landmark, column[, part]: chunks of few landmarks deal a
+//                   landmark's factors to 2 or 4 lanes, joined by DPP)
 //   P  scalars      Jacobi scale, dogleg diagonal, Schur weight; W_a and b_l complete the U row; the per-landmark outputs k_backsub needs
 //   S  Schur        - sum_l w_l u_l u_l^T as a SYRK on the matrix cores, 16 x 16 tiles of the lower block triangle in accumulator registers for the whole
 //                   walk; b_l rides along as column 6 N of the U row, so the row 6 N of the product is the Schur right-hand side
-//   A chunk passes four barriers; the inputs of chunk k + 1 (factor and landmark arrays: two dependent trips to HBM) are requested while chunk k is in D .. S.
+//   A chunk passes four barriers; the inputs of chunk k + 1 (its 32-byte geometry record, then the factor and landmark arrays: two dependent trips to HBM) are
+//   requested while chunk k is in E .. S.  N <= 10: two workgroups share a CU (80 KB of LDS, 256 registers each).
 //   flush           once per workgroup (and at an anchor change): accumulators -> the element-major 3 x 3-task partial row the other form writes, through a
-//                   scatter table of the tile entries built at upload
+//                   scatter table of the tile entries built at upload; staged in LDS when the row fits it, straight to the row in HBM otherwise (N > ~20)
 //
 // Sums are taken in fixed orders (no floating-point atomics): re-solves are bit-identical.
 //
-// LDS after the common part (doubles):  X [256][28] | U [2][S][US] | LMR [S][8] | small per-chunk tables; a flush reuses X .. LMR as its stage
+// LDS after the common part (doubles):  X [256][28] | U [S][US] | LMR [S][8] | small per-chunk tables; a flush reuses X .. LMR as its stage
+// Measured per phase (shader-clock stamps, tests/prof_large_tp.py): DESIGN.md 7.4.
 #pragma once
 
 // (the LDS geometry -- kTpXCols, tp_u_stride, tp_lds_doubles ... -- is in ba_types.h: the host sizes chunks and the launch with it)
@@ -460,7 +463,7 @@ __device__ __forceinline__ void role_landmarks_tp(const View &v, double *lds, co
         if (ck + 1 < ck_end) request2(ng);
         __syncthreads();
         PV_STAMP(0, 6);
-        // ---- S: Schur complement on the matrix cores; beside it the next chunk's landmark tables and the other U buffer's clear ----
+        // ---- S: Schur complement on the matrix cores; behind it the next chunk's landmark tables (nothing reads the current ones any more) ----
         for (int s0 = 0; s0 < ns; s0 += 4) {
             const int row = s0 + lk; // rows past ns are zero (phase P), their weight is read as 0
             const double nw = row < ns ? -LMR[(size_t)row * kTpLmr] : 0.0;
