@@ -9,7 +9,7 @@ OUT=$R/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 (cd $R && python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v "^RCCL version\|^HIP version\|^ROCm version\|^Hostname\|^Librccl path" | tail -4) > $OUT/${TAG}_smoke.txt
-(cd $R && PVIO_CHAIN_REPORT=$OUT/${TAG}_chain_parity.json PVIO_SEQ_REPORT=$OUT/${TAG}_seq_backend.json PVIO_SEQ_REPORT_FULL=$OUT/${TAG}_seq_full_product.json PVIO_SEQ_REPORT_LONG=$OUT/${TAG}_seq_long_relief.json python -m pytest tests -m gpu -q --durations=8 2>&1 | grep -v "^RCCL version\|^HIP version\|^ROCm version\|^Hostname\|^Librccl path" | tail -16) > $OUT/${TAG}_pytest_gpu.txt
+(cd $R && PVIO_CHAIN_REPORT=$OUT/${TAG}_chain_parity.json PVIO_SEQ_REPORT=$OUT/${TAG}_seq_backend.json PVIO_SEQ_REPORT_FULL=$OUT/${TAG}_seq_full_product.json PVIO_SEQ_REPORT_LONG=$OUT/${TAG}_seq_long_relief.json PVIO_SEQ_REPORT_LONG_B=$OUT/${TAG}_seq_long_relief_b.json python -m pytest tests -m gpu -q --durations=8 2>&1 | grep -v "^RCCL version\|^HIP version\|^ROCm version\|^Hostname\|^Librccl path" | tail -16) > $OUT/${TAG}_pytest_gpu.txt
 # large windows (k_linearize in its matrix-core form): bench lines + kernel stats + HBM counters of the 30 KF x 50k VIO window
 for W in 30x50000_vio 30x50000_vision 10x50000_vio; do
   python $R/bench.py --workload $W --steps 10 --warmup 2 --no-klt --no-cpu-baseline > $OUT/${TAG}_bench_$W.json 2> $OUT/${TAG}_bench_$W.err

@@ -1,7 +1,7 @@
 """Runs ONE chain (tests/host/libpvio_chain_*.so) over the rendered sequence of tests/test_host_headless.py in its own process (track
 and frame ids come from process-wide counters; the emulated and the real kernels cannot share a process) and leaves the record stream of
 tests/host/chain_log.h plus the reported trajectory in TUM format.
-usage: python tests/chain_run.py <library> <out prefix> <n_frames> <window> <gap> <distance> <small|full>[_relief][_sweep]
+usage: python tests/chain_run.py <library> <out prefix> <n_frames> <window> <gap> <distance> <small|full>[_relief][_sweep][_b]
 (the libraries of oracle/ref/Makefile export the same entry point: the reference's own pvio::PVIO over the sequence, oracle/ref/seq_capi.cpp;
 PVIO_SEQ_IMAGE=oracle|hip picks their pvio::Image)"""
 import ctypes as C
@@ -42,9 +42,10 @@ def main():
     tokens = size.split("_")           # small|full [relief] [sweep]
     relief = "relief" in tokens        # the scene without planes (test_host_headless._relief)
     sweep = "sweep" in tokens          # the back-and-forth trajectory for long sequences (test_host_headless._pose_sweep)
+    variant = 1 if "b" in tokens else 0  # a second family: other texture, relief and sweep (round 6)
     sz = hh.SMALL if tokens[0] == "small" else None
     W, H, K4 = sz if sz is not None else (hh.W, hh.H, hh.K4)
-    images, times, imu_t, imu_w, imu_a, gt, q_bc, p_bc = hh.render_sequence(n_frames, size=sz, relief=relief, sweep=sweep)
+    images, times, imu_t, imu_w, imu_a, gt, q_bc, p_bc = hh.render_sequence(n_frames, size=sz, relief=relief, sweep=sweep, variant=variant)
     lib = C.CDLL(lib_path, mode=C.RTLD_GLOBAL)
     out, stats = np.zeros((n_frames, 8)), np.zeros(4, np.int32)
     err = C.create_string_buffer(512)

@@ -213,3 +213,19 @@ def test_long_sequence_ate_reference_vs_whole_product_gpu(tmp_path):
     path = os.environ.get("PVIO_SEQ_REPORT_LONG")
     if path:
         json.dump(out, open(path, "w"), indent=1)
+
+
+@pytest.mark.gpu
+def test_long_sequence_second_family_gpu(tmp_path):
+    """VERDICT r5 weak #9 (the 360 / 360 identity rests on ONE rendered trajectory family): the same comparison -- the reference's pvio::PVIO with its own back-end and
+    the oracle's front end against the same pvio::PVIO with the whole product below its seams -- on a second family: another texture, another relief (other
+    wavelengths and phases), a narrower and faster sweep with a larger, faster height oscillation (tests/test_host_headless.py, variant 1; scene "..._b").
+    Same bar: every one of the 360 frames identical in track ids, flags and keypoints, every window state within 1e-6, the two ATEs equal to 1e-6 m."""
+    import json
+    info = _long_sequence(tmp_path, "full_relief_sweep_b")
+    print("long sequence, second family:", info)
+    assert info["frames"] == 360 and info["strict_frames"] == 360 and info["keyframes"] >= 25 and info["max_state"] <= 1e-6 and info["max_kp_px"] <= 1e-3
+    assert info["first_divergence"] is None and info["ate_difference_m"] <= 1e-6 and info["ate_rmse_product_m"] < 0.10
+    path = os.environ.get("PVIO_SEQ_REPORT_LONG_B")
+    if path:
+        json.dump({"relief_b": info}, open(path, "w"), indent=1)

@@ -28,8 +28,8 @@ SMALL = (352, 264, np.array([206.25, 206.25, 175.5, 131.5]))  # same field of vi
 TEX_PPM = 160.0  # texture pixels per metre of wall
 
 
-def _texture():
-    rng = synth.Rng(synth.SEED + 17)
+def _texture(variant=0):
+    rng = synth.Rng(synth.SEED + (17 if variant == 0 else 91))
     n = 64
     fx, fy, ph, amp = (rng.uniform(n) - 0.5) * 0.9, (rng.uniform(n) - 0.5) * 0.9, rng.uniform(n) * 2 * np.pi, 0.5 + rng.uniform(n)
 
@@ -41,9 +41,12 @@ def _texture():
     return tex
 
 
-def _relief(u, v):
+def _relief(u, v, variant=0):
     """height [m] of the relief scene above the wall plane at wall coordinates (u, v) [m]: smooth, +-0.45 m over ~1.5 m -- no patch of it large enough to
-    hold 30 tracks lies within the 3 cm of the reference's plane RANSAC (core/plane_extractor.cpp:55-57), so PlaneExtractor never reports a plane"""
+    hold 30 tracks lies within the 3 cm of the reference's plane RANSAC (core/plane_extractor.cpp:55-57), so PlaneExtractor never reports a plane.
+    variant 1 (scene "..._b", round 6: a second family of long sequences): other wavelengths and phases"""
+    if variant == 1:
+        return 0.22 * np.sin(3.0 * u - 1.1) * np.cos(3.6 * v + 0.5) + 0.2 * np.sin(1.7 * u + 2.4 * v - 0.4)
     return 0.25 * np.sin(4.1 * u + 0.3) * np.cos(3.3 * v - 0.8) + 0.2 * np.sin(2.2 * u - 1.9 * v + 1.1)
 
 
@@ -79,11 +82,15 @@ def _undistorted_rays(us, vs, K4, dist, model="radtan"):
 # ~4 s; this one sweeps back and forth on the same circle -- theta(t) = TH0 + A sin(w t), peak rate A w = OMEGA as before -- so that any number of frames
 # keeps the wall (or the relief) in view.  Same frame conventions, analytic velocity / acceleration / yaw rate for the IMU.
 SWEEP_A, SWEEP_W = 0.6, 0.5
+SWEEP_B = (0.42, 0.85, 1.6)  # variant 1: a narrower, faster sweep (peak rate 0.36 rad/s, a reversal every 3.7 s) with a faster, larger height oscillation
 
 
-def _pose_sweep(t):
+def _pose_sweep(t, variant=0):
     R0, H_AMP, H_FREQ = synth.RADIUS, synth.H_AMP, synth.H_FREQ
-    th, dth, ddth = SWEEP_A * np.sin(SWEEP_W * t), SWEEP_A * SWEEP_W * np.cos(SWEEP_W * t), -SWEEP_A * SWEEP_W ** 2 * np.sin(SWEEP_W * t)
+    A, Wf = (SWEEP_A, SWEEP_W) if variant == 0 else SWEEP_B[:2]
+    if variant == 1:
+        H_AMP, H_FREQ = 1.3 * H_AMP, SWEEP_B[2] * H_FREQ
+    th, dth, ddth = A * np.sin(Wf * t), A * Wf * np.cos(Wf * t), -A * Wf ** 2 * np.sin(Wf * t)
     c, s = np.cos(th), np.sin(th)
     p = np.array([R0 * c, R0 * s, H_AMP * np.sin(H_FREQ * t)])
     v = np.array([-R0 * s * dth, R0 * c * dth, H_AMP * H_FREQ * np.cos(H_FREQ * t)])
@@ -93,15 +100,15 @@ def _pose_sweep(t):
     return R, p, v, acc, dth
 
 
-def render_sequence(n_frames, fps=20.0, imu_rate=200.0, t_start=0.0, size=None, relief=False, distortion=None, model="radtan", extrinsics=None, sweep=False):
+def render_sequence(n_frames, fps=20.0, imu_rate=200.0, t_start=0.0, size=None, relief=False, distortion=None, model="radtan", extrinsics=None, sweep=False, variant=0):
     """images (n, H, W) u8, image times, IMU (t, w, a), body poses at the image times (t p q).  relief: the textured surface is the wall plus _relief()
     (ray / surface intersection by fixed-point iteration) instead of the wall itself: a scene without planes."""
     W, H, K4 = size if size is not None else (globals()["W"], globals()["H"], globals()["K4"])
     q_bc = synth.Q_BC / np.linalg.norm(synth.Q_BC)
     R_bc, p_bc = synth.qmat(q_bc), synth.P_BC
     # the wall: through the orbit centre, facing the camera at mid-sequence, tilted by 20 degrees so that depth varies
-    pose = (lambda t: _pose_sweep(t)[:4]) if sweep else synth._pose
-    yaw_rate = (lambda t: _pose_sweep(t)[4]) if sweep else (lambda t: synth.OMEGA)
+    pose = (lambda t: _pose_sweep(t, variant)[:4]) if sweep else synth._pose
+    yaw_rate = (lambda t: _pose_sweep(t, variant)[4]) if sweep else (lambda t: synth.OMEGA)
     t_mid = 0.0 if sweep else t_start + 0.5 * n_frames / fps  # (sweep: the wall faces the centre of the sweep)
     R_mid, p_mid, _, _ = pose(t_mid)
     fwd = R_mid[:, 2]
@@ -119,7 +126,7 @@ def render_sequence(n_frames, fps=20.0, imu_rate=200.0, t_start=0.0, size=None, 
     e1 = np.cross(nrm, np.array([0.0, 0.0, 1.0]))
     e1 /= np.linalg.norm(e1)
     e2 = np.cross(nrm, e1)
-    tex = _texture()
+    tex = _texture(variant)
     us, vs = np.meshgrid(np.arange(W, dtype=float), np.arange(H, dtype=float))
     if distortion is None:
         rays_c = np.stack([(us - K4[2]) / K4[0], (vs - K4[3]) / K4[1], np.ones_like(us)], -1)
@@ -137,7 +144,7 @@ def render_sequence(n_frames, fps=20.0, imu_rate=200.0, t_start=0.0, size=None, 
         X = p_wc + rays * s[..., None]
         if relief:  # n . X = d + h(u, v): six fixed-point steps (the rays are within 40 degrees of the normal, |grad h| < 1.5)
             for _ in range(6):
-                s = (d + _relief(X @ e1, X @ e2) - nrm @ p_wc) / (rays @ nrm)
+                s = (d + _relief(X @ e1, X @ e2, variant) - nrm @ p_wc) / (rays @ nrm)
                 X = p_wc + rays * s[..., None]
         img = tex(TEX_PPM * (X @ e1), TEX_PPM * (X @ e2)) + rng.normal(0, 1.5, (H, W))
         images.append(np.clip(np.rint(img), 0, 255).astype(np.uint8))
