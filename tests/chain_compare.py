@@ -275,7 +275,13 @@ def compare_seq(log_ref, log_dropin, fx, kp_px=2.0e-3, allow_divergence=False, p
                 assert dp <= SEQ_STATE, "frame %d: plane parameters differ by %.3g" % (frame, dp)
             info["planes_seen"] = max(info["planes_seen"], P)
             info["window_records"] += 1
-            info["keyframes"] += int(Ia[2 + 4 * (N - 1) + 1])
+            is_kf = int(Ia[2 + 4 * (N - 1) + 1])
+            info["keyframes"] += is_kf
+            # keyframe windows that carry plane-distance factors: a plane with >= 20 tracks (bundle_adjustor.cpp:180-195); identical on both sides (ints are compared above)
+            sizes = [int(Ia[2 + 4 * N + 1 + 2 * k + 1]) for k in range(P)]
+            if is_kf and any(t >= 20 for t in sizes):
+                info["keyframes_with_plane_factors"] = info.get("keyframes_with_plane_factors", 0) + 1
+            info["largest_plane_tracks"] = max(info.get("largest_plane_tracks", 0), max(sizes, default=0))
             info["strict_frames"] = frame + 1
     assert info["max_kp_px"] <= kp_px, "tracked keypoints differ by %.3g px" % info["max_kp_px"]
     assert allow_divergence or info["first_divergence"] is None, info["first_divergence"]
