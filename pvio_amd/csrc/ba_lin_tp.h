@@ -451,7 +451,7 @@ __device__ __forceinline__ void role_landmarks_tp(const View &v, double *lds, co
             Us[P6] = b; // row 6 N of the SYRK below: - sum_l w_l b_l u_l = - the Schur right-hand side
             // the blocks of the frames that do not see the landmark: whatever the last chunk left there
             const unsigned unseen = ~((unsigned)seen_e[tid] | (1u << a)) & (N >= 32 ? 0xffffffffu : (1u << N) - 1u);
-            for (int f = 0; unseen >> f; ++f) // (nothing to do for a landmark every frame sees)
+            for (int f = 0; f < N && unseen != 0u; ++f) // (nothing to do for a landmark every frame sees; f < N also bounds the shift: N may be 32)
                 if ((unseen >> f) & 1u) {
 #pragma unroll
                     for (int k = 0; k < 6; ++k) Us[6 * f + k] = 0.0;

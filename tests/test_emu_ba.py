@@ -205,6 +205,9 @@ MM_CASES = {
     "vio_duplicate_blocks": ba_compare.CASES["vio_duplicate_blocks"],
     "vision_30x90_two_direct_tasks_per_thread": dict(n_frames=30, n_landmarks=90, visibility=11),
     "vio_8x400_full_chunks": dict(n_frames=8, n_landmarks=400, use_inertial=True, visibility=3),
+    # 32 frames: 91 tiles (23 per wave), the frame mask of a landmark uses all 32 bits -- the walk over its unseen frames once shifted by 32 (a hang on the GPU,
+    # a crash in the emulator: found by an edge-case run, fixed before it shipped)
+    "vision_32x70_partial_visibility": dict(n_frames=32, n_landmarks=70, visibility=10),
 }
 
 

@@ -167,14 +167,16 @@ def gpu_ctx_tp():
 
 
 @pytest.mark.parametrize("name", ["vio_duplicate_blocks", "vision_30x90_two_direct_tasks_per_thread", "vio_8x400_full_chunks", "vio_10x200_anchor_changes",
-                                  "vision_16x120_twelve_tiles_per_wave", "vio_4x150"])
+                                  "vision_16x120_twelve_tiles_per_wave", "vio_4x150", "vision_32x70_partial_visibility", "vio_32x60_partial_visibility"])
 def test_gpu_large_window_role_matches_oracle(gpu_ctx_tp, oracle, name):
     """the emulator's cases of tests/test_emu_ba.py (duplicate blocks; 30 frames: two direct tasks per thread, twenty tiles per wave; chunks of 64
     landmarks; anchor flushes; ...) on the GPU, per iteration against the oracle"""
     kw = {"vio_duplicate_blocks": ba_compare.CASES["vio_duplicate_blocks"], "vision_30x90_two_direct_tasks_per_thread": dict(n_frames=30, n_landmarks=90, visibility=11),
           "vio_8x400_full_chunks": dict(n_frames=8, n_landmarks=400, use_inertial=True, visibility=3),
           "vio_10x200_anchor_changes": dict(n_frames=10, n_landmarks=200, use_inertial=True, visibility=5),
-          "vision_16x120_twelve_tiles_per_wave": dict(n_frames=16, n_landmarks=120, visibility=9), "vio_4x150": dict(n_frames=4, n_landmarks=150, use_inertial=True, visibility=3)}[name]
+          "vision_16x120_twelve_tiles_per_wave": dict(n_frames=16, n_landmarks=120, visibility=9), "vio_4x150": dict(n_frames=4, n_landmarks=150, use_inertial=True, visibility=3),
+          # 32 frames: every bit of a landmark's frame mask in use (tests/test_emu_ba.py: the unseen-frame walk once shifted by 32)
+          "vision_32x70_partial_visibility": dict(n_frames=32, n_landmarks=70, visibility=10), "vio_32x60_partial_visibility": dict(n_frames=32, n_landmarks=60, use_inertial=True, visibility=8)}[name]
     print(name, ba_compare.check_against_oracle(gpu_ctx_tp, oracle, ba_compare.make(oracle, **kw)))
 
 
