@@ -239,6 +239,14 @@ def test_emulated_large_window_role_with_unsorted_anchors_and_a_fixed_frame(emu_
     ba_compare.check_against_oracle(emu_ctx_mm, oracle, pb3)
 
 
+@pytest.mark.parametrize("n", [2, 3, 10, 11, 15, 16, 22, 23, 27, 28, 31, 32])
+def test_emulated_large_window_role_at_the_boundaries_of_its_geometry_classes(emu_ctx_mm, oracle, n):
+    """frame counts on both sides of every switch of the role's compile-time geometry (tiles per wave 3 | 6 | 12 | 17 | 20 | 23, one | two direct tasks per thread) and
+    of its U row width: two iterations against the oracle"""
+    pb = ba_compare.make(oracle, n_frames=n, n_landmarks=30 + 2 * n, use_inertial=(n % 2 == 0), visibility=max(2, min(n, 3 + n // 4)), seed=300 + n, max_iterations=2)
+    ba_compare.check_against_oracle(emu_ctx_mm, oracle, pb)
+
+
 @pytest.mark.parametrize("victim", [0, 2, 5])
 def test_emulated_mfma_tile_marginalization_matches_oracle(emu_ctx_mm, oracle, victim):
     import marg_compare

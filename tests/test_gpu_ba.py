@@ -232,6 +232,23 @@ def test_gpu_large_window_role_is_deterministic_and_reads_nothing_stale(gpu_ctx_
     np.testing.assert_allclose(ref[1], st0.lm_inv_depth, rtol=0, atol=1e-6)
 
 
+def test_gpu_large_window_role_for_every_frame_count(oracle):
+    """2 .. 32 frames through the large-window role: every class of its compile-time geometry (accumulator tiles per wave 3 / 6 / 12 / 17 / 20 / 23, one or two direct
+    tasks per thread, U rows of 16 .. 208 doubles, one or two workgroups per CU) and every LDS size it asks for must launch and agree with the register-tile role
+    (the 32-frame case once hung: see tests/test_emu_ba.py MM_CASES)."""
+    from pvio_amd.solver import HipContext
+    c1, c2 = HipContext(device=0, linearize_mode=1), HipContext(device=0, linearize_mode=2)
+    for n in range(2, 33):
+        vio = n % 3 != 0
+        pb = ba_compare.make(oracle, n_frames=n, n_landmarks=60 + 5 * n, use_inertial=vio, visibility=max(2, min(n, 3 + n // 3)), seed=100 + n)
+        (s1, m1), (s2, m2) = c1.solve(pb), c2.solve(pb)
+        t1, t2 = m1.trace(), m2.trace()
+        assert len(t1) == len(t2) and all((a["step_is_valid"], a["step_is_successful"]) == (b["step_is_valid"], b["step_is_successful"]) for a, b in zip(t1, t2)), n
+        np.testing.assert_allclose(s2.frame_state, s1.frame_state, rtol=0, atol=1e-7, err_msg="%d frames" % n)
+        np.testing.assert_allclose(s2.lm_inv_depth, s1.lm_inv_depth, rtol=0, atol=1e-7, err_msg="%d frames" % n)
+    c1.close(), c2.close()
+
+
 def test_gpu_both_linearize_modes_agree_on_a_large_window(oracle):
     from pvio_amd.solver import HipContext
     pb = ba_compare.make(oracle, n_frames=24, n_landmarks=8000, use_inertial=True, visibility=9)
