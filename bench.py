@@ -25,6 +25,8 @@ Extra objects on the JSON line:
                 factoring launch / its duration against the FP64 peak.
   scaling_window  the 10 KF x 50 000 landmark VIO window (the one north_star states the 8-GPU target on), sharded the
                 same way, a few solves: its iterations/s at this N next to the headline value.
+  reference_window  the window the reference's own configuration solves (8 KF, 300 landmarks seen by 5 frames each, full VIO factor
+                set): iterations/s resident, and the CPU restatement on the same window (2 s sample).
   api           the same window through pvio_hip_ba_solve (upload + iterations + download per solve): the H2D/D2H-inclusive rate.
   cpu_baseline  the CPU oracle (oracle/, a single-threaded restatement of the reference's Ceres path; the real
                 reference cannot be built here) timed on the same window on this box's host cores.
@@ -269,6 +271,43 @@ def bench_concurrent_windows(pb, streams=3, steps=60):
     for c in ctxs:
         c.close()
     return {"streams": streams, "value": sum(iters) / dt, "unit": "iterations/s (aggregate)", "steps_per_stream": steps}
+
+
+def bench_reference_window(preintegrate, cpu_seconds=2.0, steps=100):
+    """BA iterations/s of the window the reference itself solves in a session (config/euroc.yaml: sliding_window_size 8; a few
+    hundred landmarks, each seen by about half of the frames), full VIO factor set, next to the CPU restatement timed on the same
+    window.  Not the headline metric (north_star names the 10 KF x 1000 window): it says what a drop-in user of the reference's
+    own configuration gets."""
+    from pvio_amd import BAState, BASummary, synth
+    from pvio_amd.solver import HipContext
+    pb = synth.make_window(n_frames=8, n_landmarks=300, use_inertial=True, visibility=5, preintegrate=preintegrate)
+    ctx = HipContext(device=0)
+    ctx.upload(pb)
+    sm = BASummary(pb, trace=False)
+    for _ in range(10):
+        ctx.solve_resident(sm)
+    t0, it = time.perf_counter(), 0
+    for _ in range(steps):
+        ctx.solve_resident(sm)
+        it += sm.num_iterations
+    dt = time.perf_counter() - t0
+    ctx.close()
+    out = {"workload": "8 KF x 300 landmarks seen by 5 frames each, full VIO factor set, %d reprojection factors" % pb.n_obs,
+           "value": it / dt, "unit": "iterations/s", "steps": steps, "us_per_solve": dt / steps * 1e6}
+    if cpu_seconds > 0:
+        from oracle import oracle_py as O
+        O.build()
+        c_it, c_t = 0, 0.0
+        O.solve_fast(pb, BAState(pb), BASummary(pb, trace=False))
+        while c_t < cpu_seconds:
+            st, so = BAState(pb), BASummary(pb, trace=False)
+            t1 = time.perf_counter()
+            O.solve_fast(pb, st, so)
+            c_t += time.perf_counter() - t1
+            c_it += so.num_iterations
+        out["cpu_baseline"] = {"value": c_it / c_t, "unit": "BA iterations/s", "cores": 1, "kind": "port", "sample": "%.1f s of solves of the same window" % c_t}
+        out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+    return out
 
 
 def bench_scaling_window(ctx, args, rank, world, dist, barrier, preintegrate, n_frames=10, n_landmarks=50000, steps=10, warmup=2):
@@ -605,6 +644,13 @@ def main():
     if rank == 0 and world == 1 and not args.no_klt:
         multi = bench_concurrent_windows(pb_full)
 
+    ref_window = None
+    if rank == 0 and world == 1 and not args.no_klt and args.workload == "vio":
+        try:
+            ref_window = bench_reference_window(preintegrate, cpu_seconds=0.0 if args.no_cpu_baseline else 2.0)
+        except Exception as e:  # the headline line must still be printed
+            ref_window = {"error": repr(e)}
+
     if rank == 0:
         value = iters / elapsed
         out = {
@@ -627,6 +673,7 @@ def main():
             "klt": klt,
             "concurrent_windows": multi,
             "scaling_window": scaling_window,
+            "reference_window": ref_window,
         }
         if world > 1:
             out["single_gpu_same_workload"] = single_gpu
