@@ -23,7 +23,7 @@
 //
 // Sums are taken in fixed orders (no floating-point atomics): re-solves are bit-identical.
 //
-// LDS after the common part (doubles):  X [256][28] | U [S][US] | LMR [S][8] | small per-chunk tables; a flush reuses X .. LMR as its stage
+// LDS after the common part (doubles):  X [256][14 pairs] (as two halves of 7, ba_types.h) | U [S][tp_u_ld] | LMR [S][kTpLmrLd] (rows padded against bank conflicts, ba_types.h) | small per-chunk tables; a flush reuses X .. LMR as its stage
 // Measured per phase (shader-clock stamps, tests/prof_large_tp.py): DESIGN.md 7.4.
 #pragma once
 
@@ -35,7 +35,7 @@ __device__ __forceinline__ void role_landmarks_tp(const View &v, double *lds, co
     const int lane = tid & 63, wv = tid >> 6, lk = lane >> 4, lr = lane & 15;
     const double *frec = lds + N * 16;
     double *scratch = lds + N * 16 + N * kFrameRec;
-    const int S = (v.dm.lm_slots + 3) & ~3, US = tp_u_stride(P6);
+    const int S = (v.dm.lm_slots + 3) & ~3, US = tp_u_ld(P6); // (US: leading dimension of U, tp_u_stride(P6) columns in use)
     // ---- LDS carve ----
     double *work = lds + common_lds_doubles(N);
     lds_d2 *X2 = reinterpret_cast<lds_d2 *>(work);               // [256][14]
@@ -64,7 +64,7 @@ __device__ __forceinline__ void role_landmarks_tp(const View &v, double *lds, co
     double *pS = v.part_S + (size_t)wg * n_tasks * 9;
 
     // ---- Schur tiles of this wave (lower block triangle of the (6 N + 1)-column system, dealt round-robin to the four waves) ----
-    const int nbt = US >> 4, ntile = (nbt * (nbt + 1)) >> 1;
+    const int nbt = tp_u_stride(P6) >> 4, ntile = (nbt * (nbt + 1)) >> 1;
     mfma_d4 tacc[TW];
     int tile_bb[TW]; // bi << 8 | bj, -1 past the last tile
 #pragma unroll
@@ -82,7 +82,7 @@ __device__ __forceinline__ void role_landmarks_tp(const View &v, double *lds, co
     const int n_dir = kTpDirTasks * N;
     const int nsub = (NDT * kLinThreads - 4 * kTpAnchTasks) / n_dir > 0 ? (NDT * kLinThreads - 4 * kTpAnchTasks) / n_dir : 1;
     const int nsubA = (NDT * kLinThreads - n_dir * nsub) / kTpAnchTasks; // >= 4 for N <= 32 (9 N + 20 <= 512)
-    int d_kind[NDT], d_t[NDT], d_a[NDT], d_b[NDT], d_bs[NDT], d_blk[NDT], d_sub[NDT]; // -1 idle / 0 target / 1 anchor; target; first A column, first B column, its step; block; sub
+    int d_kind[NDT], d_t[NDT], d_a[NDT], d_b[NDT], d_bs[NDT], d_blk[NDT], d_sub[NDT]; // -1 idle / 0 target / 1 anchor; target; first A column, first B column (pair offsets in an X row, tp_xcol), its step; block; sub
     double dacc[NDT][9];
 #pragma unroll
     for (int q = 0; q < NDT; ++q) {
@@ -93,15 +93,15 @@ __device__ __forceinline__ void role_landmarks_tp(const View &v, double *lds, co
             b = task / N;
             d_kind[q] = 0, d_t[q] = task - b * N, d_blk[q] = b, d_sub[q] = u - task * nsub;
             // TT00 TT01 TT11 TR00 TR01 TR10 TR11 g0 g1
-            d_a[q] = (b == 0 || b == 1 || b == 3 || b == 4 || b == 7) ? 0 : 3;
-            d_b[q] = b == 0 ? 0 : (b == 1 || b == 2) ? 3 : (b == 3 || b == 5) ? 6 : (b == 4 || b == 6) ? 9 : 12;
+            d_a[q] = tp_xcol((b == 0 || b == 1 || b == 3 || b == 4 || b == 7) ? 0 : 3);
+            d_b[q] = tp_xcol(b == 0 ? 0 : (b == 1 || b == 2) ? 3 : (b == 3 || b == 5) ? 6 : (b == 4 || b == 6) ? 9 : 12);
             d_bs[q] = b >= 7 ? 0 : 1;
         } else if (ua < kTpAnchTasks * nsubA) {
             b = ua / nsubA;
             d_kind[q] = 1, d_t[q] = -1, d_blk[q] = b, d_sub[q] = ua - b * nsubA;
             // RR00 RR01 RR11 gR0 gR1
-            d_a[q] = (b == 0 || b == 1 || b == 3) ? 6 : 9;
-            d_b[q] = b == 0 ? 6 : (b == 1 || b == 2) ? 9 : 12;
+            d_a[q] = tp_xcol((b == 0 || b == 1 || b == 3) ? 6 : 9);
+            d_b[q] = tp_xcol(b == 0 ? 6 : (b == 1 || b == 2) ? 9 : 12);
             d_bs[q] = b >= 3 ? 0 : 1;
         } else {
             d_kind[q] = -1, d_t[q] = -1, d_blk[q] = 0, d_sub[q] = 0, d_a[q] = 0, d_b[q] = 0, d_bs[q] = 0;
@@ -329,17 +329,17 @@ __device__ __forceinline__ void role_landmarks_tp(const View &v, double *lds, co
                 s_cost += mult * (0.5 * log(1.0 + sq)); // CauchyLoss(1): rho(s) = log(1 + s)
                 s_bad += bad;
             }
-            lds_d2 *x = X2 + (size_t)tid * kTpXCols;
+            lds_d2 *x = X2 + (size_t)tid * kTpXLd;
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
                 lds_d2 p, q;
                 p[0] = Jt[k], p[1] = Jt[6 + k], q[0] = Jr[k], q[1] = Jr[6 + k];
-                x[k] = p, x[6 + k] = q;
+                x[tp_xcol(k)] = p, x[tp_xcol(6 + k)] = q;
             }
             {
                 lds_d2 p, q;
                 p[0] = r[0], p[1] = r[1], q[0] = Jd[0], q[1] = Jd[1];
-                x[12] = p, x[13] = q;
+                x[tp_xcol(12)] = p, x[tp_xcol(13)] = q;
             }
             double *Us = U + (size_t)s * US + 6 * t;
 #pragma unroll
@@ -362,7 +362,7 @@ __device__ __forceinline__ void role_landmarks_tp(const View &v, double *lds, co
                 int i = e0 + d_sub[q];
                 for (; i + step < e1; i += 2 * step) {
                     const int fA = tgt ? perm[i] : i, fB = tgt ? perm[i + step] : i + step;
-                    const lds_d2 *x = X2 + (size_t)fA * kTpXCols, *y = X2 + (size_t)fB * kTpXCols;
+                    const lds_d2 *x = X2 + (size_t)fA * kTpXLd, *y = X2 + (size_t)fB * kTpXLd;
                     const lds_d2 a0 = x[ao], a1 = x[ao + 1], a2 = x[ao + 2], b0 = x[bo], b1 = x[bo + bs], b2 = x[bo + 2 * bs];
                     const lds_d2 c0 = y[ao], c1 = y[ao + 1], c2 = y[ao + 2], d0 = y[bo], d1 = y[bo + bs], d2 = y[bo + 2 * bs];
                     dacc[q][0] += a0[0] * b0[0] + a0[1] * b0[1], dacc[q][1] += a0[0] * b1[0] + a0[1] * b1[1], dacc[q][2] += a0[0] * b2[0] + a0[1] * b2[1];
@@ -373,7 +373,7 @@ __device__ __forceinline__ void role_landmarks_tp(const View &v, double *lds, co
                     dacc[q][6] += c2[0] * d0[0] + c2[1] * d0[1], dacc[q][7] += c2[0] * d1[0] + c2[1] * d1[1], dacc[q][8] += c2[0] * d2[0] + c2[1] * d2[1];
                 }
                 if (i < e1) {
-                    const lds_d2 *x = X2 + (size_t)(tgt ? perm[i] : i) * kTpXCols;
+                    const lds_d2 *x = X2 + (size_t)(tgt ? perm[i] : i) * kTpXLd;
                     const lds_d2 a0 = x[ao], a1 = x[ao + 1], a2 = x[ao + 2], b0 = x[bo], b1 = x[bo + bs], b2 = x[bo + 2 * bs];
                     dacc[q][0] += a0[0] * b0[0] + a0[1] * b0[1], dacc[q][1] += a0[0] * b1[0] + a0[1] * b1[1], dacc[q][2] += a0[0] * b2[0] + a0[1] * b2[1];
                     dacc[q][3] += a1[0] * b0[0] + a1[1] * b0[1], dacc[q][4] += a1[0] * b1[0] + a1[1] * b1[1], dacc[q][5] += a1[0] * b2[0] + a1[1] * b2[1];
@@ -385,7 +385,7 @@ __device__ __forceinline__ void role_landmarks_tp(const View &v, double *lds, co
         // deals a landmark's factors to 2 or 4 adjacent lanes, whose partial sums meet by DPP (fixed order) ----
         {
             const int split = ns <= 8 ? 4 : (ns <= 16 ? 2 : 1); // uniform
-            const int q = tid & (split - 1), sc = tid / split, c = sc & 7, col = c == 0 ? 13 : (c == 1 ? 12 : 4 + c);
+            const int q = tid & (split - 1), sc = tid / split, c = sc & 7, col = tp_xcol(c == 0 ? 13 : (c == 1 ? 12 : 4 + c));
             for (int sb = 0; sb < ns; sb += kLinThreads / (8 * split)) { // (uniform trip count: the DPP exchange below is executed by whole waves)
                 const int s = sb + (sc >> 3);
                 double s0 = 0.0, s1 = 0.0;
@@ -393,20 +393,20 @@ __device__ __forceinline__ void role_landmarks_tp(const View &v, double *lds, co
                     const int f0 = fp[s], f1 = fp[s + 1];
                     int f = f0 + q;
                     for (; f + split < f1; f += 2 * split) {
-                        const lds_d2 *x = X2 + (size_t)f * kTpXCols, *y = x + (size_t)split * kTpXCols;
-                        const lds_d2 jd0 = x[13], y0 = x[col], jd1 = y[13], y1 = y[col];
+                        const lds_d2 *x = X2 + (size_t)f * kTpXLd, *y = x + (size_t)split * kTpXLd;
+                        const lds_d2 jd0 = x[tp_xcol(13)], y0 = x[col], jd1 = y[tp_xcol(13)], y1 = y[col];
                         s0 += jd0[0] * y0[0] + jd0[1] * y0[1], s1 += jd1[0] * y1[0] + jd1[1] * y1[1];
                     }
                     if (f < f1) {
-                        const lds_d2 *x = X2 + (size_t)f * kTpXCols;
-                        const lds_d2 jd0 = x[13], y0 = x[col];
+                        const lds_d2 *x = X2 + (size_t)f * kTpXLd;
+                        const lds_d2 jd0 = x[tp_xcol(13)], y0 = x[col];
                         s0 += jd0[0] * y0[0] + jd0[1] * y0[1];
                     }
                 }
                 double sum = s0 + s1;
                 if (split >= 2) sum += dpp_f64(sum, 0); // lane ^ 1
                 if (split >= 4) sum += dpp_f64(sum, 1); // lane ^ 2
-                if (s < ns && q == 0) LMR[(size_t)s * kTpLmr + c] = sum;
+                if (s < ns && q == 0) LMR[(size_t)s * kTpLmrLd + c] = sum;
             }
         }
         __syncthreads();
@@ -414,7 +414,7 @@ __device__ __forceinline__ void role_landmarks_tp(const View &v, double *lds, co
         // ---- P: per-landmark scalars: Jacobi scale, dogleg diagonal, Schur weight; W_a and b_l complete the U row ----
         if (tid < ns) {
             const int l = l0 + tid;
-            double *W = LMR + (size_t)tid * kTpLmr;
+            double *W = LMR + (size_t)tid * kTpLmrLd;
             const double Hll = W[0], b = W[1];
             const bool used = fp[tid + 1] > fp[tid];
             double cl;
@@ -466,7 +466,7 @@ __device__ __forceinline__ void role_landmarks_tp(const View &v, double *lds, co
         // ---- S: Schur complement on the matrix cores; behind it the next chunk's landmark tables (nothing reads the current ones any more) ----
         for (int s0 = 0; s0 < ns; s0 += 4) {
             const int row = s0 + lk; // rows past ns are zero (phase P), their weight is read as 0
-            const double nw = row < ns ? -LMR[(size_t)row * kTpLmr] : 0.0;
+            const double nw = row < ns ? -LMR[(size_t)row * kTpLmrLd] : 0.0;
             const double *Rl = U + (size_t)row * US + lr;
             constexpr int kOps = TW < 6 ? TW : 6; // operands of a batch are all requested before its first MFMA
 #pragma unroll

@@ -192,16 +192,31 @@ inline int lin_set_stride_M() { return 1; }
 #endif
 constexpr int kTpXCols = 14;   // (row 0, row 1) pairs of a factor row: 0-5 Jt, 6-11 Jr, 12 r, 13 Jd
 constexpr int kTpLmr = 8;      // per-landmark results: 0 H_ll (then the Schur weight w)  1 b_l  2..7 W_a
+// LDS has 32 four-byte banks.  (PVBA_TP_PAD=0 builds the round's first layout for the A/B: X rows of 14 pairs, U rows of 16 k doubles, LMR rows of 8.)
+//  * X rows of 14 pairs = 56 dwords put a given column of ANY row on one of four bank offsets: half the banks are never used by a column, every access where
+//    lanes read one column of different rows takes twice the cycles.  X is therefore kept as TWO arrays of 7 pairs per row (28 dwords: eight offsets, all
+//    banks) -- the same bytes: [Jt 0-5, r] and [Jr 0-5, Jd]; a direct task's column triplets never straddle the two.  tp_xcol(c) = pair offset of column c
+//    from the row's base X2 + row * kTpXLd.
+//  * a U row of 16 k doubles and an LMR row of 8 put every row on the SAME banks (phase P's lane-per-row stores serialize completely): one double of padding.
+// The arithmetic and its order are untouched.
+#ifndef PVBA_TP_PAD
+#define PVBA_TP_PAD 1
+#endif
+constexpr int kTpXLd = PVBA_TP_PAD ? kTpXCols / 2 : kTpXCols; // pairs per X row (of one half)
+constexpr int kTpXHalf = kLinThreads * (kTpXCols / 2);        // pair offset of the second half
+PVBA_HD constexpr int tp_xcol(int c) { return PVBA_TP_PAD ? (c < 6 ? c : (c < 12 ? kTpXHalf + c - 6 : (c == 12 ? 6 : kTpXHalf + 6))) : c; }
+constexpr int kTpLmrLd = kTpLmr + PVBA_TP_PAD;   // doubles per LMR row
 constexpr int kTpDirTasks = 9; // per target: TT00 TT01 TT11 | TR00 TR01 TR10 TR11 | g[0:3] g[3:6]
 constexpr int kTpAnchTasks = 5; // per anchor: RR00 RR01 RR11 | gR[0:3] gR[3:6]
 
 // U rows: 6 N pose columns, then b_l in column 6 N (the row 6 N of the SYRK is then the Schur right-hand side), padded to whole 16 x 16 tiles
 PVBA_HD inline int tp_u_stride(int P6) { return ((P6 + 1 + 15) >> 4) << 4; }
+PVBA_HD inline int tp_u_ld(int P6) { return tp_u_stride(P6) + PVBA_TP_PAD; } // doubles per U row
 PVBA_HD inline int tp_tiles(int P6) { const int nbt = tp_u_stride(P6) >> 4; return (nbt * (nbt + 1)) >> 1; }
 // doubles of LDS the role needs behind the common part: X [256][14 pairs] | U [S][US] | LMR [S][8]; a flush reuses them as its stage
 PVBA_HD inline size_t tp_work_doubles(int N, int P6, int slots, int n_tasks) {
-    const size_t S = (size_t)slots, US = (size_t)tp_u_stride(P6);
-    size_t work = (size_t)kLinThreads * 2 * kTpXCols + S * US + S * kTpLmr;
+    const size_t S = (size_t)slots, US = (size_t)tp_u_ld(P6);
+    size_t work = (size_t)kLinThreads * 2 * kTpXCols + S * US + S * kTpLmrLd;
     const size_t flush = (size_t)2 * n_tasks + 2 * (size_t)kLinThreads * 9 + 64; // a flush: >= two elements of the partial row per pass + the tasks' sums
     return work < flush ? flush : work;
 }
