@@ -337,7 +337,9 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st, bool ma
     dm.G_back = M <= 4096 ? std::max(1, std::min(64, (M + 15) / 16)) : std::min(cus, (M + 63) / 64);
     // (PVIO_HIP_FUSE_BACKSUB=0: tests -- small windows through the separate k_backsub launch, i.e. the split-finalize form)
     static const bool fuse_off = std::getenv("PVIO_HIP_FUSE_BACKSUB") != nullptr && std::atoi(std::getenv("PVIO_HIP_FUSE_BACKSUB")) == 0;
-    dm.fuse_backsub = (!sharded_ && M <= 256 && !fuse_off) ? 1 : 0; // beyond one landmark per thread the separate launch is faster
+    // (PVIO_HIP_FUSE_BACKSUB_MAX: experiments -- the landmark count up to which the back-substitution stays inside k_dense; clamped to 16 .. 4096)
+    static const int fuse_max = std::getenv("PVIO_HIP_FUSE_BACKSUB_MAX") ? std::min(4096, std::max(16, std::atoi(std::getenv("PVIO_HIP_FUSE_BACKSUB_MAX")))) : 256;
+    dm.fuse_backsub = (!sharded_ && M <= fuse_max && !fuse_off) ? 1 : 0; // beyond one landmark per thread the separate launch is faster
     dm.n_back_rows = (sharded_ || dm.fuse_backsub) ? 1 : dm.G_back;
 
     // 3x3 tile tasks over the upper block triangle
