@@ -259,7 +259,7 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st, bool ma
     // matrix cores); its prologue + flush + first chunk cost ~30 us whatever the window, the register-tile role's time grows with the landmarks per workgroup:
     // same-box A/B over 6 .. 24 frames (profiles/r6_lin_mode_ab.txt): they cross at ~40 000 factors (10 x 5000: 35.7 -> 32.4 us, 10 x 10 000: 66.7 -> 40.2 us,
     // 16 x 3000: 48.4 -> 41.0 us; 10 x 3000: 28.1 against 31.3 us, 6 x 3000: 24.5 against 34.5 us)
-    dm.lm_mm = lin_mode_ == 2 || (lin_mode_ == 0 && F >= 40000);
+    dm.lm_mm = (lin_mode_ == 2 && M > 0) || (lin_mode_ == 0 && F >= 40000); // (a window without landmarks has no chunks: the register-tile role's empty walk handles it)
     // Large windows (ba_lin_tp.h): chunks of <= 256 factors whose landmarks share ONE anchor frame (a chunk is cut where the anchor changes: the
     // reference's block order is anchor-sorted, any other order only makes more chunks), as many landmarks as the LDS holds U rows for; every
     // chunk's factors sorted by target frame (the direct part of J^T J is accumulated per target)
@@ -328,7 +328,7 @@ int BASolver::upload(const pvio_ba_problem *pb, const pvio_ba_state *st, bool ma
     // pvio_hip_opts::reuse_identical_candidates.  Not on landmark shards: their k_reduce feeds an all-reduce that sums IN PLACE, a skipped slot
     // would add the last slot's sums to themselves.
     dm.reuse_cand = (reuse_cand_ && !sharded_) ? 1 : 0;
-    if (dm.lm_mm) { // contiguous chunk ranges (a range mostly shares one anchor frame): no more workgroups than ranges
+    if (dm.lm_mm && dm.n_chunks > 0) { // contiguous chunk ranges (a range mostly shares one anchor frame): no more workgroups than ranges
         const int per_wg = (dm.n_chunks + dm.G_lm - 1) / dm.G_lm;
         dm.G_lm = std::max(1, (dm.n_chunks + per_wg - 1) / per_wg);
     }

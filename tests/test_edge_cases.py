@@ -87,6 +87,67 @@ def test_emulated_edge_case_matches_oracle(emu_ctx, oracle, name):
     print(name, ba_compare.check_against_oracle(emu_ctx, oracle, _cases(oracle)[name]))
 
 
+@pytest.fixture(scope="module")
+def emu_ctx_tp():
+    subprocess.check_call(["make", "-s", "-C", EMU_DIR, "libpvio_hipemu.so"])
+    ctx = HipContext(lib=capi.load(os.path.join(EMU_DIR, "libpvio_hipemu.so")), linearize_mode=2)
+    yield ctx
+    ctx.close()
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_emulated_edge_case_through_the_large_window_role(emu_ctx_tp, oracle, name):
+    """linearize_mode 2 forced on the degenerate shapes (round 6: a window WITHOUT landmarks has no chunks -- upload() divided by the chunk count; such a
+    window takes the register-tile role's empty walk now)."""
+    print(name, ba_compare.check_against_oracle(emu_ctx_tp, oracle, _cases(oracle)[name]))
+
+
+def _sparse_cases(oracle):
+    out = {"one_landmark": ba_compare.make(oracle, n_frames=4, n_landmarks=1), "one_landmark_vio": ba_compare.make(oracle, n_frames=3, n_landmarks=1, use_inertial=True)}
+    pb = ba_compare.make(oracle, n_frames=6, n_landmarks=40, visibility=4)  # landmarks without observations at the ends and in the middle of a chunk
+    counts = np.diff(pb.lm_obs_ptr).copy()
+    kill = np.zeros(len(counts), bool)
+    kill[[0, 7, 8, 20, 39]] = True
+    keep = np.repeat(~kill, counts)
+    pb.obs_frame, pb.obs_z = pb.obs_frame[keep], pb.obs_z[keep]
+    counts[kill] = 0
+    pb.lm_obs_ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+    out["empty_landmarks"] = pb
+    pb = ba_compare.make(oracle, n_frames=4, n_landmarks=12, use_inertial=True)  # chunks, but not a single factor
+    pb.obs_frame, pb.obs_z = pb.obs_frame[:0], pb.obs_z[:0]
+    pb.lm_obs_ptr = np.zeros(len(pb.lm_obs_ptr), np.int32)
+    out["all_landmarks_empty_vio"] = pb
+    return out
+
+
+SPARSE = ["one_landmark", "one_landmark_vio", "empty_landmarks", "all_landmarks_empty_vio"]
+
+
+@pytest.mark.parametrize("name", SPARSE)
+def test_emulated_large_window_role_on_nearly_empty_windows(emu_ctx_tp, oracle, name):
+    print(name, ba_compare.check_against_oracle(emu_ctx_tp, oracle, _sparse_cases(oracle)[name]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", SPARSE)
+def test_gpu_large_window_role_on_nearly_empty_windows(oracle, name):
+    ctx = HipContext(device=0, linearize_mode=2)
+    try:
+        print(name, ba_compare.check_against_oracle(ctx, oracle, _sparse_cases(oracle)[name]))
+    finally:
+        ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES)
+def test_gpu_edge_case_through_the_large_window_role(oracle, name):
+    ctx = HipContext(device=0, linearize_mode=2)
+    try:
+        print(name, ba_compare.check_against_oracle(ctx, oracle, _cases(oracle)[name]))
+    finally:
+        ctx.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", NAMES)
 def test_gpu_edge_case_matches_oracle(oracle, name):
