@@ -8,6 +8,7 @@ STATE_TOL = 1e-6
 
 CASES = {
     "vision_small": dict(n_frames=4, n_landmarks=30),
+    "vio_five_landmarks": dict(n_frames=4, n_landmarks=5, use_inertial=True),  # sharded over 8 ranks: three ranks without a landmark
     "vision_partial": dict(n_frames=6, n_landmarks=40, visibility=3),
     "vio_small": dict(n_frames=4, n_landmarks=30, use_inertial=True),
     "vio_partial": dict(n_frames=6, n_landmarks=40, use_inertial=True, visibility=4),

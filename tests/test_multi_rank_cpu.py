@@ -18,6 +18,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.parametrize("case,world,mode", [("vio_plane", 2, 0), ("vision_partial", 3, 0), ("vio_partial", 2, 2),
                                              ("vio_partial", 4, 0), ("vio_partial", 8, 0), ("vio_13_frames_global_matrix", 2, 0),
                                              ("vio_duplicate_blocks", 2, 2),
+                                             # round 6: ranks WITHOUT a landmark (5 landmarks over 8 ranks), both landmark roles
+                                             ("vio_five_landmarks", 8, 0), ("vio_five_landmarks", 8, 2),
                                              # round 3 (the emulator got fast enough): the metric window on four ranks, rejected steps /
                                              # the bias quirk / rotation priors on shards, the 20-frame HBM-matrix window on three
                                              ("metric_10x1000_vio", 4, 0), ("vio_zero_bias_quirk", 2, 0), ("config1_10x200", 3, 0),
