@@ -54,8 +54,9 @@ def test_sharded_solve_matches_oracle(oracle, case, world, mode):
                 np.testing.assert_allclose(z["marg_iv"], iv0, rtol=1e-5, atol=1e-6 * np.abs(iv0).max())
 
 
-@pytest.mark.parametrize("case,world", [("vio_partial", 2), ("vio_plane", 4), ("config1_10x200", 8)])
-def test_sharded_graph_replay_with_captured_collectives(oracle, case, world):
+# (mode 2: the large-window landmark role on the shards -- what bench.py's sharded 10 KF x 50 000 leg runs inside the captured graph)
+@pytest.mark.parametrize("case,world,mode", [("vio_partial", 2, 0), ("vio_plane", 4, 0), ("config1_10x200", 8, 0), ("vio_partial", 2, 2), ("config1_10x200", 4, 2)])
+def test_sharded_graph_replay_with_captured_collectives(oracle, case, world, mode):
     """the landmark-sharded iteration inside the slot GRAPH -- kernels and both all-reduces captured (the emulator's stream
     capture records the collective as a node, as RCCL's does) -- replayed with more than one rank: every replay equals the eager solve of the
     same shards bit for bit on every rank, and the oracle within 1e-6."""
@@ -66,7 +67,7 @@ def test_sharded_graph_replay_with_captured_collectives(oracle, case, world):
     with tempfile.TemporaryDirectory() as d:
         port = 29500 + ((os.getpid() + 13 * world) % 2000)
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
-               "--master-port", str(port), os.path.join(ROOT, "tests", "multi_rank_worker.py"), d, case + "@graph", "0"]
+               "--master-port", str(port), os.path.join(ROOT, "tests", "multi_rank_worker.py"), d, case + "@graph", str(mode)]
         subprocess.run(cmd, check=True, timeout=600, env=dict(os.environ, OMP_NUM_THREADS="1"), capture_output=True)
         for r in range(world):
             z = np.load(os.path.join(d, "rank%d.npz" % r))
