@@ -11,7 +11,8 @@ ctxs = {}
 for f in ("1", "2", "3", "0"):
     os.environ["PVIO_HIP_LK_FORM"] = f
     ctxs[f] = HipContext(device=0)
-for n_pts in (1500, 150, 300):
+SIZES = [int(a) for a in sys.argv[1:]] or [1500, 150, 300]  # (other sizes: the crossover of the launch rule)
+for n_pts in SIZES:
     img0, img1, p, truth, init = synth.make_image_pair(512, 512, n_pts)
     imgs = {f: (HipImage(c, img0), HipImage(c, img1)) for f, c in ctxs.items()}
     for f, c in ctxs.items():
