@@ -75,7 +75,8 @@ typedef struct pvio_hip_opts {
     /* the landmark role of k_linearize: 0 = choose by window size (register 3x3 tiles on the FP64 VALU, a landmark chunk per
      * workgroup, below 40 000 reprojection factors; from there on the large-window role -- chunks of 256 factors walked by
      * workgroups that keep their accumulators, Schur complement on 16x16 f64 MFMA tiles), 1 = always the register tiles,
-     * 2 = always the large-window role (tests).  Results agree within rounding (another summation order). */
+     * 2 = always the large-window role (tests; a window without landmarks has nothing for it to walk and takes the register
+     * tiles' empty walk).  Results agree within rounding (another summation order). */
     int32_t linearize_mode;
     /* tests only: run the landmark-sharded code path (eager launches, the all-reduces through the communicator given to
      * pvio_hip_comm_init, the reduced system assembled from the all-reduced buffer) even with world_size == 1 -- a one-rank
