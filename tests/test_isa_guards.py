@@ -14,14 +14,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIPCC = "/opt/rocm/bin/hipcc"
 
 
+_ISA_TEXT = {}  # source -> ISA text: a file is compiled once per run, whatever the number of kernels looked at
+
+
 def _kernel_isa(tmp_path, source, mangled_prefix):
     if not os.path.exists(HIPCC):
         pytest.skip("no hipcc")
-    out = str(tmp_path / "k.s")
-    subprocess.check_call([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"), "--cuda-device-only", "-S", "-o", out,
-                           os.path.join(ROOT, "pvio_amd", "csrc", source)], stderr=subprocess.DEVNULL)
+    if source not in _ISA_TEXT:
+        out = str(tmp_path / "k.s")
+        subprocess.check_call([HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"), "--cuda-device-only", "-S", "-o", out,
+                               os.path.join(ROOT, "pvio_amd", "csrc", source)], stderr=subprocess.DEVNULL)
+        _ISA_TEXT[source] = open(out).read().splitlines(True)
     body, on = [], False
-    for line in open(out):
+    for line in _ISA_TEXT[source]:
         if not on and line.startswith(mangled_prefix) and line.rstrip().split(";")[0].rstrip().endswith(":"):
             on = True
         if on:
